@@ -1,0 +1,51 @@
+"""numpy restatement of the prefill attention math (TEST INFRASTRUCTURE ONLY).
+
+PARITY UNPINNED against the third-party kernel the reference actually calls
+(flash_attn==2.7.4.post1 via transformers 4.50/4.53 ``_flash_attention_forward``;
+call sites /root/reference/qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py:900,
+/root/reference/llava-ov-15/llavaonevision1_5/modeling_llavaonevision1_5.py:686 and
+/root/reference/qwen-vl-finetune/qwenvl/train/trainer.py:101).  flash_attn is not in
+/root/reference and no reference test pins attention outputs.  This oracle follows the
+reference's in-tree EAGER formula instead
+(/root/reference/qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py:777-791: repeat_kv,
+QK^T/sqrt(d), + causal mask, fp32 softmax, PV) and the var-len contract of
+trainer.py:79-113 (cu_seqlens delimit independent causal sequences; q and k share them).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+def varlen_attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, cu_seqlens: np.ndarray,
+                     causal: bool = True, softmax_scale: float | None = None) -> np.ndarray:
+    """q [T,Hq,d], k/v [T,Hkv,d], cu_seqlens [S+1] -> out [T,Hq,d], fp64 math.
+
+    GQA: query head h reads kv head h // (Hq // Hkv)  (repeat_kv, modeling_qwen2_5_vl.py:693-702).
+    """
+    q = np.asarray(q, np.float64)
+    k = np.asarray(k, np.float64)
+    v = np.asarray(v, np.float64)
+    t, hq, d = q.shape
+    hkv = k.shape[1]
+    rep = hq // hkv
+    scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(d)   # :783
+    out = np.zeros_like(q)
+    cu = [int(c) for c in cu_seqlens]
+    for s in range(len(cu) - 1):
+        a, b = cu[s], cu[s + 1]
+        if b <= a:
+            continue
+        n = b - a
+        for h in range(hq):
+            kk = k[a:b, h // rep, :]
+            vv = v[a:b, h // rep, :]
+            w = (q[a:b, h, :] @ kk.T) * scale                                     # :783
+            if causal:
+                w = np.where(np.tril(np.ones((n, n), bool)), w, -np.inf)          # :785-787
+            w = w - w.max(axis=1, keepdims=True)
+            p = np.exp(w)
+            p /= p.sum(axis=1, keepdims=True)                                     # :795 softmax fp32 (here fp64)
+            out[a:b, h, :] = p @ vv                                               # :797
+    return out

@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference's own modules.
+
+Runs only in the build container (needs /root/reference); the GPU box and the test-suite only read
+the committed ``*.npz`` files.  Nothing from the reference is copied: the script calls the
+reference's functions on seeded inputs (oracle/inputs.py) and stores inputs' seeds + outputs.
+
+What is executed from the reference (paths under /root/reference):
+  * qwen-vl-finetune/compression_method/selector_scorer.py   TransformerScorer.forward
+  * qwen-vl-finetune/compression_method/selector_model.py    topk/TopK/_find_ts and
+        qwen25vl_vision_tower_forward_selector (the training LIS block, lines 158-173) run on a
+        stub vision tower whose patch_embed/blocks/merger are identities
+  * qwen-evaluation/token_compression/selector_model.py      Qwen2_5_VisionTransformerPretrainedModel_Selector.forward
+        (inference LIS block, lines 182-194) on the same stub, and
+        Qwen2_5_VLForConditionalGeneration_Selector.forward (splice, lines 243-320) on a stub LLM that
+        records what it is handed; get_rope_index is the vendored one
+        (qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py:1550).
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import importlib.machinery
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from oracle import inputs as oin  # noqa: E402
+
+torch.set_grad_enabled(True)
+IMAGE_TOKEN, VIDEO_TOKEN, VSTART, VEND = 151655, 151656, 151652, 151653
+
+
+def _purge(prefixes):
+    for k in [k for k in sys.modules if k.split(".")[0] in prefixes]:
+        del sys.modules[k]
+
+
+def load_ft():
+    sys.path.insert(0, f"{REF}/qwen-vl-finetune")
+    from compression_method import selector_model as ft
+    from compression_method.selector_scorer import TransformerScorer
+    sys.path.remove(f"{REF}/qwen-vl-finetune")
+    _purge({"compression_method"})
+    return ft, TransformerScorer
+
+
+def load_ev():
+    for name in ("flash_attn", "flash_attn.bert_padding", "flash_attn.layers", "flash_attn.layers.rotary"):
+        m = types.ModuleType(name)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        m.__path__ = []
+        sys.modules[name] = m
+    fa = sys.modules["flash_attn"]
+    fa.flash_attn_func = fa.flash_attn_varlen_func = None
+    bp = sys.modules["flash_attn.bert_padding"]
+    bp.index_first_axis = bp.pad_input = bp.unpad_input = None
+    sys.modules["flash_attn.layers.rotary"].apply_rotary_emb = None
+    sys.path.insert(0, f"{REF}/qwen-evaluation")
+    from token_compression import selector_model as ev
+    sys.path.remove(f"{REF}/qwen-evaluation")
+    return ev
+
+
+class StubTower:
+    """Identity vision tower around the reference's LIS block."""
+
+    def __init__(self, scorer, budgets, n, training):
+        self.importance_scorer = scorer
+        self.budgets = budgets
+        self.n = n
+        self.spatial_merge_unit = 1
+        self.blocks = []
+        self.fullatt_block_indexes = []
+        self.gradient_checkpointing = False
+        self.training = training
+
+    def patch_embed(self, x):
+        return x
+
+    def rot_pos_emb(self, grid):
+        return torch.zeros(self.n, 2)
+
+    def get_window_index(self, grid):
+        return torch.arange(self.n), [0, self.n]
+
+    def merger(self, x):
+        return x
+
+
+def build_scorer(TransformerScorer, case):
+    hd, d = case["wq"].shape
+    m = TransformerScorer(in_features=d, hidden_dim=hd)
+    with torch.no_grad():
+        m.q_proj.weight.copy_(torch.from_numpy(case["wq"]))
+        m.q_proj.bias.copy_(torch.from_numpy(case["bq"]))
+        m.k_proj.weight.copy_(torch.from_numpy(case["wk"]))
+        m.k_proj.bias.copy_(torch.from_numpy(case["bk"]))
+    return m
+
+
+def gen_lis_case(name, d, hd, n, seed, ft, ev, TransformerScorer):
+    case = oin.make_case(d, hd, n, seed)
+    scorer = build_scorer(TransformerScorer, case)
+    h = torch.from_numpy(case["h"])
+    grid = torch.tensor([[1, 1, n]])
+    out = {"d": d, "hd": hd, "n": n, "seed": seed}
+
+    # ---- inference (EV) -------------------------------------------------------------------------
+    for r in oin.BUDGETS:
+        stub = StubTower(scorer, r, n, training=False)
+        with torch.no_grad():
+            h_new, idx, total = ev.Qwen2_5_VisionTransformerPretrainedModel_Selector.forward(stub, h, grid)
+        tag = str(r).replace(".", "p")
+        out[f"idx_{tag}"] = idx.numpy().astype(np.int64)
+        out[f"ps_{tag}"] = stub.last_combined_scores.numpy().astype(np.float32)
+        assert total == n and torch.equal(h_new, h[idx])
+        assert torch.equal(stub.last_selected_indices, idx)
+    with torch.no_grad():
+        scores = scorer(h[None])[0]
+    out["scores"] = scores.numpy().astype(np.float32)
+    srt = np.sort(out["scores"])[::-1]
+    out["gaps"] = np.array([srt[max(1, int(n * r)) - 1] - srt[max(1, int(n * r))] for r in oin.BUDGETS], np.float32)
+    out["score_std"] = np.float32(out["scores"].std())
+
+    # ---- differentiable top-k in isolation (FT) -------------------------------------------------
+    k = int(n * 0.2)
+    xs = scores[None].clone().requires_grad_(True)
+    ps = ft.topk(xs, k)
+    g = torch.from_numpy(oin.make_vec(n, seed + 1000))[None]
+    ps.backward(g)
+    with torch.no_grad():
+        ts, _ = ft._find_ts(scores[None], k)
+    out["topk_k"] = k
+    out["topk_ps"] = ps.detach().numpy()[0].astype(np.float32)
+    out["topk_ts"] = np.float32(ts.item())
+    out["topk_grad"] = xs.grad.numpy()[0].astype(np.float32)
+
+    # ---- training LIS block + constraint loss + backward (FT) -----------------------------------
+    reg_w = 0.7
+    stub = StubTower(scorer, 0.2, n, training=True)
+    for p in scorer.parameters():
+        p.grad = None
+    hg = h.clone().requires_grad_(True)
+    h_new, img_mask, cmask = ft.qwen25vl_vision_tower_forward_selector(stub, hg, grid)
+    gmat = torch.from_numpy(
+        np.random.default_rng(seed + 2000).standard_normal((n, d), dtype=np.float32) / np.float32(d) ** 0.5)
+    bce = F.binary_cross_entropy(img_mask, cmask)            # FT/.../selector_model.py:310
+    loss = (h_new * gmat).sum() + reg_w * bce                # :311 with a linear stand-in for the LLM loss
+    loss.backward()
+    out["train_reg_w"] = np.float32(reg_w)
+    out["train_ps"] = img_mask.detach().numpy().astype(np.float32)
+    out["train_y"] = cmask.numpy().astype(np.float32)
+    out["train_bce"] = np.float32(bce.item())
+    out["train_loss"] = np.float32(loss.item())
+    out["train_hnew_rowsum"] = h_new.detach().double().sum(1).numpy()
+    u_d = oin.make_vec(d, seed + 3000).astype(np.float64)
+    v_h = oin.make_vec(hd, seed + 3001).astype(np.float64)
+    v_n = oin.make_vec(n, seed + 3002).astype(np.float64)
+    gq = scorer.q_proj.weight.grad.double().numpy()
+    gk = scorer.k_proj.weight.grad.double().numpy()
+    gx = hg.grad.double().numpy()
+    out["dbq"] = scorer.q_proj.bias.grad.numpy().astype(np.float32)
+    out["dbk"] = scorer.k_proj.bias.grad.numpy().astype(np.float32)
+    out["dwq_u"] = gq @ u_d
+    out["v_dwq"] = v_h @ gq
+    out["dwk_u"] = gk @ u_d
+    out["v_dwk"] = v_h @ gk
+    out["dx_u"] = gx @ u_d
+    out["v_dx"] = v_n @ gx
+    if n * d <= 4096:
+        out["dwq"] = gq.astype(np.float32)
+        out["dwk"] = gk.astype(np.float32)
+        out["dx"] = gx.astype(np.float32)
+        out["train_hnew"] = h_new.detach().numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, f"lis_{name}.npz"), **out)
+    print(f"{name}: N={n} gaps/std={out['gaps'] / out['score_std']} bce={out['train_bce']:.6f} ts={out['topk_ts']:.6f}")
+
+
+# ---------------------------------------------------------------------------------------------------
+# splice goldens
+# ---------------------------------------------------------------------------------------------------
+
+
+def embed_fn(ids, d_llm):
+    """Deterministic exact-in-fp32 stand-in for embed_tokens (the test recomputes it in numpy)."""
+    ar = torch.arange(d_llm, dtype=torch.int64)
+    return (((ids[..., None] * 31 + ar * 17) % 257).float() / 257.0)
+
+
+class RecordingLLM:
+    def __init__(self, d_llm):
+        self.d_llm = d_llm
+        self.seen = None
+
+    def embed_tokens(self, ids):
+        return embed_fn(ids, self.d_llm)
+
+    def __call__(self, **kw):
+        self.seen = kw
+        hs = kw["inputs_embeds"]
+        o = types.SimpleNamespace(past_key_values=None, hidden_states=None, attentions=None)
+        return _Out(hs, o)
+
+
+class _Out:
+    def __init__(self, hs, ns):
+        self._hs = hs
+        self.past_key_values = None
+        self.hidden_states = None
+        self.attentions = None
+
+    def __getitem__(self, i):
+        assert i == 0
+        return self._hs
+
+
+def gen_splice_case(name, ev, kind, n_visual, grid, n_pre, n_post, k, seed, d_llm=32):
+    vis_id = IMAGE_TOKEN if kind == "image" else VIDEO_TOKEN
+    ids = torch.from_numpy(oin.make_prompt(n_visual, n_pre, n_post, vis_id, seed))
+    rng = np.random.default_rng(seed + 1)
+    all_idx = np.sort(rng.choice(n_visual, size=k, replace=False)).astype(np.int64)
+    vis_embeds = rng.standard_normal((k, d_llm), dtype=np.float32)
+
+    class Visual:
+        dtype = torch.float32
+
+        def __call__(self, pixels, grid_thw=None):
+            return torch.from_numpy(vis_embeds), torch.from_numpy(all_idx), n_visual
+
+    cfg = types.SimpleNamespace(
+        output_attentions=False, output_hidden_states=False, use_return_dict=True,
+        image_token_id=IMAGE_TOKEN, video_token_id=VIDEO_TOKEN, vision_start_token_id=VSTART, vocab_size=8,
+        vision_config=types.SimpleNamespace(spatial_merge_size=2, tokens_per_second=2))
+    llm = RecordingLLM(d_llm)
+    stub = types.SimpleNamespace(config=cfg, model=llm, visual=Visual(), rope_deltas=None,
+                                 lm_head=lambda x: x[..., :8], base_model=types.SimpleNamespace(layers=[]))
+    base = ev.Qwen2_5_VLForConditionalGeneration_Selector.__mro__[1]
+    stub.get_rope_index = types.MethodType(base.get_rope_index, stub)
+    grid_t = torch.tensor([grid])
+    kw = dict(input_ids=ids, attention_mask=torch.ones_like(ids), cache_position=torch.arange(ids.shape[1]))
+    if kind == "image":
+        kw.update(pixel_values=torch.zeros(1, 1), image_grid_thw=grid_t)
+    else:
+        kw.update(pixel_values_videos=torch.zeros(1, 1), video_grid_thw=grid_t,
+                  second_per_grid_ts=torch.tensor([1.0]))
+    with torch.no_grad():
+        ev.Qwen2_5_VLForConditionalGeneration_Selector.forward(stub, **kw)
+    seen = llm.seen
+    out = dict(kind=kind, n_visual=n_visual, grid=np.array(grid), n_pre=n_pre, n_post=n_post, k=k, seed=seed,
+               d_llm=d_llm, all_idx=all_idx, vis_embeds=vis_embeds,
+               position_ids_full=stub.get_rope_index(
+                   ids, grid_t if kind == "image" else None, grid_t if kind == "video" else None,
+                   torch.tensor([1.0]) if kind == "video" else None, torch.ones_like(ids))[0].numpy(),
+               position_ids=seen["position_ids"].numpy(), attention_mask=seen["attention_mask"].numpy(),
+               inputs_embeds=seen["inputs_embeds"].numpy(), rope_deltas=stub.rope_deltas.numpy())
+    np.savez_compressed(os.path.join(HERE, f"splice_{name}.npz"), **out)
+    print(f"splice {name}: L={ids.shape[1]} -> L'={seen['inputs_embeds'].shape[1]}")
+
+
+def main():
+    ft, TransformerScorer = load_ft()
+    ev = load_ev()
+    torch.manual_seed(0)
+    for name, d, hd, n, seed in oin.GOLDEN_CASES:
+        gen_lis_case(name, d, hd, n, seed, ft, ev, TransformerScorer)
+    gen_splice_case("image_a", ev, "image", 64, (1, 16, 16), 7, 12, 12, 21)
+    gen_splice_case("image_b", ev, "image", 256, (1, 32, 32), 20, 33, 51, 22)
+    gen_splice_case("video_a", ev, "video", 128, (2, 16, 16), 9, 14, 25, 23)
+
+
+if __name__ == "__main__":
+    main()

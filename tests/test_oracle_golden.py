@@ -1,0 +1,176 @@
+"""The numpy oracle (oracle/) against vectors produced by the reference itself
+(tests/golden/make_golden.py imports /root/reference; only the .npz files are read here)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import inputs as oin
+from oracle import lis, splice
+
+CASES = {c[0]: c for c in oin.GOLDEN_CASES}
+IMAGE_TOKEN, VIDEO_TOKEN = 151655, 151656
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, f"lis_{name}.npz"))
+
+
+@pytest.fixture(scope="module")
+def cases():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            _, d, hd, n, seed = CASES[name]
+            cache[name] = oin.make_case(d, hd, n, seed)
+        return cache[name]
+
+    return get
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_scores_reference_formulation(golden_dir, cases, name):
+    g = load(golden_dir, name)
+    c = cases(name)
+    s = lis.scorer_reference(c["h"][None], c["wq"], c["bq"], c["wk"], c["bk"])[0]
+    # fp32 GEMM summation order differs between OpenBLAS and torch's CPU BLAS: a few ulp of the score scale
+    assert np.abs(s - g["scores"]).max() <= 2e-6 * max(1.0, np.abs(g["scores"]).max())
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_scores_collapsed_equals_reference(golden_dir, cases, name):
+    g = load(golden_dir, name)
+    c = cases(name)
+    s = lis.scorer_collapsed(c["h"][None], c["wq"], c["bq"], c["wk"], c["bk"])[0]
+    assert np.abs(s - g["scores"]).max() <= 2e-6 * max(1.0, np.abs(g["scores"]).max())
+    for r in oin.BUDGETS:
+        k = lis.budget_k_eval(c["h"].shape[0], r)
+        assert np.array_equal(lis.hard_topk_indices(s.astype(np.float32), k), g["idx_" + str(r).replace(".", "p")])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_hard_topk_indices(golden_dir, name):
+    g = load(golden_dir, name)
+    n = int(g["n"])
+    for r in oin.BUDGETS:
+        k = lis.budget_k_eval(n, r)
+        idx = lis.hard_topk_indices(g["scores"], k)
+        ref = g["idx_" + str(r).replace(".", "p")]
+        assert idx.dtype == np.int64 and idx.shape == (k,)
+        assert np.array_equal(idx, ref)           # bit-exact: golden seeds are tie-free at the boundary
+        assert np.all(np.diff(idx) > 0)
+
+
+def test_budget_truncation():
+    # int() of a Python double, SURVEY.md section 7 hard part 3
+    assert lis.budget_k_eval(2304, 0.2) == 460
+    assert lis.budget_k_eval(576, 0.2) == 115
+    assert lis.budget_k_eval(256, 0.2) == 51
+    assert lis.budget_k_eval(3, 0.1) == 1 and lis.budget_k_train(3, 0.1) == 0
+    assert lis.budget_k_eval(5832, 0.2) == 1166
+
+
+def test_hard_topk_ties_and_specials():
+    s = np.array([1, 2, 2, 2, 2, 2, 0, 2, 2, 3], np.float32)
+    assert lis.hard_topk_indices(s, 5).tolist() == [1, 2, 3, 4, 9]     # lowest index wins among the tied 2s
+    s = np.array([0.0, -0.0, np.nan, -np.inf, np.inf, -1.0], np.float32)
+    assert lis.hard_topk_indices(s, 2).tolist() == [2, 4]              # NaN is greatest (torch.topk convention)
+    assert lis.hard_topk_indices(s, 4).tolist() == [0, 1, 2, 4]        # -0.0 == +0.0, index order
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_soft_topk_forward_backward(golden_dir, name):
+    g = load(golden_dir, name)
+    k = int(g["topk_k"])
+    ts, ps = lis.find_ts(g["scores"][None], k)
+    assert abs(float(ts[0, 0]) - float(g["topk_ts"])) <= 2e-5
+    assert np.abs(ps[0] - g["topk_ps"]).max() <= 1e-5
+    assert abs(ps.sum() - k) <= 1e-2
+    gvec = oin.make_vec(int(g["n"]), int(g["seed"]) + 1000)[None]
+    grad = lis.soft_topk_backward(gvec, g["scores"][None], np.float32(g["topk_ts"]))[0]
+    assert np.abs(grad - g["topk_grad"]).max() <= 1e-5 * max(1.0, np.abs(g["topk_grad"]).max())
+    # inference path also fills last_combined_scores with the soft mask (EV :190), k = max(1, int(N r))
+    for r in oin.BUDGETS:
+        kk = lis.budget_k_eval(int(g["n"]), r)
+        assert np.abs(lis.soft_topk(g["scores"][None], kk)[0] - g["ps_" + str(r).replace(".", "p")]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["tiny", "qwen3b_256", "qwen3b_576", "qwen7b_2304"])
+def test_train_forward_and_loss(golden_dir, cases, name):
+    g = load(golden_dir, name)
+    c = cases(name)
+    h_new, ps, y, scores, ts = lis.train_forward(c["h"], c["wq"], c["bq"], c["wk"], c["bk"], 0.2)
+    assert np.array_equal(y, g["train_y"])
+    assert np.abs(ps - g["train_ps"]).max() <= 1e-5
+    assert abs(float(lis.bce_mean(ps, y)) - float(g["train_bce"])) <= 1e-5
+    assert np.abs(h_new.astype(np.float64).sum(1) - g["train_hnew_rowsum"]).max() <= 1e-3
+    if "train_hnew" in g.files:
+        assert np.abs(h_new - g["train_hnew"]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["tiny", "qwen3b_256", "qwen3b_576"])
+def test_train_backward_closed_form(golden_dir, cases, name):
+    g = load(golden_dir, name)
+    c = cases(name)
+    _, d, hd, n, seed = CASES[name]
+    gmat = np.random.default_rng(seed + 2000).standard_normal((n, d), dtype=np.float32) / np.float32(d) ** 0.5
+    out = lis.train_backward(c["h"], c["wq"], c["bq"], c["wk"], c["bk"], 0.2, gmat, float(g["train_reg_w"]))
+    u_d = oin.make_vec(d, seed + 3000).astype(np.float64)
+    v_h = oin.make_vec(hd, seed + 3001).astype(np.float64)
+    v_n = oin.make_vec(n, seed + 3002).astype(np.float64)
+
+    def close(a, b, rtol=2e-3):
+        scale = max(np.abs(b).max(), 1e-12)
+        assert np.abs(a - b).max() <= rtol * scale, (np.abs(a - b).max(), scale)
+
+    close(out["dbq"], g["dbq"], rtol=5e-3) if np.abs(g["dbq"]).max() > 1e-6 else None
+    close(out["dbk"], g["dbk"])
+    close(out["dwq"] @ u_d, g["dwq_u"])
+    close(v_h @ out["dwq"], g["v_dwq"])
+    close(out["dwk"] @ u_d, g["dwk_u"])
+    close(v_h @ out["dwk"], g["v_dwk"])
+    close(out["dx"] @ u_d, g["dx_u"])
+    close(v_n @ out["dx"], g["v_dx"])
+    if "dwq" in g.files:
+        close(out["dwq"], g["dwq"])
+        close(out["dwk"], g["dwk"])
+        close(out["dx"], g["dx"])
+    # explicit op-by-op backward agrees with the closed form
+    ex = lis.lis_backward_explicit(c["h"], c["wq"], c["bq"], c["wk"], c["bk"], out["dscores"])
+    cl = lis.lis_backward_closed(c["h"], c["wq"], c["bq"], c["wk"], c["bk"], out["dscores"])
+    for key in ("dwq", "dwk", "dbk", "dx"):
+        close(cl[key], ex[key], rtol=1e-9)
+
+
+def test_curriculum_weight():
+    # FT/qwenvl/train/train_qwen_selector.py:66-79 with the script's 0.1 -> 2.0
+    assert lis.curriculum_weight(0, 100, 0.1, 2.0) == 0.1
+    assert lis.curriculum_weight(50, 100, 0.1, 2.0) == pytest.approx(1.05)
+    assert lis.curriculum_weight(100, 100, 0.1, 2.0) == pytest.approx(2.0)
+    assert lis.curriculum_weight(150, 100, 0.1, 2.0) == pytest.approx(2.0)
+    assert lis.curriculum_weight(5, -1, 0.1, 2.0) == 0.1
+
+
+def _embed_np(ids, d_llm):
+    ar = np.arange(d_llm, dtype=np.int64)
+    return (((ids[..., None] * 31 + ar * 17) % 257).astype(np.float32) / np.float32(257.0))
+
+
+@pytest.mark.parametrize("name", ["image_a", "image_b", "video_a"])
+def test_splice(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"splice_{name}.npz"))
+    kind = str(g["kind"])
+    vis = IMAGE_TOKEN if kind == "image" else VIDEO_TOKEN
+    ids = oin.make_prompt(int(g["n_visual"]), int(g["n_pre"]), int(g["n_post"]), vis, int(g["seed"]))
+    if kind == "image":
+        sel, new_ids = splice.splice_image(ids, vis, g["all_idx"])
+    else:
+        sel, new_ids, timask = splice.splice_video(ids, vis, g["all_idx"])
+        assert timask.sum() == new_ids.shape[1] - int(g["k"])
+    emb = splice.splice_embeds(_embed_np(ids, int(g["d_llm"])), new_ids, sel, vis, g["vis_embeds"])
+    assert np.array_equal(emb, g["inputs_embeds"])
+    pos, am = splice.slice_positions(g["position_ids_full"], np.ones_like(ids), sel)
+    assert np.array_equal(pos, g["position_ids"])
+    assert np.array_equal(am, g["attention_mask"])
+    assert new_ids.shape[1] == ids.shape[1] - int(g["n_visual"]) + int(g["k"])

@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- vision tokens scored+selected per second on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path (fused LIS score + hard top-k + gather, `vsel_lis_select`) over one
+batch of synthetic visual tokens H[B, N, D] that is already resident in HBM.  Workload = BASELINE.json
+configs[1]: Qwen2.5-VL-7B geometry (D=3584, Hd=1792), N_vis=2304 (1344x1344), 20 % retain (k=460).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--images B] [--budget r]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: images are independent units -> each rank processes its own B images,
+no data-path collective ("weak" scaling); only the barrier and the max-over-ranks of the time use RCCL.
+
+Prints ONE JSON line on rank 0 (see the keys at the bottom).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+D, HD, N_VIS = 3584, 1792, 2304
+
+
+def algorithmic_bytes(b, n, d, hd, k, e=2):
+    """tokens read once + kept rows written + weights once + scores + indices."""
+    return b * n * d * e + b * k * d * e + 2 * hd * d * e + 2 * hd * e + b * n * 4 + b * k * 8
+
+
+def kernel_bytes(name, b, n, d, hd, k, e=2):
+    """Algorithmic bytes of ONE launch of a named kernel ('kernels')."""
+    return {
+        "colsum_partial_kernel": b * n * d * e,                    # first sweep of the tokens
+        "score_kernel": b * n * d * e + b * n * 4,                 # second sweep + scores out
+        "gather_rows_kernel": 2 * b * k * d * e + b * k * 8,       # read kept rows + write them
+        "lis_fused_kernel": algorithmic_bytes(b, n, d, hd, k, e),
+    }.get(name)
+
+
+def cpu_baseline(budget, seconds_budget=12.0):
+    """The reference formulation on the host cores (oracle/lis_torch.py = same ATen ops as the reference)."""
+    from oracle import lis_torch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(1234)
+    h = torch.randn(N_VIS, D, generator=g).bfloat16().float()
+    wq = (0.02 * torch.randn(HD, D, generator=g)).bfloat16().float()
+    wk = (0.02 * torch.randn(HD, D, generator=g)).bfloat16().float()
+    bq = (0.02 * torch.randn(HD, generator=g)).bfloat16().float()
+    bk = (0.02 * torch.randn(HD, generator=g)).bfloat16().float()
+    for _ in range(2):
+        lis_torch.select_forward(h, wq, bq, wk, bk, budget)
+    times = []
+    t_end = time.perf_counter() + seconds_budget
+    while len(times) < 40 and (time.perf_counter() < t_end or len(times) < 3):
+        t0 = time.perf_counter()
+        lis_torch.select_forward(h, wq, bq, wk, bk, budget)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": N_VIS / best, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} images of N={N_VIS}, D={D}, Hd={HD}, fp32 reference formulation "
+                      f"(2 GEMMs + NxN matmul + mean + topk + sort + gather), torch CPU {torch.get_num_threads()} threads, best-of",
+            "ms_per_image": best * 1e3, "ms_per_image_median": sorted(times)[len(times) // 2] * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--images", type=int, default=64, help="images per step per GPU (B)")
+    ap.add_argument("--budget", type=float, default=0.2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-attn", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+
+    from visionselector_amd import _native, ops
+
+    b, n, d, hd = args.images, N_VIS, D, HD
+    k = max(1, int(n * args.budget))
+    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    h = torch.randn(b, n, d, device="cuda", generator=gen).bfloat16()
+    wq = (0.02 * torch.randn(hd, d, device="cuda", generator=gen)).bfloat16()
+    wk = (0.02 * torch.randn(hd, d, device="cuda", generator=gen)).bfloat16()
+    bq = (0.02 * torch.randn(hd, device="cuda", generator=gen)).bfloat16()
+    bk = (0.02 * torch.randn(hd, device="cuda", generator=gen)).bfloat16()
+
+    def step():
+        return ops.lis_select(h, wq, bq, wk, bk, k)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    _native.profile_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, idx, scores = step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    prof = _native.profile_stop()
+    if dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    if dist:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * b * n / (elapsed / args.steps)
+
+    # ---- parity gate on the timed data (one image, fp64 collapsed oracle on the host) ----------------
+    parity = None
+    if rank == 0:
+        import numpy as np
+        from oracle import lis as olis
+        f = lambda t: t.float().cpu().numpy()  # noqa: E731
+        ref = olis.scorer_collapsed(f(h[0])[None], f(wq), f(bq), f(wk), f(bk))[0]
+        s0 = scores[0].cpu().numpy()
+        ridx = olis.hard_topk_indices(ref.astype(np.float32), k)
+        parity = {"max_abs_dscore": float(np.abs(s0 - ref).max()),
+                  "idx_equal_fp64_oracle": bool(np.array_equal(ridx, idx[0].cpu().numpy())),
+                  "idx_equal_own_scores": bool(np.array_equal(olis.hard_topk_indices(s0, k), idx[0].cpu().numpy())),
+                  "gather_exact": bool(torch.equal(out[0], h[0][idx[0]]))}
+
+    if rank != 0:
+        if dist:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (HIP events recorded by libvsel on the launch stream) -------
+    kern = {name: {"avg_us": ms / calls * 1e3, "launches_per_step": calls / args.steps, "share": 0.0}
+            for name, (ms, calls) in prof.items()}
+    tot_ms = sum(ms for ms, _ in prof.values()) or 1.0
+    for name, (ms, _) in prof.items():
+        kern[name]["share"] = ms / tot_ms
+    dom = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else None
+    roofline = None
+    if dom is not None:
+        kb = kernel_bytes(dom, b, n, d, hd, k)
+        avg_s = prof[dom][0] / prof[dom][1] * 1e-3
+        ach = (kb / avg_s / 1e9) if kb else None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None,
+                    "algorithmic_bytes_per_launch": kb, "avg_launch_us": avg_s * 1e6,
+                    "note": "achieved = algorithmic bytes of this kernel / its HIP-event duration; traffic (PMC) in profiles/"}
+    path_bytes = algorithmic_bytes(b, n, d, hd, k)
+    path = {"algorithmic_bytes_per_step": path_bytes, "achieved_GBps": path_bytes / (ms_per_step * 1e-3) / 1e9,
+            "frac_of_8TBps": path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    res = {
+        "metric": "vision_tokens_scored_selected_per_sec", "value": value, "unit": "tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "accumulate": "f32",
+        "data": "synthetic",
+        "config": {"workload": "Qwen2.5-VL-7B LIS score + hard top-k + gather (vsel_lis_select), N_vis=2304, D=3584, "
+                               "Hd=1792, 20% retain (k=460)" if args.budget == 0.2 else
+                               f"Qwen2.5-VL-7B LIS select, N_vis=2304, D=3584, Hd=1792, budget={args.budget} (k={k})",
+                   "images_per_step_per_gpu": b, "n_vis": n, "d": d, "hd": hd, "k": k, "budget": args.budget,
+                   "sharding": f"{world} independent replicas, one process per GPU, no data-path collective"},
+        "roofline": roofline, "roofline_path": path, "kernels": kern, "parity": parity,
+    }
+
+    # ---- prefill attention at the compressed vs the full length (second half of the metric) ----------
+    if not args.no_attn:
+        try:
+            res["prefill_attention"] = bench_attention(ops, k)
+        except Exception as e:  # the attention kernel is optional for this line
+            res["prefill_attention"] = {"error": str(e)[:200]}
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(args.budget)
+        res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+    print(json.dumps(res))
+    if dist:
+        dist.destroy_process_group()
+
+
+def bench_attention(ops, k, text=64, hq=28, hkv=4, dh=128, layers=28, iters=20):
+    """Var-len causal GQA attention (Qwen2.5-VL-7B geometry) at L' = k + 64 vs L = N + 64, one sequence."""
+    out = {}
+    for tag, L in (("retain20", k + text), ("full", N_VIS + text)):
+        gen = torch.Generator(device="cuda").manual_seed(7)
+        q = torch.randn(L, hq, dh, device="cuda", generator=gen).bfloat16()
+        kk = torch.randn(L, hkv, dh, device="cuda", generator=gen).bfloat16()
+        v = torch.randn(L, hkv, dh, device="cuda", generator=gen).bfloat16()
+        cu = torch.tensor([0, L], dtype=torch.int32, device="cuda")
+        for _ in range(3):
+            ops.varlen_attn(q, kk, v, cu, L)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.varlen_attn(q, kk, v, cu, L)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        flops = 4.0 * L * L * hq * dh / 2
+        out[tag] = {"L": L, "ms_per_layer": ms, "ms_28_layers": ms * layers, "tflops": flops / (ms * 1e-3) / 1e12}
+    out["speedup"] = out["full"]["ms_per_layer"] / out["retain20"]["ms_per_layer"]
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+/*
+ * vsel.h -- C-ABI of libvsel.so, the MI355X (gfx950) implementation of the VisionSelector hot path.
+ *
+ * Plain pointers and sizes only: no torch / HIP types in the signatures.  Every device pointer is a
+ * raw HBM address (torch: tensor.data_ptr()), `stream` is a hipStream_t passed as void* (torch:
+ * torch.cuda.current_stream().cuda_stream; NULL = the default stream).  All calls are asynchronous
+ * on `stream`; none synchronises.  Return value: 0 = ok, otherwise a vsel_status; the message is
+ * available from vsel_last_error() (thread-local).  Kernels are deterministic (no float atomics).
+ *
+ * Each entry point names the reference interface it replaces (paths under the reference repo;
+ * FT = qwen-vl-finetune, EV = qwen-evaluation, OV = llava-ov-15).
+ */
+#ifndef VSEL_H
+#define VSEL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  VSEL_OK = 0,
+  VSEL_ERR_INVALID = 1,      /* bad argument (shape, alignment, k out of range, null pointer) */
+  VSEL_ERR_WORKSPACE = 2,    /* workspace too small: call the matching *_workspace_bytes()       */
+  VSEL_ERR_HIP = 3,          /* a HIP runtime call / launch failed                               */
+  VSEL_ERR_UNSUPPORTED = 4   /* shape outside what the kernels implement                         */
+} vsel_status;
+
+typedef enum {
+  VSEL_BF16 = 0,             /* tokens / weights stored as bfloat16                              */
+  VSEL_F32 = 1               /* tokens / weights stored as float32                               */
+} vsel_dtype;
+
+const char* vsel_version(void);
+const char* vsel_last_error(void);
+
+/* Measurement hook (no reference counterpart; the reference times with torch.cuda.Event around the whole
+ * forward, EV/token_compression/selector_model.py:228-234,353-359).  Between start and stop every kernel
+ * libvsel launches is bracketed by HIP events recorded on the launch stream.  stop() synchronises the last
+ * event and returns, per kernel name (comma-joined into `names`), the summed elapsed ms and launch count. */
+int vsel_profile_start(void);
+int vsel_profile_stop(char* names, size_t names_len, float* total_ms, int64_t* calls, int max_entries, int* n_entries);
+
+/* ---------------------------------------------------------------------------------------------
+ * Segments.  The token tensor is H[T, D] row-major.  A call scores `n_seg` independent segments
+ * ("calls" of the reference: one image, or all images of a sample jointly -- the mean over tokens
+ * in TransformerScorer.forward is over one segment):
+ *   uniform:  seg_rows == NULL, every segment has `rows_per_seg` rows  (H viewed as [B, N, D])
+ *   ragged :  seg_rows = DEVICE int32[n_seg + 1] row offsets (cu_seqlens style), seg_out = DEVICE
+ *             int32[n_seg + 1] offsets of the kept rows (cumsum of k_s); `rows_per_seg` = max rows,
+ *             `k` = max k_s.  k_s is computed on the host exactly as the reference does:
+ *             max(1, int(N_s * budgets)) (EV/token_compression/selector_model.py:186).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t n_seg;           /* B                                                  */
+  int64_t rows_per_seg;    /* N (uniform) or max_s N_s (ragged)                  */
+  int64_t total_rows;      /* T = sum_s N_s                                      */
+  int64_t k;               /* kept rows per segment (uniform) or max_s k_s       */
+  int64_t total_out;       /* sum_s k_s                                          */
+  const int32_t* seg_rows; /* DEVICE, or NULL for uniform                        */
+  const int32_t* seg_out;  /* DEVICE, or NULL for uniform                        */
+} vsel_segments;
+
+/* Scorer parameters: TransformerScorer.{q_proj,k_proj}.{weight [Hd, D], bias [Hd]}
+ * (FT/compression_method/selector_scorer.py:12-22), all of dtype `wdtype`, contiguous. */
+typedef struct {
+  const void* wq;
+  const void* bq;
+  const void* wk;
+  const void* bk;
+  int64_t d;               /* in_features  D                                     */
+  int64_t hd;              /* hidden_dim   Hd                                    */
+  vsel_dtype wdtype;
+} vsel_scorer;
+
+/* -------- inference: score + hard top-k + gather ------------------------------------------------
+ * Replaces, in one call, EV/token_compression/selector_model.py:184-189
+ *   learned_scores = importance_scorer(hidden_states[None])           (selector_scorer.py:34-55)
+ *   all_indices    = learned_scores.topk(k).indices.sort().values
+ *   hidden_new     = hidden_states[all_indices, :]
+ * (same lines in OV/compression_method/modeling_selector.py:173-180).
+ *   h      [T, D]  dtype `hdtype`
+ *   out    [total_out, D] same dtype          (kept rows, segment-major, ascending index inside)
+ *   idx    int64 [total_out]                  (index LOCAL to the segment, ascending)
+ *   scores float32 [T]                        (the learned scores, fp32 accumulate)
+ * Tie rule: larger score first, equal scores -> lower index first; NaN sorts greatest.          */
+size_t vsel_lis_workspace_bytes(const vsel_segments* seg, int64_t d, int64_t hd);
+int vsel_lis_select(void* stream, const void* h, vsel_dtype hdtype, const vsel_segments* seg,
+                    const vsel_scorer* scorer, void* workspace, size_t workspace_bytes,
+                    void* out, int64_t* idx, float* scores);
+
+/* Scores only: TransformerScorer.forward (FT/compression_method/selector_scorer.py:34-55).      */
+int vsel_lis_scores(void* stream, const void* h, vsel_dtype hdtype, const vsel_segments* seg,
+                    const vsel_scorer* scorer, void* workspace, size_t workspace_bytes, float* scores);
+
+/* Hard top-k on given scores: scores.topk(k).indices.sort().values
+ * (EV/token_compression/selector_model.py:187-188).  Optionally also writes the 0/1 constraint mask
+ * of FT/compression_method/selector_model.py:168-171 (mask may be NULL).                         */
+int vsel_topk_select(void* stream, const float* scores, const vsel_segments* seg, int64_t* idx, float* mask);
+
+/* Row gather hidden_states[idx, :] (EV/token_compression/selector_model.py:189).                 */
+int vsel_gather_rows(void* stream, const void* h, vsel_dtype hdtype, int64_t d, const vsel_segments* seg,
+                     const int64_t* idx, void* out);
+
+/* -------- differentiable top-k ------------------------------------------------------------------
+ * TopK.forward / _find_ts (FT/compression_method/selector_model.py:53-58,72-86): 64 bisection steps
+ * for t with sum(sigmoid(x + t)) = k, fp32.  xs [B, N] float32 -> ps [B, N], ts [B].
+ * Reference asserts 0 < k < N (:75) -> VSEL_ERR_INVALID.                                          */
+int vsel_soft_topk_fwd(void* stream, const float* xs, int64_t b, int64_t n, int64_t k, float* ps, float* ts);
+/* TopK.backward (FT/compression_method/selector_model.py:60-70).                                  */
+int vsel_soft_topk_bwd(void* stream, const float* grad_ps, const float* xs, const float* ts, int64_t b, int64_t n,
+                       float* grad_xs);
+
+/* -------- training LIS block --------------------------------------------------------------------
+ * Forward of FT/compression_method/selector_model.py:158-173 (OV/compression_method/selector_model.py:127-142)
+ * for ONE segment (the reference scores all images of the micro-batch jointly):
+ *   scores = scorer(h); k given (host: int(N * budgets)); ps = topk(scores, k); h_new = (ps[:,None] * h).type(dtype)
+ *   y = scatter(zeros, scores.topk(k).indices, 1);  bce = mean BCE(ps, y) with ATen's log clamp at -100 (:310)
+ * Outputs: h_new [N, D] (hdtype), ps [N], y [N], scores [N], ts [1], bce [1]  (all float32 but h_new). */
+size_t vsel_lis_train_workspace_bytes(int64_t n, int64_t d, int64_t hd);
+int vsel_lis_train_fwd(void* stream, const void* h, vsel_dtype hdtype, int64_t n, int64_t k, const vsel_scorer* scorer,
+                       void* workspace, size_t workspace_bytes, void* h_new, float* ps, float* y, float* scores,
+                       float* ts, float* bce);
+/* Backward of the same block.  The gradient reaching ps is
+ *     dps_i = sum_d d_hnew[i,d] * h[i,d]  +  d_ps_ext[i]  +  dl_dbce * dBCE/dps_i
+ *   d_ps_ext (nullable): gradient that arrived at ps from outside the block (the drop-in path calls
+ *     F.binary_cross_entropy(img_mask, constraint_img_mask) in torch, FT/.../selector_model.py:310);
+ *   dl_dbce: weight of the fused BCE term (the native trainer passes regularization_weight, else 0).
+ *   out: dwq [Hd, D], dbq [Hd], dwk [Hd, D], dbk [Hd] float32 (overwritten); dh [N, D] (hdtype) or NULL.
+ * Uses the closed form of autograd through selector_scorer.py:47-53 and TopK.backward (:60-70):
+ * both weight gradients are rank-1 (SURVEY.md section 7 hard part 4).                              */
+int vsel_lis_train_bwd(void* stream, const void* d_hnew, const void* h, vsel_dtype hdtype, int64_t n,
+                       const vsel_scorer* scorer, const float* ps, const float* y, const float* scores,
+                       const float* ts, const float* d_ps_ext, float dl_dbce, void* workspace,
+                       size_t workspace_bytes, float* dwq, float* dbq, float* dwk, float* dbk, void* dh);
+
+/* Backward of TransformerScorer.forward alone (autograd through FT/compression_method/selector_scorer.py:47-53)
+ * for one segment: g = dL/dscores [N] float32 -> dwq, dbq, dwk, dbk float32 (overwritten), dh [N, D] or NULL.
+ * Workspace: vsel_lis_train_workspace_bytes(n, d, hd).                                             */
+int vsel_lis_scores_bwd(void* stream, const float* g, const void* h, vsel_dtype hdtype, int64_t n,
+                        const vsel_scorer* scorer, void* workspace, size_t workspace_bytes, float* dwq, float* dbq,
+                        float* dwk, float* dbk, void* dh);
+
+/* -------- var-len causal attention (compressed-sequence prefill) --------------------------------
+ * Replaces flash_attn_varlen_func as called by FT/qwenvl/train/trainer.py:101-113 and the FA2 prefill
+ * of EV/qwen25vl/modeling_qwen2_5_vl.py:900 / OV/llavaonevision1_5/modeling_llavaonevision1_5.py:686.
+ *   q [T, Hq, d], k/v [T, Hkv, d] bf16, already rotated; cu_seqlens DEVICE int32 [n_seq + 1]
+ *   (the tensor the reference passes as `attention_mask`); out [T, Hq, d] bf16.  d must be 128.
+ * Math: softmax(q k^T * scale + causal) v with fp32 softmax (EV/qwen25vl/modeling_qwen2_5_vl.py:777-797). */
+int vsel_varlen_attn_fwd(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens,
+                         int64_t n_seq, int64_t max_seqlen, int64_t total, int64_t hq, int64_t hkv, int64_t d,
+                         float scale, int causal, void* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSEL_H */

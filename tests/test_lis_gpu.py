@@ -1,0 +1,222 @@
+"""GPU parity tests of the LIS inference path: HIP kernels (through the C-ABI) vs the numpy oracle
+and the golden vectors produced by the reference.  Run on the MI355X box:  pytest -m gpu."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import inputs as oin
+from oracle import lis as olis
+
+pytestmark = pytest.mark.gpu
+
+CASES = {c[0]: c for c in oin.GOLDEN_CASES}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from visionselector_amd import ops as _ops
+    return _ops
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, f"lis_{name}.npz"))
+
+
+def tag(r):
+    return "idx_" + str(r).replace(".", "p")
+
+
+# ---------------------------------------------------------------------------------------------------
+# hard top-k on GIVEN scores: bit-exact indices (SURVEY.md section 7 hard part 1, contract (i))
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(CASES))
+def test_select_on_reference_scores_is_bit_exact(ops, golden_dir, name):
+    g = load(golden_dir, name)
+    s = dev(g["scores"])
+    n = s.numel()
+    for r in oin.BUDGETS:
+        k = olis.budget_k_eval(n, r)
+        idx, mask = ops.hard_topk(s, k, want_mask=True)
+        assert idx.dtype == torch.int64
+        assert np.array_equal(idx.cpu().numpy(), g[tag(r)])
+        y = np.zeros(n, np.float32)
+        y[g[tag(r)]] = 1
+        assert np.array_equal(mask.cpu().numpy(), y)
+
+
+def test_select_ties_nan_and_signed_zero(ops):
+    s = dev(np.array([1, 2, 2, 2, 2, 2, 0, 2, 2, 3], np.float32))
+    assert ops.hard_topk(s, 5).tolist() == [1, 2, 3, 4, 9]          # lowest index first among equals
+    s = dev(np.array([0.0, -0.0, np.nan, -np.inf, np.inf, -1.0], np.float32))
+    assert ops.hard_topk(s, 2).tolist() == [2, 4]                   # NaN greatest (torch.topk convention)
+    assert ops.hard_topk(s, 4).tolist() == [0, 1, 2, 4]
+    assert ops.hard_topk(s, 6).tolist() == [0, 1, 2, 3, 4, 5]       # k == n
+    # all-equal scores (the shipped near-zero init in the limit): first k indices
+    s = dev(np.full(1000, 0.25, np.float32))
+    assert ops.hard_topk(s, 200).tolist() == list(range(200))
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (2, 1), (63, 7), (64, 64), (65, 1), (1023, 500), (1024, 1), (1025, 1024),
+                                 (4096, 819), (5000, 4999), (40000, 8000)])
+def test_select_random_sizes_match_oracle(ops, n, k):
+    rng = np.random.default_rng(n * 31 + k)
+    s = rng.standard_normal(n).astype(np.float32)
+    s[rng.integers(0, n, max(1, n // 10))] = s[0]                   # inject ties
+    idx = ops.hard_topk(dev(s), k).cpu().numpy()
+    assert np.array_equal(idx, olis.hard_topk_indices(s, k))
+
+
+def test_select_batched_rows_independent(ops):
+    rng = np.random.default_rng(5)
+    s = rng.standard_normal((37, 777)).astype(np.float32)
+    idx = ops.hard_topk(dev(s), 155).cpu().numpy()
+    for b in range(37):
+        assert np.array_equal(idx[b], olis.hard_topk_indices(s[b], 155))
+
+
+# ---------------------------------------------------------------------------------------------------
+# end to end: scores computed by the HIP path, indices vs the fp32 reference (contract (ii))
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_lis_select_matches_reference(ops, golden_dir, name, storage):
+    g = load(golden_dir, name)
+    _, d, hd, n, seed = CASES[name]
+    c = oin.make_case(d, hd, n, seed)
+    dt = torch.float32 if storage == "f32" else torch.bfloat16     # inputs are bf16-representable: same values
+    h, wq, bq, wk, bk = (dev(c[x], dt) for x in ("h", "wq", "bq", "wk", "bk"))
+    scale = max(1.0, float(np.abs(g["scores"]).max()))
+    for r in oin.BUDGETS:
+        k = olis.budget_k_eval(n, r)
+        out, idx, scores = ops.lis_select(h, wq, bq, wk, bk, k)
+        # TOLERANCE: fp32 accumulation in a different order than the reference's GEMMs -> a few ulp of the scale
+        assert np.abs(scores.cpu().numpy() - g["scores"]).max() <= 4e-6 * scale
+        assert np.array_equal(idx.cpu().numpy(), g[tag(r)]), "selected indices must be bit-exact (tie-free seeds)"
+        assert torch.equal(out, h[idx])
+    s2 = ops.lis_scores(h[None], wq, bq, wk, bk)
+    assert torch.equal(s2[0], scores)
+
+
+def test_lis_select_deterministic(ops):
+    c = oin.make_case(3584, 1792, 2304, 99)
+    h, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    a = ops.lis_select(h, wq, bq, wk, bk, 460)
+    b = ops.lis_select(h, wq, bq, wk, bk, 460)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("d,hd,n", [(64, 32, 5), (72, 40, 33), (512, 100, 130), (1032, 520, 257), (8192, 64, 70)])
+def test_lis_generic_shapes(ops, d, hd, n):
+    """Shapes off the fast paths (D not a multiple of 512, odd Hd, tiny N)."""
+    c = oin.make_case(d, hd, n, 7)
+    ref = olis.scorer_reference(c["h"][None], c["wq"], c["bq"], c["wk"], c["bk"])[0]
+    for dt in (torch.float32, torch.bfloat16):
+        h, wq, bq, wk, bk = (dev(c[x], dt) for x in ("h", "wq", "bq", "wk", "bk"))
+        k = max(1, n // 3)
+        out, idx, scores = ops.lis_select(h, wq, bq, wk, bk, k)
+        s = scores.cpu().numpy()
+        assert np.abs(s - ref).max() <= 4e-6 * max(1.0, np.abs(ref).max())
+        assert np.array_equal(idx.cpu().numpy(), olis.hard_topk_indices(s, k))   # select is exact on our own scores
+        assert torch.equal(out, h[idx])
+
+
+def test_lis_batched_uniform(ops):
+    """[B,N,D]: each batch item is scored with its own token mean (reference: mean over dim -1 per batch item)."""
+    b, n, d, hd = 5, 300, 2048, 1024
+    c = oin.make_case(d, hd, n, 21, batch=b)
+    ref = olis.scorer_reference(c["h"], c["wq"], c["bq"], c["wk"], c["bk"])
+    h, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    out, idx, scores = ops.lis_select(h, wq, bq, wk, bk, 60)
+    s = scores.cpu().numpy()
+    assert s.shape == (b, n) and np.abs(s - ref).max() <= 4e-6 * max(1.0, np.abs(ref).max())
+    for i in range(b):
+        assert np.array_equal(idx[i].cpu().numpy(), olis.hard_topk_indices(s[i], 60))
+        assert torch.equal(out[i], h[i][idx[i]])
+
+
+def test_lis_ragged_segments(ops):
+    """Mixed-resolution batch (BASELINE config 5, per-segment budgets): every segment equals a separate call."""
+    d, hd = 2048, 1024
+    lens = [576, 1024, 61, 2304, 1, 900]
+    ks = [olis.budget_k_eval(n, 0.2) for n in lens]
+    c = oin.make_case(d, hd, sum(lens), 33)
+    h, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    out, idx, scores = ops.lis_select_varlen(h, lens, ks, wq, bq, wk, bk)
+    ro = oo = 0
+    for n, k in zip(lens, ks):
+        seg = c["h"][ro:ro + n]
+        ref = olis.scorer_reference(seg[None], c["wq"], c["bq"], c["wk"], c["bk"])[0]
+        s = scores[ro:ro + n].cpu().numpy()
+        assert np.abs(s - ref).max() <= 4e-6 * max(1.0, np.abs(ref).max())
+        assert np.array_equal(idx[oo:oo + k].cpu().numpy(), olis.hard_topk_indices(s, k))
+        assert torch.equal(out[oo:oo + k], h[ro:ro + n][idx[oo:oo + k]])
+        ro += n
+        oo += k
+
+
+def test_near_zero_init_edge_case(ops):
+    """The shipped init (std 1e-4, zero bias) gives scores ~1e-5: still selects exactly what its own scores say."""
+    c = oin.make_case(2048, 1024, 576, 3, near_zero_init=True)
+    h, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    out, idx, scores = ops.lis_select(h, wq, bq, wk, bk, 115)
+    s = scores.cpu().numpy()
+    ref = olis.scorer_reference(c["h"][None], c["wq"], c["bq"], c["wk"], c["bk"])[0]
+    assert np.abs(s - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-12
+    assert np.array_equal(idx.cpu().numpy(), olis.hard_topk_indices(s, 115))
+
+
+def test_errors_are_loud(ops):
+    from visionselector_amd._native import VselError
+    c = oin.make_case(64, 32, 16, 1)
+    h, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    with pytest.raises(VselError, match="k=17"):
+        ops.lis_select(h, wq, bq, wk, bk, 17)
+    with pytest.raises(VselError):
+        ops.lis_select(h, wq, bq, wk, bk, 0)
+    with pytest.raises(TypeError):
+        ops.lis_select(h.half(), wq, bq, wk, bk, 2)
+    with pytest.raises(ValueError):
+        ops.lis_select(h[:, :32].contiguous(), wq, bq, wk, bk, 2)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json full size (config 1: 7B geometry, N=2304, 10/20/50 %), size-independent properties
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("budget", [0.1, 0.2, 0.5])
+def test_full_size_properties(ops, budget):
+    b, n, d, hd = 32, 2304, 3584, 1792
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    h = torch.randn(b, n, d, device="cuda", generator=gen).bfloat16()
+    wq = (0.02 * torch.randn(hd, d, device="cuda", generator=gen)).bfloat16()
+    wk = (0.02 * torch.randn(hd, d, device="cuda", generator=gen)).bfloat16()
+    bq = (0.02 * torch.randn(hd, device="cuda", generator=gen)).bfloat16()
+    bk = (0.02 * torch.randn(hd, device="cuda", generator=gen)).bfloat16()
+    k = olis.budget_k_eval(n, budget)
+    out, idx, scores = ops.lis_select(h, wq, bq, wk, bk, k)
+    assert out.shape == (b, k, d) and idx.shape == (b, k) and scores.shape == (b, n)
+    assert bool((idx[:, 1:] > idx[:, :-1]).all()), "ascending, unique"
+    assert bool((idx >= 0).all()) and bool((idx < n).all())
+    sel = torch.gather(scores, 1, idx)
+    thr = sel.min(dim=1, keepdim=True).values
+    assert bool(((scores > thr).sum(1) < k).all()) and bool(((scores >= thr).sum(1) >= k).all())
+    assert torch.equal(out, torch.gather(h, 1, idx[:, :, None].expand(-1, -1, d)))
+    # linearity of the scorer in the query side: scores are affine in each token given the mean; check
+    # against an independent fp64 evaluation of the collapsed form for 2 batch items on the host
+    for bi in (0, b - 1):
+        ref = olis.scorer_collapsed(h[bi].float().cpu().numpy()[None], wq.float().cpu().numpy(), bq.float().cpu().numpy(),
+                                    wk.float().cpu().numpy(), bk.float().cpu().numpy())[0]
+        s = scores[bi].cpu().numpy()
+        assert np.abs(s - ref).max() <= 4e-6 * max(1.0, np.abs(ref).max())
+        ridx = olis.hard_topk_indices(ref.astype(np.float32), k)
+        # boundary-tie tolerant: symmetric difference only among scores within fp32 noise of the threshold
+        diff = np.setxor1d(ridx, idx[bi].cpu().numpy())
+        assert all(abs(ref[j] - np.sort(ref)[::-1][k - 1]) <= 1e-5 for j in diff)

@@ -174,3 +174,18 @@ def test_splice(golden_dir, name):
     assert np.array_equal(pos, g["position_ids"])
     assert np.array_equal(am, g["attention_mask"])
     assert new_ids.shape[1] == ids.shape[1] - int(g["n_visual"]) + int(g["k"])
+
+
+@pytest.mark.parametrize("name", ["tiny", "qwen3b_256", "qwen7b_2304"])
+def test_torch_cpu_restatement(golden_dir, cases, name):
+    """oracle/lis_torch.py (bench.py's cpu_baseline leg) reproduces the goldens too."""
+    import torch
+    from oracle import lis_torch
+    g = load(golden_dir, name)
+    c = cases(name)
+    t = {k: torch.from_numpy(v) for k, v in c.items()}
+    for r in oin.BUDGETS:
+        h_new, idx, scores = lis_torch.select_forward(t["h"], t["wq"], t["bq"], t["wk"], t["bk"], r)
+        assert np.array_equal(idx.numpy(), g["idx_" + str(r).replace(".", "p")])
+        assert np.abs(scores.numpy() - g["scores"]).max() <= 2e-6 * max(1.0, np.abs(g["scores"]).max())
+        assert torch.equal(h_new, t["h"][idx])

@@ -1,0 +1,89 @@
+"""ctypes binding of libvsel.so (C-ABI in include/vsel.h).  No fallback: a missing library is an error."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libvsel.so")
+
+VSEL_BF16, VSEL_F32 = 0, 1
+STATUS = {0: "VSEL_OK", 1: "VSEL_ERR_INVALID", 2: "VSEL_ERR_WORKSPACE", 3: "VSEL_ERR_HIP", 4: "VSEL_ERR_UNSUPPORTED"}
+
+
+class VselError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"{STATUS.get(status, status)}: {msg}")
+        self.status = status
+
+
+class Segments(C.Structure):
+    _fields_ = [("n_seg", C.c_int64), ("rows_per_seg", C.c_int64), ("total_rows", C.c_int64), ("k", C.c_int64),
+                ("total_out", C.c_int64), ("seg_rows", C.c_void_p), ("seg_out", C.c_void_p)]
+
+
+class Scorer(C.Structure):
+    _fields_ = [("wq", C.c_void_p), ("bq", C.c_void_p), ("wk", C.c_void_p), ("bk", C.c_void_p),
+                ("d", C.c_int64), ("hd", C.c_int64), ("wdtype", C.c_int)]
+
+
+# name -> (restype, argtypes); must list every symbol include/vsel.h declares (tests check this)
+_P, _I64, _F, _SZ = C.c_void_p, C.c_int64, C.c_float, C.c_size_t
+_SEG, _SC = C.POINTER(Segments), C.POINTER(Scorer)
+SIGNATURES = {
+    "vsel_version": (C.c_char_p, []),
+    "vsel_last_error": (C.c_char_p, []),
+    "vsel_profile_start": (C.c_int, []),
+    "vsel_profile_stop": (C.c_int, [C.c_char_p, _SZ, _P, _P, C.c_int, _P]),
+    "vsel_lis_workspace_bytes": (_SZ, [_SEG, _I64, _I64]),
+    "vsel_lis_select": (C.c_int, [_P, _P, C.c_int, _SEG, _SC, _P, _SZ, _P, _P, _P]),
+    "vsel_lis_scores": (C.c_int, [_P, _P, C.c_int, _SEG, _SC, _P, _SZ, _P]),
+    "vsel_topk_select": (C.c_int, [_P, _P, _SEG, _P, _P]),
+    "vsel_gather_rows": (C.c_int, [_P, _P, C.c_int, _I64, _SEG, _P, _P]),
+    "vsel_soft_topk_fwd": (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _P]),
+    "vsel_soft_topk_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P]),
+    "vsel_lis_train_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
+    "vsel_lis_train_fwd": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _SC, _P, _SZ, _P, _P, _P, _P, _P, _P]),
+    "vsel_lis_train_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _SC, _P, _P, _P, _P, _P, _F, _P, _SZ, _P, _P, _P, _P, _P]),
+    "vsel_lis_scores_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _SC, _P, _SZ, _P, _P, _P, _P, _P]),
+    "vsel_varlen_attn_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, C.c_int, _P]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libvsel.so once.  Raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -m visionselector_amd.build` "
+                "(hipcc --offload-arch=gfx950).  visionselector_amd has no CPU / eager fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise VselError(status, lib().vsel_last_error().decode())
+
+
+def profile_start() -> None:
+    check(lib().vsel_profile_start())
+
+
+def profile_stop() -> dict:
+    """-> {kernel_name: (total_ms, launches)} for everything launched since profile_start()."""
+    names = C.create_string_buffer(4096)
+    ms = (C.c_float * 64)()
+    calls = (C.c_int64 * 64)()
+    n = C.c_int(0)
+    check(lib().vsel_profile_stop(names, 4096, C.cast(ms, C.c_void_p), C.cast(calls, C.c_void_p), 64, C.cast(C.byref(n), C.c_void_p)))
+    keys = names.value.decode().split(",") if n.value else []
+    return {k: (float(ms[i]), int(calls[i])) for i, k in enumerate(keys)}

@@ -1,0 +1,144 @@
+// Shared device/host helpers for libvsel (gfx950 / CDNA4 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/vsel.h"
+
+namespace vsel {
+
+constexpr int kWave = 64;
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+struct bf16_t { uint16_t bits; };
+
+// ---- error plumbing --------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(vsel_status st, const char* fmt, ...);
+const std::string& last_error();
+
+#define VSEL_HIP_CHECK(expr)                                                              \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) return ::vsel::fail(VSEL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+#define VSEL_LAUNCH_CHECK(name)                                                           \
+  do {                                                                                    \
+    hipError_t _e = hipGetLastError();                                                    \
+    if (_e != hipSuccess) return ::vsel::fail(VSEL_ERR_HIP, "launch %s: %s", name, hipGetErrorString(_e)); \
+  } while (0)
+
+// ---- optional per-kernel timing (vsel_profile_start/stop): HIP events on the launch stream -------
+bool prof_enabled();
+void prof_mark(hipStream_t st, const char* name);   // event AFTER the named kernel ("<begin>" opens an API call)
+
+#define VSEL_AFTER_LAUNCH(st, name)                                                       \
+  do {                                                                                    \
+    VSEL_LAUNCH_CHECK(name);                                                              \
+    if (::vsel::prof_enabled()) ::vsel::prof_mark(st, name);                              \
+  } while (0)
+#define VSEL_PROF_BEGIN(st)                                                               \
+  do {                                                                                    \
+    if (::vsel::prof_enabled()) ::vsel::prof_mark((hipStream_t)(st), "<begin>");          \
+  } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- element access: 16-byte vectors ----------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<bf16_t> {
+  static constexpr int kVec = 8;   // elements per 16-byte lane load
+};
+template <> struct Elem<float> {
+  static constexpr int kVec = 4;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+
+// round-to-nearest-even fp32 -> bf16 (matches torch .to(bfloat16)); NaN stays NaN
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+// load kVec consecutive elements (16 B, must be 16-B aligned) and widen to fp32
+__device__ __forceinline__ void load_vec(const bf16_t* p, float (&v)[8]) {
+  const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(r[i] << 16);
+    v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void load_vec(const float* p, float (&v)[4]) {
+  const f32x4 r = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = r[i];
+}
+__device__ __forceinline__ void store_vec(bf16_t* p, const float (&v)[8]) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = f32_to_bf16_bits(v[2 * i]) | (f32_to_bf16_bits(v[2 * i + 1]) << 16);
+  *reinterpret_cast<u32x4*>(p) = r;
+}
+__device__ __forceinline__ void store_vec(float* p, const float (&v)[4]) {
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = v[i];
+  *reinterpret_cast<f32x4*>(p) = r;
+}
+__device__ __forceinline__ float load_elem(const bf16_t* p) { return bf16_to_f32(p->bits); }
+__device__ __forceinline__ float load_elem(const float* p) { return *p; }
+__device__ __forceinline__ void store_elem(bf16_t* p, float v) { p->bits = (uint16_t)f32_to_bf16_bits(v); }
+__device__ __forceinline__ void store_elem(float* p, float v) { *p = v; }
+
+// ---- wave64 reductions (fixed order => deterministic) -----------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// ---- segments -----------------------------------------------------------------------------------
+struct SegView {
+  const int32_t* seg_rows;  // device or null
+  const int32_t* seg_out;   // device or null
+  int32_t rows_per_seg;
+  int32_t k;
+  __device__ __forceinline__ int64_t row_begin(int s) const { return seg_rows ? (int64_t)seg_rows[s] : (int64_t)s * rows_per_seg; }
+  __device__ __forceinline__ int32_t n_rows(int s) const { return seg_rows ? seg_rows[s + 1] - seg_rows[s] : rows_per_seg; }
+  __device__ __forceinline__ int64_t out_begin(int s) const { return seg_out ? (int64_t)seg_out[s] : (int64_t)s * k; }
+  __device__ __forceinline__ int32_t n_out(int s) const { return seg_out ? seg_out[s + 1] - seg_out[s] : k; }
+};
+
+inline SegView make_view(const vsel_segments* seg) {
+  SegView v;
+  v.seg_rows = seg->seg_rows;
+  v.seg_out = seg->seg_out;
+  v.rows_per_seg = (int32_t)seg->rows_per_seg;
+  v.k = (int32_t)seg->k;
+  return v;
+}
+
+int check_segments(const vsel_segments* seg, bool need_k);
+
+}  // namespace vsel

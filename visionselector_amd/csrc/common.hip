@@ -1,0 +1,94 @@
+// Error plumbing and version for libvsel.
+#include "common.h"
+
+#include <stdarg.h>
+#include <string.h>
+#include <utility>
+#include <vector>
+
+namespace vsel {
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int fail(vsel_status st, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return (int)st;
+}
+const std::string& last_error() { return g_last_error; }
+}  // namespace vsel
+
+namespace vsel {
+// Per-kernel timing with HIP events recorded on the launch stream between kernels.  Off by default;
+// bench.py turns it on for the timed region.  Single-threaded use (one process per GPU).
+struct Profiler {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  std::vector<std::pair<const char*, hipEvent_t>> marks;
+};
+static Profiler g_prof;
+bool prof_enabled() { return g_prof.on; }
+void prof_mark(hipStream_t st, const char* name) {
+  const size_t i = g_prof.marks.size();
+  if (i >= g_prof.pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    g_prof.pool.push_back(e);
+  }
+  (void)hipEventRecord(g_prof.pool[i], st);
+  g_prof.marks.emplace_back(name, g_prof.pool[i]);
+}
+}  // namespace vsel
+
+extern "C" int vsel_profile_start(void) {
+  vsel::g_prof.marks.clear();
+  vsel::g_prof.on = true;
+  return VSEL_OK;
+}
+
+extern "C" int vsel_profile_stop(char* names, size_t names_len, float* total_ms, int64_t* calls, int max_entries,
+                                 int* n_entries) {
+  using namespace vsel;
+  g_prof.on = false;
+  if (!names || !total_ms || !calls || !n_entries || max_entries < 1) return fail(VSEL_ERR_INVALID, "NULL pointer");
+  std::vector<std::string> keys;
+  std::vector<double> ms;
+  std::vector<int64_t> cnt;
+  if (!g_prof.marks.empty()) VSEL_HIP_CHECK(hipEventSynchronize(g_prof.marks.back().second));
+  for (size_t i = 1; i < g_prof.marks.size(); ++i) {
+    const char* nm = g_prof.marks[i].first;
+    if (!strcmp(nm, "<begin>")) continue;
+    float dt = 0.f;
+    VSEL_HIP_CHECK(hipEventElapsedTime(&dt, g_prof.marks[i - 1].second, g_prof.marks[i].second));
+    size_t j = 0;
+    for (; j < keys.size(); ++j) if (keys[j] == nm) break;
+    if (j == keys.size()) { keys.emplace_back(nm); ms.push_back(0); cnt.push_back(0); }
+    ms[j] += dt;
+    cnt[j] += 1;
+  }
+  g_prof.marks.clear();
+  std::string joined;
+  int n = 0;
+  for (size_t j = 0; j < keys.size() && n < max_entries; ++j, ++n) {
+    if (j) joined += ",";
+    joined += keys[j];
+    total_ms[n] = (float)ms[j];
+    calls[n] = cnt[j];
+  }
+  if (joined.size() + 1 > names_len) return fail(VSEL_ERR_INVALID, "names buffer too small");
+  memcpy(names, joined.c_str(), joined.size() + 1);
+  *n_entries = n;
+  return VSEL_OK;
+}
+
+extern "C" const char* vsel_version(void) { return "vsel 0.1.0 (gfx950)"; }
+extern "C" const char* vsel_last_error(void) {
+  static thread_local std::string copy;
+  copy = vsel::last_error();
+  return copy.c_str();
+}

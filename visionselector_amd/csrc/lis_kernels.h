@@ -1,0 +1,606 @@
+// LIS inference path for gfx950: column mean -> kbar / w projections (fp32 MFMA) -> scores ->
+// radix-select hard top-k with order-preserving compaction -> row gather.
+//
+// Formulation (exact algebra, SURVEY.md section 7 hard part 2): the reference computes
+//   k = Wk x + bk, q = Wq x + bq, s_i = mean_j(q_i . k_j) / sqrt(Hd)
+// (reference: qwen-vl-finetune/compression_method/selector_scorer.py:47-53).  mean_j(q_i . k_j) =
+// q_i . kbar with kbar = Wk xbar + bk, so
+//   s_i = (x_i . w + c) / sqrt(Hd),   w = Wq^T kbar,  c = bq . kbar,  xbar = mean_i x_i.
+// That turns 78 GFLOP of GEMM into two sweeps over the token tensor (HBM-bound) plus two skinny
+// projections [S, D] x [D, Hd] and [S, Hd] x [Hd, D] which run on the fp32-input MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation, so index selection can be compared
+// bit-for-bit with the fp32 CPU oracle on tie-free inputs).
+#pragma once
+#include "common.h"
+#include <algorithm>
+#include <math.h>
+
+namespace vsel {
+
+// =================================================================================================
+// K1  partial column sums.  grid (col_tiles, row_splits, n_seg), block 256 (4 waves).
+//     A wave reads 64 lanes x 16 B = 1 KiB contiguous of one row; the block's 4 waves interleave rows.
+// =================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ h, SegView sv, int d,
+                                                             int row_splits, float* __restrict__ partial) {
+  constexpr int V = Elem<T>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = blockIdx.z, rs = blockIdx.y;
+  const int col = (blockIdx.x * 64 + lane) * V;
+  const int n = sv.n_rows(s);
+  const int64_t r0 = sv.row_begin(s);
+  const int rows_per = (n + row_splits - 1) / row_splits;
+  const int rb = rs * rows_per;
+  const int re = min(n, rb + rows_per);
+  float acc[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) acc[i] = 0.f;
+  if (col < d) {
+    const T* base = h + (r0 * (int64_t)d + col);
+    int r = rb + wave;
+    for (; r + 12 < re; r += 16) {
+      float v0[V], v1[V], v2[V], v3[V];
+      load_vec(base + (int64_t)r * d, v0);
+      load_vec(base + (int64_t)(r + 4) * d, v1);
+      load_vec(base + (int64_t)(r + 8) * d, v2);
+      load_vec(base + (int64_t)(r + 12) * d, v3);
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc[i] = ((acc[i] + v0[i]) + v1[i]) + (v2[i] + v3[i]);
+    }
+    for (; r < re; r += 4) {
+      float v0[V];
+      load_vec(base + (int64_t)r * d, v0);
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc[i] += v0[i];
+    }
+  }
+  __shared__ float red[4][64][V + 1];
+#pragma unroll
+  for (int i = 0; i < V; ++i) red[wave][lane][i] = acc[i];
+  __syncthreads();
+  if (wave == 0 && col < d) {
+    float out[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) out[i] = (red[0][lane][i] + red[1][lane][i]) + (red[2][lane][i] + red[3][lane][i]);
+    float* dst = partial + ((int64_t)(s * row_splits + rs) * d + col);
+#pragma unroll
+    for (int i = 0; i < V; i += 4) {
+      f32x4 o = {out[i], out[i + 1], out[i + 2], out[i + 3]};
+      *reinterpret_cast<f32x4*>(dst + i) = o;
+    }
+  }
+}
+
+// K1b  xbar[s][c] = sum_rs partial[s][rs][c] / N_s   (fixed order)
+static __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, SegView sv, int d,
+                                                            int row_splits, float* __restrict__ xbar) {
+  const int s = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d) return;
+  const float* p = partial + (int64_t)s * row_splits * d + c;
+  float acc = 0.f;
+  for (int rs = 0; rs < row_splits; ++rs) acc += p[(int64_t)rs * d];
+  xbar[(int64_t)s * d + c] = acc / (float)sv.n_rows(s);
+}
+
+// =================================================================================================
+// K2  skinny GEMM "NT":  part[ks][m][n] = sum_{k in slice ks} x[m][k] * w[n][k]
+//     x fp32 [M, K], w (bf16|f32) [N, K] row-major.  One wave per (n-tile 32, m-tile 32, k-slice).
+//     v_mfma_f32_32x32x2_f32: A[i][kk] = w[n0+i][.], B[kk][j] = x[m0+j][.]; lane = 32*kk + i.
+//     Each lane owns 8 consecutive k per 16-wide step (16-B weight load), MFMA step t pairs element t.
+// =================================================================================================
+template <typename TW>
+__device__ __forceinline__ void load8_guard(const TW* row, int kb, int k_end, bool row_ok, float (&v)[8]) {
+  constexpr int V = Elem<TW>::kVec;
+  if (row_ok && kb + 8 <= k_end) {
+    if constexpr (V == 8) {
+      load_vec(row + kb, v);
+    } else {
+      float a[4], b[4];
+      load_vec(row + kb, a);
+      load_vec(row + kb + 4, b);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (row_ok && kb + i < k_end) ? load_elem(row + kb + i) : 0.f;
+  }
+}
+
+template <typename TW>
+__global__ __launch_bounds__(64) void gemm_nt_kernel(const float* __restrict__ x, const TW* __restrict__ w, int M,
+                                                     int N, int K, int kslice, float* __restrict__ part) {
+  const int lane = threadIdx.x;
+  const int i = lane & 31, kk = lane >> 5;
+  const int n_row = blockIdx.x * 32 + i;
+  const int m_row = blockIdx.y * 32 + i;
+  const int ks = blockIdx.z;
+  const int k_begin = ks * kslice;
+  const int k_end = min(K, k_begin + kslice);
+  const bool n_ok = n_row < N, m_ok = m_row < M;
+  const TW* wrow = w + (int64_t)(n_ok ? n_row : 0) * K;
+  const float* xrow = x + (int64_t)(m_ok ? m_row : 0) * K;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = k_begin; k0 < k_end; k0 += 16) {
+    const int kb = k0 + 8 * kk;
+    float a[8], b[8];
+    load8_guard<TW>(wrow, kb, k_end, n_ok, a);
+    load8_guard<float>(xrow, kb, k_end, m_ok, b);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+  }
+  // C[row = n][col = m]: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int m = blockIdx.y * 32 + (lane & 31);
+  if (m < M) {
+    float* dst = part + ((int64_t)ks * M + m) * N + blockIdx.x * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+      if (blockIdx.x * 32 + row < N) dst[row] = acc[r];
+    }
+  }
+}
+
+// K2b  kbar[m][n] = sum_ks part[ks][m][n] + bk[n];  c[m] = sum_n bq[n] * kbar[m][n].  One block per m.
+template <typename TW>
+__global__ __launch_bounds__(256) void kbar_finish_kernel(const float* __restrict__ part, int KS, int M, int N,
+                                                          const TW* __restrict__ bk, const TW* __restrict__ bq,
+                                                          float* __restrict__ kbar, float* __restrict__ c) {
+  const int m = blockIdx.x;
+  float cacc = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float v = 0.f;
+    for (int ks = 0; ks < KS; ++ks) v += part[((int64_t)ks * M + m) * N + n];
+    v += load_elem(bk + n);
+    kbar[(int64_t)m * N + n] = v;
+    cacc += load_elem(bq + n) * v;
+  }
+  cacc = wave_sum(cacc);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cacc;
+  __syncthreads();
+  if (threadIdx.x == 0) c[m] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// =================================================================================================
+// K3  skinny GEMM "NN":  part[ks][m][n] = sum_{k in slice} x[m][k] * w[k][n],  w (bf16|f32) [K, N].
+//     One wave per (n-tile 256, m-tile 32, k-slice).  Lane (i, kk) loads 8 consecutive n of row k
+//     (16-B coalesced) and feeds 8 accumulators: acc[t] is the 32x32 tile for n = n0 + 8*i' + t.
+// =================================================================================================
+template <typename TW>
+__global__ __launch_bounds__(64) void gemm_nn_kernel(const float* __restrict__ x, const TW* __restrict__ w, int M,
+                                                     int N, int K, int kslice, float* __restrict__ part) {
+  const int lane = threadIdx.x;
+  const int i = lane & 31, kk = lane >> 5;
+  const int nbase = blockIdx.x * 256 + 8 * i;
+  const int m_row = blockIdx.y * 32 + i;
+  const int ks = blockIdx.z;
+  const int k_begin = ks * kslice;
+  const int k_end = min(K, k_begin + kslice);
+  const bool n_ok = nbase < N, m_ok = m_row < M;   // N % 8 == 0 (checked on the host)
+  const float* xrow = x + (int64_t)(m_ok ? m_row : 0) * K;
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int k0 = k_begin; k0 < k_end; k0 += 8) {
+    const int kb = k0 + 4 * kk;
+    float xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = (m_ok && kb + u < k_end) ? xrow[kb + u] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float wv[8];
+      const int k = kb + u;
+      if (n_ok && k < k_end) {
+        const TW* p = w + (int64_t)k * N + nbase;
+        if constexpr (Elem<TW>::kVec == 8) {
+          load_vec(p, wv);
+        } else {
+          float a[4], b[4];
+          load_vec(p, a);
+          load_vec(p + 4, b);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { wv[q] = a[q]; wv[4 + q] = b[q]; }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wv[q] = 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t], xv[u], acc[t], 0, 0, 0);
+    }
+  }
+  const int m = blockIdx.y * 32 + (lane & 31);
+  if (m < M) {
+    float* dst = part + ((int64_t)ks * M + m) * N + blockIdx.x * 256;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int irow = (r & 3) + 8 * (r >> 2) + 4 * kk;
+      const int n = blockIdx.x * 256 + 8 * irow;
+      if (n < N) {
+        f32x4 lo = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        f32x4 hi = {acc[4][r], acc[5][r], acc[6][r], acc[7][r]};
+        *reinterpret_cast<f32x4*>(dst + 8 * irow) = lo;
+        *reinterpret_cast<f32x4*>(dst + 8 * irow + 4) = hi;
+      }
+    }
+  }
+}
+
+// K3b  out[e] = sum_ks part[ks][e]
+static __global__ __launch_bounds__(256) void slice_sum_kernel(const float* __restrict__ part, int KS, int64_t count,
+                                                        float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= count) return;
+  float v = 0.f;
+  for (int ks = 0; ks < KS; ++ks) v += part[(int64_t)ks * count + e];
+  out[e] = v;
+}
+
+// =================================================================================================
+// K4  scores[row] = (x_row . w[s] + c[s]) / sqrt(Hd).  grid (row_chunks, n_seg), block 256.
+//     ITERS > 0: D == ITERS * 64 * V exactly and w[s] lives in registers; ITERS == 0: generic.
+// =================================================================================================
+template <typename T, int ITERS>
+__global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, SegView sv, int d,
+                                                    const float* __restrict__ w, const float* __restrict__ c,
+                                                    float sqrt_hd, int rows_per_block, float* __restrict__ scores) {
+  constexpr int V = Elem<T>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = blockIdx.y;
+  const int n = sv.n_rows(s);
+  const int rb = blockIdx.x * rows_per_block;
+  if (rb >= n) return;
+  const int re = min(n, rb + rows_per_block);
+  const int64_t r0 = sv.row_begin(s);
+  const float cs = c[s];
+  const float* ws = w + (int64_t)s * d;
+  if constexpr (ITERS > 0) {
+    float wr[ITERS][V];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+      for (int q = 0; q < V; q += 4) {
+        float t4[4];
+        load_vec(ws + (it * 64 + lane) * V + q, t4);
+#pragma unroll
+        for (int z = 0; z < 4; ++z) wr[it][q + z] = t4[z];
+      }
+    }
+    const T* base = h + r0 * (int64_t)d + lane * V;
+    int r = rb + wave;
+    for (; r + 4 < re; r += 8) {
+      const T* p0 = base + (int64_t)r * d;
+      const T* p1 = base + (int64_t)(r + 4) * d;
+      float x0[ITERS][V], x1[ITERS][V];
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) load_vec(p0 + it * 64 * V, x0[it]);
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) load_vec(p1 + it * 64 * V, x1[it]);
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+          a0 = fmaf(x0[it][q], wr[it][q], a0);
+          a1 = fmaf(x1[it][q], wr[it][q], a1);
+        }
+      a0 = wave_sum(a0);
+      a1 = wave_sum(a1);
+      if (lane == 0) {
+        scores[r0 + r] = (a0 + cs) / sqrt_hd;
+        scores[r0 + r + 4] = (a1 + cs) / sqrt_hd;
+      }
+    }
+    for (; r < re; r += 4) {
+      const T* p0 = base + (int64_t)r * d;
+      float a0 = 0.f;
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        float x0[V];
+        load_vec(p0 + it * 64 * V, x0);
+#pragma unroll
+        for (int q = 0; q < V; ++q) a0 = fmaf(x0[q], wr[it][q], a0);
+      }
+      a0 = wave_sum(a0);
+      if (lane == 0) scores[r0 + r] = (a0 + cs) / sqrt_hd;
+    }
+  } else {
+    for (int r = rb + wave; r < re; r += 4) {
+      const T* p0 = h + (r0 + r) * (int64_t)d;
+      float a0 = 0.f;
+      for (int col = lane * V; col < d; col += 64 * V) {
+        float x0[V];
+        load_vec(p0 + col, x0);
+#pragma unroll
+        for (int q = 0; q < V; q += 4) {
+          float t4[4];
+          load_vec(ws + col + q, t4);
+#pragma unroll
+          for (int z = 0; z < 4; ++z) a0 = fmaf(x0[q + z], t4[z], a0);
+        }
+      }
+      a0 = wave_sum(a0);
+      if (lane == 0) scores[r0 + r] = (a0 + cs) / sqrt_hd;
+    }
+  }
+}
+
+// =================================================================================================
+// K5  hard top-k per segment: 4-pass radix-256 select of the k-th largest key, then one ordered
+//     compaction pass (ballot + popcount prefix) that emits ascending indices -- the reference's
+//     topk(k).indices.sort() without a sort.  One block of 1024 threads per segment.
+// =================================================================================================
+__device__ __forceinline__ uint32_t order_key(float x) {
+  const float f = x + 0.0f;  // -0.0 -> +0.0
+  const uint32_t u = __float_as_uint(f);
+  if (f != f) return 0xffffffffu;  // NaN sorts greatest (torch.topk convention)
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+static __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restrict__ scores, SegView sv,
+                                                           int64_t* __restrict__ idx, float* __restrict__ mask) {
+  const int s = blockIdx.x;
+  const int n = sv.n_rows(s);
+  const int k = min(sv.n_out(s), n);
+  const float* sc = scores + sv.row_begin(s);
+  int64_t* out = idx ? idx + sv.out_begin(s) : nullptr;
+  float* mk = mask ? mask + sv.row_begin(s) : nullptr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh_bin, sh_kk;
+  __shared__ uint32_t wtot_gt[16], wtot_eq[16];
+
+  uint32_t prefix = 0, maskbits = 0, kk = (uint32_t)k;
+  for (int pass = 3; pass >= 0; --pass) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const int shift = 8 * pass;
+    for (int i = tid; i < n; i += 1024) {
+      const uint32_t key = order_key(sc[i]);
+      if ((key & maskbits) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // lane owns bins 4*lane .. 4*lane+3; find the bin where the count from the top reaches kk
+      const uint32_t c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+      const uint32_t tot = c0 + c1 + c2 + c3;
+      uint32_t suf = tot;  // inclusive suffix sum over lanes (lanes >= this one)
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_down(suf, off, 64);
+        if (lane + off < 64) suf += o;
+      }
+      uint32_t run = suf - tot;  // keys in bins above this lane's bins
+      const uint32_t cs[4] = {c3, c2, c1, c0};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (run < kk && run + cs[b] >= kk) {
+          sh_bin = 4 * lane + (3 - b);
+          sh_kk = kk - run;
+        }
+        run += cs[b];
+      }
+    }
+    __syncthreads();
+    prefix |= sh_bin << shift;
+    maskbits |= 0xffu << shift;
+    kk = sh_kk;
+    __syncthreads();
+  }
+  const uint32_t thr = prefix;   // key of the k-th largest element
+  const uint32_t need = kk;      // how many elements equal to thr are kept (lowest index first)
+
+  uint32_t run_gt = 0, run_eq = 0;
+  for (int c0 = 0; c0 < n; c0 += 1024) {
+    const int i = c0 + tid;
+    const bool valid = i < n;
+    const uint32_t key = valid ? order_key(sc[i]) : 0u;
+    const bool gt = valid && key > thr;
+    const bool eq = valid && key == thr;
+    const unsigned long long bgt = __ballot(gt), beq = __ballot(eq);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) {
+      wtot_gt[wave] = __popcll(bgt);
+      wtot_eq[wave] = __popcll(beq);
+    }
+    __syncthreads();
+    uint32_t gt_before = run_gt + __popcll(bgt & below), eq_before = run_eq + __popcll(beq & below);
+    uint32_t tot_gt = 0, tot_eq = 0;
+#pragma unroll
+    for (int wv = 0; wv < 16; ++wv) {
+      const uint32_t g = wtot_gt[wv], e = wtot_eq[wv];
+      if (wv < wave) { gt_before += g; eq_before += e; }
+      tot_gt += g;
+      tot_eq += e;
+    }
+    const bool sel = gt || (eq && eq_before < need);
+    if (sel && out) out[gt_before + min(eq_before, need)] = (int64_t)i;
+    if (valid && mk) mk[i] = sel ? 1.0f : 0.0f;
+    run_gt += tot_gt;
+    run_eq += tot_eq;
+    __syncthreads();
+  }
+}
+
+// =================================================================================================
+// K6  row gather out[ob + j] = h[rb + idx[ob + j]].  grid (row_chunks, n_seg), block 256, wave per row.
+// =================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ h, SegView sv, int d,
+                                                          const int64_t* __restrict__ idx, T* __restrict__ out,
+                                                          int rows_per_block) {
+  constexpr int V = Elem<T>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = blockIdx.y;
+  const int ko = sv.n_out(s);
+  const int jb = blockIdx.x * rows_per_block;
+  if (jb >= ko) return;
+  const int je = min(ko, jb + rows_per_block);
+  const int64_t ob = sv.out_begin(s), rb = sv.row_begin(s);
+  for (int j = jb + wave; j < je; j += 4) {
+    const int64_t src = rb + idx[ob + j];
+    const u32x4* sp = reinterpret_cast<const u32x4*>(h + src * d);
+    u32x4* dp = reinterpret_cast<u32x4*>(out + (ob + j) * d);
+    for (int v = lane; v < d / V; v += 64) dp[v] = sp[v];
+  }
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+struct LisPlan {
+  int64_t S, maxn, d, hd;
+  int row_splits;
+  int ks1, kslice1;  // kbar projection  [S, D] x [Hd, D]^T
+  int ks2, kslice2;  // w projection     [S, Hd] x [Hd, D]
+  size_t off_partial, off_xbar, off_part1, off_kbar, off_c, off_part2, off_w, total;
+};
+
+inline LisPlan make_plan(int64_t S, int64_t maxn, int64_t d, int64_t hd) {
+  LisPlan p{};
+  p.S = S; p.maxn = maxn; p.d = d; p.hd = hd;
+  const int64_t col_tiles = cdiv(d, 512);
+  int64_t rs = cdiv(1024, S * col_tiles);
+  rs = std::max<int64_t>(1, std::min<int64_t>(rs, std::max<int64_t>(1, maxn / 32)));
+  p.row_splits = (int)rs;
+  const int64_t mt = cdiv(S, 32);
+  int64_t ks1 = cdiv(2048, cdiv(hd, 32) * mt);
+  ks1 = std::max<int64_t>(1, std::min<int64_t>(ks1, std::max<int64_t>(1, d / 64)));
+  p.kslice1 = (int)(cdiv(cdiv(d, ks1), 16) * 16);
+  p.ks1 = (int)cdiv(d, p.kslice1);
+  int64_t ks2 = cdiv(1024, cdiv(d, 256) * mt);
+  ks2 = std::max<int64_t>(1, std::min<int64_t>(ks2, std::max<int64_t>(1, hd / 16)));
+  p.kslice2 = (int)(cdiv(cdiv(hd, ks2), 8) * 8);
+  p.ks2 = (int)cdiv(hd, p.kslice2);
+  size_t o = 0;
+  auto take = [&](size_t nfloat) { size_t r = o; o += align_up(nfloat * sizeof(float), 256); return r; };
+  p.off_partial = take((size_t)S * p.row_splits * d);
+  p.off_xbar = take((size_t)S * d);
+  p.off_part1 = take((size_t)p.ks1 * S * hd);
+  p.off_kbar = take((size_t)S * hd);
+  p.off_c = take((size_t)S);
+  p.off_part2 = take((size_t)p.ks2 * S * d);
+  p.off_w = take((size_t)S * d);
+  p.total = o;
+  return p;
+}
+
+inline int check_segments_impl(const vsel_segments* seg, bool need_k) {
+  if (!seg) return fail(VSEL_ERR_INVALID, "segments is NULL");
+  if (seg->n_seg < 1 || seg->rows_per_seg < 1 || seg->total_rows < 1)
+    return fail(VSEL_ERR_INVALID, "empty segments (n_seg=%lld rows_per_seg=%lld total_rows=%lld)",
+                (long long)seg->n_seg, (long long)seg->rows_per_seg, (long long)seg->total_rows);
+  if (seg->n_seg > 65535) return fail(VSEL_ERR_UNSUPPORTED, "n_seg %lld > 65535", (long long)seg->n_seg);
+  if (seg->total_rows >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "total_rows must fit int32");
+  if (!seg->seg_rows && seg->total_rows != seg->n_seg * seg->rows_per_seg)
+    return fail(VSEL_ERR_INVALID, "uniform segments: total_rows != n_seg * rows_per_seg");
+  if (need_k) {
+    if (seg->k < 1 || seg->k > seg->rows_per_seg)
+      return fail(VSEL_ERR_INVALID, "k=%lld must satisfy 1 <= k <= rows_per_seg=%lld", (long long)seg->k,
+                  (long long)seg->rows_per_seg);
+    if ((seg->seg_rows != nullptr) != (seg->seg_out != nullptr))
+      return fail(VSEL_ERR_INVALID, "seg_rows and seg_out must both be given (ragged) or both NULL (uniform)");
+    if (!seg->seg_out && seg->total_out != seg->n_seg * seg->k)
+      return fail(VSEL_ERR_INVALID, "uniform segments: total_out != n_seg * k");
+  }
+  return VSEL_OK;
+}
+
+inline int check_scorer(const vsel_scorer* sc, vsel_dtype hdtype) {
+  if (!sc || !sc->wq || !sc->bq || !sc->wk || !sc->bk) return fail(VSEL_ERR_INVALID, "scorer parameter pointer is NULL");
+  if (sc->d < 8 || sc->hd < 1) return fail(VSEL_ERR_INVALID, "bad scorer dims d=%lld hd=%lld", (long long)sc->d, (long long)sc->hd);
+  if (sc->d % 8 != 0) return fail(VSEL_ERR_UNSUPPORTED, "in_features D=%lld must be a multiple of 8 (16-byte rows)", (long long)sc->d);
+  if (sc->wdtype != VSEL_BF16 && sc->wdtype != VSEL_F32) return fail(VSEL_ERR_INVALID, "bad weight dtype");
+  if (hdtype != VSEL_BF16 && hdtype != VSEL_F32) return fail(VSEL_ERR_INVALID, "bad token dtype");
+  return VSEL_OK;
+}
+
+template <typename T>
+inline int launch_score(hipStream_t st, const T* h, const SegView& sv, const vsel_segments* seg, int d,
+                        const float* w, const float* c, int hd, float* scores) {
+  constexpr int V = Elem<T>::kVec;
+  // rows per block: keep >= ~2048 blocks when there is enough work, 8..64 rows per block
+  int64_t rpb = 64;
+  while (rpb > 8 && seg->n_seg * cdiv(seg->rows_per_seg, rpb) < 2048) rpb >>= 1;
+  dim3 grid((unsigned)cdiv(seg->rows_per_seg, rpb), (unsigned)seg->n_seg);
+  const float sq = (float)sqrt((double)hd);
+  const int iters = (d % (64 * V) == 0) ? d / (64 * V) : 0;
+#define VSEL_SCORE_CASE(I)                                                                              \
+  case I: hipLaunchKernelGGL((score_kernel<T, I>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores); break;
+  switch (iters) {
+    VSEL_SCORE_CASE(1) VSEL_SCORE_CASE(2) VSEL_SCORE_CASE(3) VSEL_SCORE_CASE(4)
+    VSEL_SCORE_CASE(5) VSEL_SCORE_CASE(6) VSEL_SCORE_CASE(7) VSEL_SCORE_CASE(8)
+    default: hipLaunchKernelGGL((score_kernel<T, 0>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores);
+  }
+#undef VSEL_SCORE_CASE
+  VSEL_AFTER_LAUNCH(st, "score_kernel");
+  return VSEL_OK;
+}
+
+template <typename T, typename TW>
+inline int run_scores(hipStream_t st, const T* h, const vsel_segments* seg, const vsel_scorer* sc, char* ws,
+                      const LisPlan& p, float* scores) {
+  constexpr int V = Elem<T>::kVec;
+  const SegView sv = make_view(seg);
+  const int d = (int)sc->d, hd = (int)sc->hd, S = (int)seg->n_seg;
+  float* partial = (float*)(ws + p.off_partial);
+  float* xbar = (float*)(ws + p.off_xbar);
+  float* part1 = (float*)(ws + p.off_part1);
+  float* kbar = (float*)(ws + p.off_kbar);
+  float* c = (float*)(ws + p.off_c);
+  float* part2 = (float*)(ws + p.off_part2);
+  float* w = (float*)(ws + p.off_w);
+
+  hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3((unsigned)cdiv(d, 64 * V), p.row_splits, S), dim3(256), 0, st, h,
+                     sv, d, p.row_splits, partial);
+  VSEL_AFTER_LAUNCH(st, "colsum_partial_kernel");
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)cdiv(d, 256), S), dim3(256), 0, st, partial, sv, d,
+                     p.row_splits, xbar);
+  VSEL_AFTER_LAUNCH(st, "colsum_finish_kernel");
+  hipLaunchKernelGGL((gemm_nt_kernel<TW>), dim3((unsigned)cdiv(hd, 32), (unsigned)cdiv(S, 32), p.ks1), dim3(64), 0, st,
+                     xbar, (const TW*)sc->wk, S, hd, d, p.kslice1, part1);
+  VSEL_AFTER_LAUNCH(st, "gemm_nt_kernel");
+  hipLaunchKernelGGL((kbar_finish_kernel<TW>), dim3(S), dim3(256), 0, st, part1, p.ks1, S, hd, (const TW*)sc->bk,
+                     (const TW*)sc->bq, kbar, c);
+  VSEL_AFTER_LAUNCH(st, "kbar_finish_kernel");
+  hipLaunchKernelGGL((gemm_nn_kernel<TW>), dim3((unsigned)cdiv(d, 256), (unsigned)cdiv(S, 32), p.ks2), dim3(64), 0, st,
+                     kbar, (const TW*)sc->wq, S, d, hd, p.kslice2, part2);
+  VSEL_AFTER_LAUNCH(st, "gemm_nn_kernel");
+  hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)cdiv((int64_t)S * d, 256)), dim3(256), 0, st, part2, p.ks2,
+                     (int64_t)S * d, w);
+  VSEL_AFTER_LAUNCH(st, "slice_sum_kernel");
+  return launch_score<T>(st, h, sv, seg, d, w, c, hd, scores);
+}
+
+template <typename T>
+inline int run_scores_w(hipStream_t st, const T* h, const vsel_segments* seg, const vsel_scorer* sc, char* ws,
+                        const LisPlan& p, float* scores) {
+  if (sc->wdtype == VSEL_BF16) return run_scores<T, bf16_t>(st, h, seg, sc, ws, p, scores);
+  return run_scores<T, float>(st, h, seg, sc, ws, p, scores);
+}
+
+inline int launch_select(hipStream_t st, const float* scores, const vsel_segments* seg, int64_t* idx, float* mask) {
+  hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)seg->n_seg), dim3(1024), 0, st, scores, make_view(seg), idx, mask);
+  VSEL_AFTER_LAUNCH(st, "topk_select_kernel");
+  return VSEL_OK;
+}
+
+template <typename T>
+inline int launch_gather(hipStream_t st, const T* h, int d, const vsel_segments* seg, const int64_t* idx, T* out) {
+  int64_t rpb = 32;
+  while (rpb > 4 && seg->n_seg * cdiv(seg->k, rpb) < 2048) rpb >>= 1;
+  hipLaunchKernelGGL((gather_rows_kernel<T>), dim3((unsigned)cdiv(seg->k, rpb), (unsigned)seg->n_seg), dim3(256), 0, st, h,
+                     make_view(seg), d, idx, out, (int)rpb);
+  VSEL_AFTER_LAUNCH(st, "gather_rows_kernel");
+  return VSEL_OK;
+}
+
+}  // namespace vsel

@@ -1,0 +1,409 @@
+// Training LIS block (reference: qwen-vl-finetune/compression_method/selector_model.py:158-173 forward,
+// :308-311 constraint loss, :60-70 TopK.backward; llava-ov-15/compression_method/selector_model.py:127-142).
+//
+// forward : scores (lis_kernels.h) -> soft top-k (64-step bisection) -> h_new = ps * h -> hard mask y -> BCE
+// backward: closed form of autograd through the scorer (SURVEY.md section 7 hard part 4).  With g = dL/dscores,
+//           rs = 1/sqrt(Hd), xbar = mean x, kbar = Wk xbar + bk:
+//             dWq = (kbar rs) (x) sum_i g_i x_i        dbq = kbar rs sum_i g_i
+//             dk  = (Wq sum_i g_i x_i + bq sum_i g_i) rs / N
+//             dWk = dk (x) sum_i x_i                   dbk = N dk
+//             dx_i = ps_i dh'_i + g_i rs Wq^T kbar + Wk^T dk
+//           i.e. two more sweeps over the token tensor (row dots, weighted column sums) + GEMVs + rank-1 writes.
+#include "lis_kernels.h"
+
+namespace vsel {
+
+int launch_soft_topk_fwd(hipStream_t st, const float* xs, int64_t b, int64_t n, int64_t k, float* ps, float* ts);
+int launch_soft_topk_bwd(hipStream_t st, const float* g, const float* xs, const float* ts, int64_t b, int64_t n, float* gx);
+
+// h_new[i, :] = (ps[i] * h[i, :]).type(dtype)     (:164-166)   wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void mask_apply_kernel(const T* __restrict__ h, const float* __restrict__ ps, int n,
+                                                         int d, T* __restrict__ out) {
+  constexpr int V = Elem<T>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = blockIdx.x * 4 + wave; r < n; r += gridDim.x * 4) {
+    const float p = ps[r];
+    const T* src = h + (int64_t)r * d;
+    T* dst = out + (int64_t)r * d;
+    for (int c = lane * V; c < d; c += 64 * V) {
+      float v[V];
+      load_vec(src + c, v);
+#pragma unroll
+      for (int q = 0; q < V; ++q) v[q] *= p;
+      store_vec(dst + c, v);
+    }
+  }
+}
+
+// bce = mean_i -(y_i max(log p_i, -100) + (1 - y_i) max(log(1 - p_i), -100))     (:310, ATen clamp)
+__global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ ps, const float* __restrict__ y, int n,
+                                                   float* __restrict__ out) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float p = ps[i], t = y[i];
+    acc += (t - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - t * fmaxf(logf(p), -100.0f);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    out[0] = t / (float)n;
+  }
+}
+
+// dps[i] = <d_hnew[i,:], h[i,:]> + d_ps_ext[i] + dl_dbce * (p - y) / max((1 - p) p, 1e-12) / N     wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ dhn, const T* __restrict__ h,
+                                                     const float* __restrict__ ps, const float* __restrict__ y,
+                                                     const float* __restrict__ d_ps_ext, float dl_dbce, int n, int d,
+                                                     float* __restrict__ dps) {
+  constexpr int V = Elem<T>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = blockIdx.x * 4 + wave; r < n; r += gridDim.x * 4) {
+    const T* a = dhn + (int64_t)r * d;
+    const T* b = h + (int64_t)r * d;
+    float acc = 0.f;
+    for (int c = lane * V; c < d; c += 64 * V) {
+      float va[V], vb[V];
+      load_vec(a + c, va);
+      load_vec(b + c, vb);
+#pragma unroll
+      for (int q = 0; q < V; ++q) acc = fmaf(va[q], vb[q], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float p = ps[r];
+      float v = acc;
+      if (d_ps_ext) v += d_ps_ext[r];
+      if (dl_dbce != 0.f) v += dl_dbce * ((p - y[r]) / fmaxf((1.0f - p) * p, 1e-12f)) / (float)n;
+      dps[r] = v;
+    }
+  }
+}
+
+// partial[rs][0][c] = sum_i x[i][c], partial[rs][1][c] = sum_i g[i] x[i][c]   over the block's rows
+template <typename T>
+__global__ __launch_bounds__(256) void wcolsum_partial_kernel(const T* __restrict__ h, const float* __restrict__ g, int n,
+                                                              int d, int row_splits, float* __restrict__ partial) {
+  constexpr int V = Elem<T>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rs = blockIdx.y;
+  const int col = (blockIdx.x * 64 + lane) * V;
+  const int rows_per = (n + row_splits - 1) / row_splits;
+  const int rb = rs * rows_per, re = min(n, rb + rows_per);
+  float a0[V], a1[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+  if (col < d) {
+    for (int r = rb + wave; r < re; r += 4) {
+      float v[V];
+      load_vec(h + (int64_t)r * d + col, v);
+      const float gr = g[r];
+#pragma unroll
+      for (int i = 0; i < V; ++i) { a0[i] += v[i]; a1[i] = fmaf(gr, v[i], a1[i]); }
+    }
+  }
+  __shared__ float red[4][64][2 * V + 1];
+#pragma unroll
+  for (int i = 0; i < V; ++i) { red[wave][lane][i] = a0[i]; red[wave][lane][V + i] = a1[i]; }
+  __syncthreads();
+  if (wave == 0 && col < d) {
+    float* dst = partial + (int64_t)rs * 2 * d;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      dst[col + i] = (red[0][lane][i] + red[1][lane][i]) + (red[2][lane][i] + red[3][lane][i]);
+      dst[d + col + i] = (red[0][lane][V + i] + red[1][lane][V + i]) + (red[2][lane][V + i] + red[3][lane][V + i]);
+    }
+  }
+}
+
+// xsum[c], gx[c], xbar[c] = xsum / N; block 0 also reduces sg = sum_i g_i
+__global__ __launch_bounds__(256) void wcolsum_finish_kernel(const float* __restrict__ partial, const float* __restrict__ g,
+                                                             int n, int d, int row_splits, float* __restrict__ xsum,
+                                                             float* __restrict__ gx, float* __restrict__ xbar,
+                                                             float* __restrict__ sg) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < d) {
+    float a = 0.f, b = 0.f;
+    for (int rs = 0; rs < row_splits; ++rs) {
+      a += partial[(int64_t)rs * 2 * d + c];
+      b += partial[(int64_t)rs * 2 * d + d + c];
+    }
+    xsum[c] = a;
+    gx[c] = b;
+    xbar[c] = a / (float)n;
+  }
+  if (blockIdx.x == 0) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += g[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sg[0] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// dk[h] = (sum_ks part[ks][h] + bq[h] sg) rs / N ; dbk[h] = N dk[h] ; dbq[h] = kbar[h] rs sg ; a[h] = kbar[h] rs
+template <typename TW>
+__global__ __launch_bounds__(256) void dk_finish_kernel(const float* __restrict__ part, int KS, int hd,
+                                                        const TW* __restrict__ bq, const float* __restrict__ kbar,
+                                                        const float* __restrict__ sg, float rs, int n,
+                                                        float* __restrict__ dk, float* __restrict__ a,
+                                                        float* __restrict__ dbq, float* __restrict__ dbk) {
+  const int h = blockIdx.x * 256 + threadIdx.x;
+  if (h >= hd) return;
+  float v = 0.f;
+  for (int ks = 0; ks < KS; ++ks) v += part[(int64_t)ks * hd + h];
+  const float s = sg[0];
+  const float dkv = (v + load_elem(bq + h) * s) * rs / (float)n;
+  dk[h] = dkv;
+  dbk[h] = dkv * (float)n;
+  const float kb = kbar[h] * rs;
+  a[h] = kb;
+  dbq[h] = kb * s;
+}
+
+// out[r][c] = a[r] * b[c]   (rank-1 weight gradient, fp32)
+__global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ a, const float* __restrict__ b, int rows,
+                                                    int cols, float* __restrict__ out) {
+  const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c4 >= cols) return;
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(b + c4);
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float av = a[r];
+    f32x4 o = {av * bv[0], av * bv[1], av * bv[2], av * bv[3]};
+    *reinterpret_cast<f32x4*>(out + (int64_t)r * cols + c4) = o;
+  }
+}
+
+// dh[i,:] = ps[i] d_hnew[i,:] + (g[i] rs) w[:] + u[:]      (first term dropped when dhn == NULL)
+template <typename T>
+__global__ __launch_bounds__(256) void dh_kernel(const T* __restrict__ dhn, const float* __restrict__ ps,
+                                                 const float* __restrict__ g, const float* __restrict__ w,
+                                                 const float* __restrict__ u, float rs, int n, int d, T* __restrict__ dh) {
+  constexpr int V = Elem<T>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = blockIdx.x * 4 + wave; r < n; r += gridDim.x * 4) {
+    const float p = dhn ? ps[r] : 0.f, gr = g[r] * rs;
+    for (int c = lane * V; c < d; c += 64 * V) {
+      float v[V];
+      if (dhn) {
+        load_vec(dhn + (int64_t)r * d + c, v);
+      } else {
+#pragma unroll
+        for (int q = 0; q < V; ++q) v[q] = 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < V; ++q) v[q] = fmaf(p, v[q], fmaf(gr, w[c + q], u[c + q]));
+      store_vec(dh + (int64_t)r * d + c, v);
+    }
+  }
+}
+
+struct TrainPlan {
+  LisPlan lis;
+  int wsplits;
+  size_t off_dps, off_g, off_wpart, off_xsum, off_gx, off_sg, off_dkraw, off_dk, off_a, off_u, total;
+};
+
+static TrainPlan make_train_plan(int64_t n, int64_t d, int64_t hd) {
+  TrainPlan t{};
+  t.lis = make_plan(1, n, d, hd);
+  t.wsplits = t.lis.row_splits;
+  size_t o = t.lis.total;
+  auto take = [&](size_t nfloat) { size_t r = o; o += align_up(nfloat * sizeof(float), 256); return r; };
+  t.off_dps = take(n);
+  t.off_g = take(n);
+  t.off_wpart = take((size_t)t.wsplits * 2 * d);
+  t.off_xsum = take(d);
+  t.off_gx = take(d);
+  t.off_sg = take(1);
+  t.off_dkraw = take((size_t)t.lis.ks1 * hd);
+  t.off_dk = take(hd);
+  t.off_a = take(hd);
+  t.off_u = take(d);
+  t.total = o;
+  return t;
+}
+
+template <typename T, typename TW>
+static int train_fwd_impl(hipStream_t st, const T* h, int64_t n, int64_t k, const vsel_scorer* sc, char* ws,
+                          const TrainPlan& tp, T* h_new, float* ps, float* y, float* scores, float* ts, float* bce) {
+  vsel_segments seg{1, n, n, k, k, nullptr, nullptr};
+  int rc = run_scores<T, TW>(st, h, &seg, sc, ws, tp.lis, scores);
+  if (rc) return rc;
+  rc = launch_soft_topk_fwd(st, scores, 1, n, k, ps, ts);
+  if (rc) return rc;
+  rc = launch_select(st, scores, &seg, nullptr, y);
+  if (rc) return rc;
+  const int d = (int)sc->d;
+  hipLaunchKernelGGL((mask_apply_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv(n, 4), 4096)), dim3(256), 0, st, h, ps,
+                     (int)n, d, h_new);
+  VSEL_AFTER_LAUNCH(st, "mask_apply_kernel");
+  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, st, ps, y, (int)n, bce);
+  VSEL_AFTER_LAUNCH(st, "bce_kernel");
+  return VSEL_OK;
+}
+
+// Backward of scores = scorer(h) given g = dL/dscores [N] (g must live outside the workspace or at tp.off_g).
+template <typename T, typename TW>
+static int scores_bwd_impl(hipStream_t st, const float* g, const T* h, int64_t n, const vsel_scorer* sc, char* ws,
+                           const TrainPlan& tp, float* dwq, float* dbq, float* dwk, float* dbk, T* dh, const T* dhn,
+                           const float* ps) {
+  constexpr int V = Elem<T>::kVec;
+  const int d = (int)sc->d, hd = (int)sc->hd;
+  const LisPlan& p = tp.lis;
+  float* wpart = (float*)(ws + tp.off_wpart);
+  float* xsum = (float*)(ws + tp.off_xsum);
+  float* gx = (float*)(ws + tp.off_gx);
+  float* sg = (float*)(ws + tp.off_sg);
+  float* dkraw = (float*)(ws + tp.off_dkraw);
+  float* dk = (float*)(ws + tp.off_dk);
+  float* a = (float*)(ws + tp.off_a);
+  float* u = (float*)(ws + tp.off_u);
+  float* xbar = (float*)(ws + p.off_xbar);
+  float* part1 = (float*)(ws + p.off_part1);
+  float* kbar = (float*)(ws + p.off_kbar);
+  float* c = (float*)(ws + p.off_c);
+  float* part2 = (float*)(ws + p.off_part2);
+  float* w = (float*)(ws + p.off_w);
+  const float rs = 1.0f / (float)sqrt((double)hd);
+  const unsigned row_blocks = (unsigned)std::min<int64_t>(cdiv(n, 4), 4096);
+
+  hipLaunchKernelGGL((wcolsum_partial_kernel<T>), dim3((unsigned)cdiv(d, 64 * V), tp.wsplits), dim3(256), 0, st, h, g, (int)n,
+                     d, tp.wsplits, wpart);
+  VSEL_AFTER_LAUNCH(st, "wcolsum_partial_kernel");
+  hipLaunchKernelGGL(wcolsum_finish_kernel, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st, wpart, g, (int)n, d, tp.wsplits,
+                     xsum, gx, xbar, sg);
+  VSEL_AFTER_LAUNCH(st, "wcolsum_finish_kernel");
+  // kbar = Wk xbar + bk
+  hipLaunchKernelGGL((gemm_nt_kernel<TW>), dim3((unsigned)cdiv(hd, 32), 1, p.ks1), dim3(64), 0, st, xbar, (const TW*)sc->wk, 1,
+                     hd, d, p.kslice1, part1);
+  VSEL_AFTER_LAUNCH(st, "gemm_nt_kernel");
+  hipLaunchKernelGGL((kbar_finish_kernel<TW>), dim3(1), dim3(256), 0, st, part1, p.ks1, 1, hd, (const TW*)sc->bk,
+                     (const TW*)sc->bq, kbar, c);
+  VSEL_AFTER_LAUNCH(st, "kbar_finish_kernel");
+  // dk = (Wq gx + bq sg) rs / N
+  hipLaunchKernelGGL((gemm_nt_kernel<TW>), dim3((unsigned)cdiv(hd, 32), 1, p.ks1), dim3(64), 0, st, gx, (const TW*)sc->wq, 1,
+                     hd, d, p.kslice1, dkraw);
+  VSEL_AFTER_LAUNCH(st, "gemm_nt_kernel");
+  hipLaunchKernelGGL((dk_finish_kernel<TW>), dim3((unsigned)cdiv(hd, 256)), dim3(256), 0, st, dkraw, p.ks1, hd,
+                     (const TW*)sc->bq, kbar, sg, rs, (int)n, dk, a, dbq, dbk);
+  VSEL_AFTER_LAUNCH(st, "dk_finish_kernel");
+  const dim3 og((unsigned)cdiv(d, 1024), (unsigned)std::min<int>(hd, 512));
+  hipLaunchKernelGGL(outer_kernel, og, dim3(256), 0, st, a, gx, hd, d, dwq);
+  VSEL_AFTER_LAUNCH(st, "outer_kernel");
+  hipLaunchKernelGGL(outer_kernel, og, dim3(256), 0, st, dk, xsum, hd, d, dwk);
+  VSEL_AFTER_LAUNCH(st, "outer_kernel");
+  if (dh) {
+    hipLaunchKernelGGL((gemm_nn_kernel<TW>), dim3((unsigned)cdiv(d, 256), 1, p.ks2), dim3(64), 0, st, kbar, (const TW*)sc->wq, 1,
+                       d, hd, p.kslice2, part2);
+    VSEL_AFTER_LAUNCH(st, "gemm_nn_kernel");
+    hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st, part2, p.ks2, (int64_t)d, w);
+    VSEL_AFTER_LAUNCH(st, "slice_sum_kernel");
+    hipLaunchKernelGGL((gemm_nn_kernel<TW>), dim3((unsigned)cdiv(d, 256), 1, p.ks2), dim3(64), 0, st, dk, (const TW*)sc->wk, 1, d,
+                       hd, p.kslice2, part2);
+    VSEL_AFTER_LAUNCH(st, "gemm_nn_kernel");
+    hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st, part2, p.ks2, (int64_t)d, u);
+    VSEL_AFTER_LAUNCH(st, "slice_sum_kernel");
+    hipLaunchKernelGGL((dh_kernel<T>), dim3(row_blocks), dim3(256), 0, st, dhn, ps, g, w, u, rs, (int)n, d, dh);
+    VSEL_AFTER_LAUNCH(st, "dh_kernel");
+  }
+  return VSEL_OK;
+}
+
+template <typename T, typename TW>
+static int train_bwd_impl(hipStream_t st, const T* dhn, const T* h, int64_t n, const vsel_scorer* sc, const float* ps,
+                          const float* y, const float* scores, const float* ts, const float* d_ps_ext, float dl_dbce,
+                          char* ws, const TrainPlan& tp, float* dwq, float* dbq, float* dwk, float* dbk, T* dh) {
+  const int d = (int)sc->d;
+  float* dps = (float*)(ws + tp.off_dps);
+  float* g = (float*)(ws + tp.off_g);
+  const unsigned row_blocks = (unsigned)std::min<int64_t>(cdiv(n, 4), 4096);
+  hipLaunchKernelGGL((rowdot_kernel<T>), dim3(row_blocks), dim3(256), 0, st, dhn, h, ps, y, d_ps_ext, dl_dbce, (int)n, d, dps);
+  VSEL_AFTER_LAUNCH(st, "rowdot_kernel");
+  int rc = launch_soft_topk_bwd(st, dps, scores, ts, 1, n, g);
+  if (rc) return rc;
+  return scores_bwd_impl<T, TW>(st, g, h, n, sc, ws, tp, dwq, dbq, dwk, dbk, dh, dhn, ps);
+}
+
+}  // namespace vsel
+
+using namespace vsel;
+
+extern "C" size_t vsel_lis_train_workspace_bytes(int64_t n, int64_t d, int64_t hd) {
+  if (n < 1 || d < 1 || hd < 1) return 0;
+  return make_train_plan(n, d, hd).total;
+}
+
+static int train_checks(const void* h, vsel_dtype hdtype, int64_t n, const vsel_scorer* sc, void* ws, size_t ws_bytes,
+                        TrainPlan* tp) {
+  if (!h) return fail(VSEL_ERR_INVALID, "h is NULL");
+  if (n < 1 || n >= (1ll << 31)) return fail(VSEL_ERR_INVALID, "bad n=%lld", (long long)n);
+  int st = check_scorer(sc, hdtype);
+  if (st) return st;
+  *tp = make_train_plan(n, sc->d, sc->hd);
+  if (!ws || ws_bytes < tp->total) return fail(VSEL_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, tp->total);
+  if (((uintptr_t)h | (uintptr_t)ws | (uintptr_t)sc->wq | (uintptr_t)sc->wk) & 15)
+    return fail(VSEL_ERR_INVALID, "h / workspace / weights must be 16-byte aligned");
+  return VSEL_OK;
+}
+
+#define VSEL_DISPATCH2(hdtype, wdtype, CALL)                                        \
+  do {                                                                              \
+    if ((hdtype) == VSEL_BF16 && (wdtype) == VSEL_BF16) { using T = bf16_t; using TW = bf16_t; return CALL; } \
+    if ((hdtype) == VSEL_BF16 && (wdtype) == VSEL_F32) { using T = bf16_t; using TW = float; return CALL; }   \
+    if ((hdtype) == VSEL_F32 && (wdtype) == VSEL_BF16) { using T = float; using TW = bf16_t; return CALL; }   \
+    { using T = float; using TW = float; return CALL; }                             \
+  } while (0)
+
+extern "C" int vsel_lis_train_fwd(void* stream, const void* h, vsel_dtype hdtype, int64_t n, int64_t k,
+                                  const vsel_scorer* sc, void* ws, size_t ws_bytes, void* h_new, float* ps, float* y,
+                                  float* scores, float* ts, float* bce) {
+  TrainPlan tp;
+  int st = train_checks(h, hdtype, n, sc, ws, ws_bytes, &tp);
+  if (st) return st;
+  if (!h_new || !ps || !y || !scores || !ts || !bce) return fail(VSEL_ERR_INVALID, "output pointer is NULL");
+  // the reference's _find_ts asserts 0 < k < n (FT/compression_method/selector_model.py:75)
+  if (!(0 < k && k < n)) return fail(VSEL_ERR_INVALID, "training needs 0 < k < n (k=%lld, n=%lld)", (long long)k, (long long)n);
+  hipStream_t s = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(s);
+  VSEL_DISPATCH2(hdtype, sc->wdtype,
+                 (train_fwd_impl<T, TW>(s, (const T*)h, n, k, sc, (char*)ws, tp, (T*)h_new, ps, y, scores, ts, bce)));
+}
+
+extern "C" int vsel_lis_train_bwd(void* stream, const void* d_hnew, const void* h, vsel_dtype hdtype, int64_t n,
+                                  const vsel_scorer* sc, const float* ps, const float* y, const float* scores,
+                                  const float* ts, const float* d_ps_ext, float dl_dbce, void* ws, size_t ws_bytes,
+                                  float* dwq, float* dbq, float* dwk, float* dbk, void* dh) {
+  TrainPlan tp;
+  int st = train_checks(h, hdtype, n, sc, ws, ws_bytes, &tp);
+  if (st) return st;
+  if (!d_hnew || !ps || !y || !scores || !ts || !dwq || !dbq || !dwk || !dbk) return fail(VSEL_ERR_INVALID, "NULL pointer");
+  if (sc->d % 4) return fail(VSEL_ERR_UNSUPPORTED, "D must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(s);
+  VSEL_DISPATCH2(hdtype, sc->wdtype,
+                 (train_bwd_impl<T, TW>(s, (const T*)d_hnew, (const T*)h, n, sc, ps, y, scores, ts, d_ps_ext, dl_dbce,
+                                        (char*)ws, tp, dwq, dbq, dwk, dbk, (T*)dh)));
+}
+
+extern "C" int vsel_lis_scores_bwd(void* stream, const float* g, const void* h, vsel_dtype hdtype, int64_t n,
+                                   const vsel_scorer* sc, void* ws, size_t ws_bytes, float* dwq, float* dbq, float* dwk,
+                                   float* dbk, void* dh) {
+  TrainPlan tp;
+  int st = train_checks(h, hdtype, n, sc, ws, ws_bytes, &tp);
+  if (st) return st;
+  if (!g || !dwq || !dbq || !dwk || !dbk) return fail(VSEL_ERR_INVALID, "NULL pointer");
+  if (sc->d % 4) return fail(VSEL_ERR_UNSUPPORTED, "D must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(s);
+  VSEL_DISPATCH2(hdtype, sc->wdtype,
+                 (scores_bwd_impl<T, TW>(s, g, (const T*)h, n, sc, (char*)ws, tp, dwq, dbq, dwk, dbk, (T*)dh, (const T*)nullptr,
+                                         (const float*)nullptr)));
+}

@@ -1,0 +1,278 @@
+"""Torch-tensor front end of the C-ABI in include/vsel.h.
+
+Every function takes ROCm tensors, passes raw pointers + the current HIP stream to libvsel.so and
+returns torch tensors allocated by the caching allocator.  There is no CPU path: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as N
+
+_DT = {torch.bfloat16: N.VSEL_BF16, torch.float32: N.VSEL_F32}
+
+
+def _code(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"visionselector_amd supports bfloat16 / float32 tensors, got {t.dtype}") from None
+
+
+def _dev(*ts: torch.Tensor) -> torch.device:
+    d = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("visionselector_amd ops run on the GPU only (HIP kernels in libvsel.so); "
+                               f"got a tensor on {t.device}.  There is no CPU fallback.")
+        if not t.is_contiguous():
+            raise RuntimeError("visionselector_amd ops need contiguous tensors")
+        if d is None:
+            d = t.device
+        elif t.device != d:
+            raise RuntimeError(f"tensors on different devices: {d} vs {t.device}")
+    return d
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _scorer(wq, bq, wk, bk) -> N.Scorer:
+    hd, d = wq.shape
+    if wk.shape != (hd, d) or bq.shape != (hd,) or bk.shape != (hd,):
+        raise ValueError(f"scorer parameter shapes disagree: wq {tuple(wq.shape)} wk {tuple(wk.shape)} "
+                         f"bq {tuple(bq.shape)} bk {tuple(bk.shape)}")
+    if not (wq.dtype == wk.dtype == bq.dtype == bk.dtype):
+        raise TypeError("scorer parameters must share one dtype")
+    return N.Scorer(wq.data_ptr(), bq.data_ptr(), wk.data_ptr(), bk.data_ptr(), d, hd, _code(wq))
+
+
+_seg_cache: dict = {}
+
+
+def _uniform_segments(b: int, n: int, k: int) -> N.Segments:
+    return N.Segments(b, n, b * n, k, b * k, None, None)
+
+
+def _ragged_segments(seg_lens: Sequence[int], ks: Sequence[int], device) -> Tuple[N.Segments, torch.Tensor, torch.Tensor]:
+    key = (tuple(seg_lens), tuple(ks), str(device))
+    hit = _seg_cache.get(key)
+    if hit is None:
+        cu_r = torch.tensor([0] + list(seg_lens), dtype=torch.int64).cumsum(0).to(torch.int32)
+        cu_o = torch.tensor([0] + list(ks), dtype=torch.int64).cumsum(0).to(torch.int32)
+        hit = (cu_r.to(device), cu_o.to(device), int(cu_r[-1]), int(cu_o[-1]))
+        if len(_seg_cache) > 256:
+            _seg_cache.clear()
+        _seg_cache[key] = hit
+    cu_r, cu_o, total, total_out = hit
+    seg = N.Segments(len(seg_lens), max(seg_lens), total, max(ks), total_out, cu_r.data_ptr(), cu_o.data_ptr())
+    return seg, cu_r, cu_o
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+
+
+def _as_bnd(h: torch.Tensor) -> Tuple[int, int, int]:
+    if h.dim() == 2:
+        return 1, h.shape[0], h.shape[1]
+    if h.dim() == 3:
+        return h.shape[0], h.shape[1], h.shape[2]
+    raise ValueError(f"tokens must be [N, D] or [B, N, D], got {tuple(h.shape)}")
+
+
+# ------------------------------------------------------------------------------------------------
+# inference
+# ------------------------------------------------------------------------------------------------
+
+def lis_scores(h, wq, bq, wk, bk) -> torch.Tensor:
+    """TransformerScorer.forward: h [B,N,D] (or [N,D]) -> fp32 scores [B,N] (or [N])."""
+    dev = _dev(h, wq, bq, wk, bk)
+    b, n, d = _as_bnd(h)
+    sc = _scorer(wq, bq, wk, bk)
+    if sc.d != d:
+        raise ValueError(f"token width {d} != scorer in_features {sc.d}")
+    seg = _uniform_segments(b, n, 1)
+    lib = N.lib()
+    ws = _workspace(lib.vsel_lis_workspace_bytes(C.byref(seg), d, sc.hd), dev)
+    scores = torch.empty(h.shape[:-1], dtype=torch.float32, device=dev)
+    N.check(lib.vsel_lis_scores(_stream(), h.data_ptr(), _code(h), C.byref(seg), C.byref(sc), ws.data_ptr(), ws.numel(),
+                                scores.data_ptr()))
+    return scores
+
+
+def lis_select(h, wq, bq, wk, bk, k: int):
+    """Fused score + hard top-k + gather.  h [B,N,D] or [N,D] -> (out [B,k,D], idx int64 [B,k] ascending, scores fp32 [B,N])."""
+    dev = _dev(h, wq, bq, wk, bk)
+    b, n, d = _as_bnd(h)
+    sc = _scorer(wq, bq, wk, bk)
+    if sc.d != d:
+        raise ValueError(f"token width {d} != scorer in_features {sc.d}")
+    seg = _uniform_segments(b, n, int(k))
+    lib = N.lib()
+    ws = _workspace(lib.vsel_lis_workspace_bytes(C.byref(seg), d, sc.hd), dev)
+    lead = h.shape[:-2]
+    out = torch.empty(*lead, k, d, dtype=h.dtype, device=dev)
+    idx = torch.empty(*lead, k, dtype=torch.int64, device=dev)
+    scores = torch.empty(*lead, n, dtype=torch.float32, device=dev)
+    N.check(lib.vsel_lis_select(_stream(), h.data_ptr(), _code(h), C.byref(seg), C.byref(sc), ws.data_ptr(), ws.numel(),
+                                out.data_ptr(), idx.data_ptr(), scores.data_ptr()))
+    return out, idx, scores
+
+
+def lis_select_varlen(h, seg_lens: Sequence[int], ks: Sequence[int], wq, bq, wk, bk):
+    """Ragged form: h [T,D] holds len(seg_lens) segments back to back; segment s keeps ks[s] rows.
+    -> (out [sum ks, D], idx int64 [sum ks] local to the segment, scores fp32 [T])."""
+    dev = _dev(h, wq, bq, wk, bk)
+    if h.dim() != 2:
+        raise ValueError("ragged tokens must be [T, D]")
+    if len(seg_lens) != len(ks) or len(ks) == 0:
+        raise ValueError("seg_lens and ks must have the same non-zero length")
+    for n_s, k_s in zip(seg_lens, ks):
+        if not (1 <= k_s <= n_s):
+            raise ValueError(f"need 1 <= k <= rows per segment, got k={k_s}, rows={n_s}")
+    t, d = h.shape
+    if sum(seg_lens) != t:
+        raise ValueError(f"sum(seg_lens)={sum(seg_lens)} != rows {t}")
+    sc = _scorer(wq, bq, wk, bk)
+    seg, cu_r, cu_o = _ragged_segments(seg_lens, ks, dev)
+    lib = N.lib()
+    ws = _workspace(lib.vsel_lis_workspace_bytes(C.byref(seg), d, sc.hd), dev)
+    out = torch.empty(seg.total_out, d, dtype=h.dtype, device=dev)
+    idx = torch.empty(seg.total_out, dtype=torch.int64, device=dev)
+    scores = torch.empty(t, dtype=torch.float32, device=dev)
+    N.check(lib.vsel_lis_select(_stream(), h.data_ptr(), _code(h), C.byref(seg), C.byref(sc), ws.data_ptr(), ws.numel(),
+                                out.data_ptr(), idx.data_ptr(), scores.data_ptr()))
+    return out, idx, scores
+
+
+def hard_topk(scores: torch.Tensor, k: int, want_mask: bool = False):
+    """scores fp32 [B,N] or [N] -> idx int64 [B,k] ascending (topk(k).indices.sort()); optional 0/1 mask."""
+    dev = _dev(scores)
+    if scores.dtype != torch.float32:
+        raise TypeError("hard_topk takes float32 scores")
+    b = 1 if scores.dim() == 1 else scores.shape[0]
+    n = scores.shape[-1]
+    seg = _uniform_segments(b, n, int(k))
+    idx = torch.empty(*scores.shape[:-1], k, dtype=torch.int64, device=dev)
+    mask = torch.empty_like(scores) if want_mask else None
+    N.check(N.lib().vsel_topk_select(_stream(), scores.data_ptr(), C.byref(seg), idx.data_ptr(), _p(mask)))
+    return (idx, mask) if want_mask else idx
+
+
+def gather_rows(h: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """h [B,N,D] / [N,D], idx int64 [B,k] / [k] -> h[idx] per segment."""
+    dev = _dev(h, idx)
+    b, n, d = _as_bnd(h)
+    k = idx.shape[-1]
+    seg = _uniform_segments(b, n, k)
+    out = torch.empty(*h.shape[:-2], k, d, dtype=h.dtype, device=dev)
+    N.check(N.lib().vsel_gather_rows(_stream(), h.data_ptr(), _code(h), d, C.byref(seg), idx.data_ptr(), out.data_ptr()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# differentiable top-k
+# ------------------------------------------------------------------------------------------------
+
+def soft_topk_fwd(xs: torch.Tensor, k: int):
+    dev = _dev(xs)
+    if xs.dtype != torch.float32 or xs.dim() != 2:
+        raise TypeError("soft_topk_fwd takes float32 [B, N]")
+    b, n = xs.shape
+    ps = torch.empty_like(xs)
+    ts = torch.empty(b, dtype=torch.float32, device=dev)
+    N.check(N.lib().vsel_soft_topk_fwd(_stream(), xs.data_ptr(), b, n, int(k), ps.data_ptr(), ts.data_ptr()))
+    return ps, ts
+
+
+def soft_topk_bwd(grad_ps: torch.Tensor, xs: torch.Tensor, ts: torch.Tensor) -> torch.Tensor:
+    _dev(grad_ps, xs, ts)
+    b, n = xs.shape
+    out = torch.empty_like(xs)
+    N.check(N.lib().vsel_soft_topk_bwd(_stream(), grad_ps.data_ptr(), xs.data_ptr(), ts.data_ptr(), b, n, out.data_ptr()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# training block
+# ------------------------------------------------------------------------------------------------
+
+def lis_train_fwd(h, wq, bq, wk, bk, k: int):
+    """One segment h [N,D] -> (h_new [N,D], ps [N], y [N], scores [N], ts [1], bce [1])."""
+    dev = _dev(h, wq, bq, wk, bk)
+    n, d = h.shape
+    sc = _scorer(wq, bq, wk, bk)
+    lib = N.lib()
+    ws = _workspace(lib.vsel_lis_train_workspace_bytes(n, d, sc.hd), dev)
+    h_new = torch.empty_like(h)
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    ps, y, scores, ts, bce = f(n), f(n), f(n), f(1), f(1)
+    N.check(lib.vsel_lis_train_fwd(_stream(), h.data_ptr(), _code(h), n, int(k), C.byref(sc), ws.data_ptr(), ws.numel(),
+                                   h_new.data_ptr(), ps.data_ptr(), y.data_ptr(), scores.data_ptr(), ts.data_ptr(),
+                                   bce.data_ptr()))
+    return h_new, ps, y, scores, ts, bce
+
+
+def lis_train_bwd(d_hnew, h, wq, bq, wk, bk, ps, y, scores, ts, d_ps_ext=None, dl_dbce: float = 0.0, need_dh: bool = False):
+    """-> (dwq, dbq, dwk, dbk fp32, dh or None)."""
+    dev = _dev(d_hnew, h, wq, bq, wk, bk, ps, y, scores, ts, d_ps_ext)
+    n, d = h.shape
+    sc = _scorer(wq, bq, wk, bk)
+    lib = N.lib()
+    ws = _workspace(lib.vsel_lis_train_workspace_bytes(n, d, sc.hd), dev)
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    dwq, dbq, dwk, dbk = f(sc.hd, d), f(sc.hd), f(sc.hd, d), f(sc.hd)
+    dh = torch.empty_like(h) if need_dh else None
+    N.check(lib.vsel_lis_train_bwd(_stream(), d_hnew.data_ptr(), h.data_ptr(), _code(h), n, C.byref(sc), ps.data_ptr(),
+                                   y.data_ptr(), scores.data_ptr(), ts.data_ptr(), _p(d_ps_ext), float(dl_dbce),
+                                   ws.data_ptr(), ws.numel(), dwq.data_ptr(), dbq.data_ptr(), dwk.data_ptr(),
+                                   dbk.data_ptr(), _p(dh)))
+    return dwq, dbq, dwk, dbk, dh
+
+
+def lis_scores_bwd(g, h, wq, bq, wk, bk, need_dh: bool = False):
+    """Backward of lis_scores for one segment: g fp32 [N], h [N,D] -> (dwq, dbq, dwk, dbk fp32, dh or None)."""
+    dev = _dev(g, h, wq, bq, wk, bk)
+    n, d = h.shape
+    sc = _scorer(wq, bq, wk, bk)
+    lib = N.lib()
+    ws = _workspace(lib.vsel_lis_train_workspace_bytes(n, d, sc.hd), dev)
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    dwq, dbq, dwk, dbk = f(sc.hd, d), f(sc.hd), f(sc.hd, d), f(sc.hd)
+    dh = torch.empty_like(h) if need_dh else None
+    N.check(lib.vsel_lis_scores_bwd(_stream(), g.data_ptr(), h.data_ptr(), _code(h), n, C.byref(sc), ws.data_ptr(),
+                                    ws.numel(), dwq.data_ptr(), dbq.data_ptr(), dwk.data_ptr(), dbk.data_ptr(), _p(dh)))
+    return dwq, dbq, dwk, dbk, dh
+
+
+# ------------------------------------------------------------------------------------------------
+# var-len attention
+# ------------------------------------------------------------------------------------------------
+
+def varlen_attn(q, k, v, cu_seqlens: torch.Tensor, max_seqlen: int, causal: bool = True,
+                softmax_scale: Optional[float] = None) -> torch.Tensor:
+    """q [T,Hq,d], k/v [T,Hkv,d] bf16, cu_seqlens int32 [S+1] on device -> out [T,Hq,d]."""
+    dev = _dev(q, k, v, cu_seqlens)
+    if q.dtype != torch.bfloat16 or k.dtype != torch.bfloat16 or v.dtype != torch.bfloat16:
+        raise TypeError("varlen_attn takes bfloat16 q/k/v")
+    if cu_seqlens.dtype != torch.int32:
+        raise TypeError("cu_seqlens must be int32")
+    t, hq, d = q.shape
+    hkv = k.shape[1]
+    scale = float(softmax_scale) if softmax_scale is not None else d ** -0.5
+    out = torch.empty_like(q)
+    N.check(N.lib().vsel_varlen_attn_fwd(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), cu_seqlens.data_ptr(),
+                                         cu_seqlens.numel() - 1, int(max_seqlen), t, hq, hkv, d, scale, int(causal),
+                                         out.data_ptr()))
+    return out

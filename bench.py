@@ -47,30 +47,38 @@ def kernel_bytes(name, b, n, d, hd, k, e=2):
     }.get(name)
 
 
-def cpu_baseline(budget, seconds_budget=12.0):
-    """The reference formulation on the host cores (oracle/lis_torch.py = same ATen ops as the reference)."""
+def cpu_baseline(budget, seconds_budget=14.0):
+    """The reference formulation on the host cores (oracle/lis_torch.py = same ATen ops as the reference).
+    The thread count is swept (all cores is NOT the fastest on a many-core host for one 2304-token image)
+    and the best configuration is reported; `cores` = the threads of that configuration."""
     from oracle import lis_torch
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     g = torch.Generator().manual_seed(1234)
     h = torch.randn(N_VIS, D, generator=g).bfloat16().float()
     wq = (0.02 * torch.randn(HD, D, generator=g)).bfloat16().float()
     wk = (0.02 * torch.randn(HD, D, generator=g)).bfloat16().float()
     bq = (0.02 * torch.randn(HD, generator=g)).bfloat16().float()
     bk = (0.02 * torch.randn(HD, generator=g)).bfloat16().float()
-    for _ in range(2):
+    cands = sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu} or {ncpu})
+    best = None
+    per = seconds_budget / len(cands)
+    total = 0
+    for threads in cands:
+        torch.set_num_threads(threads)
         lis_torch.select_forward(h, wq, bq, wk, bk, budget)
-    times = []
-    t_end = time.perf_counter() + seconds_budget
-    while len(times) < 40 and (time.perf_counter() < t_end or len(times) < 3):
-        t0 = time.perf_counter()
-        lis_torch.select_forward(h, wq, bq, wk, bk, budget)
-        times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {"value": N_VIS / best, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} images of N={N_VIS}, D={D}, Hd={HD}, fp32 reference formulation "
-                      f"(2 GEMMs + NxN matmul + mean + topk + sort + gather), torch CPU {torch.get_num_threads()} threads, best-of",
-            "ms_per_image": best * 1e3, "ms_per_image_median": sorted(times)[len(times) // 2] * 1e3}
+        times = []
+        t_end = time.perf_counter() + per
+        while len(times) < 20 and (time.perf_counter() < t_end or len(times) < 2):
+            t0 = time.perf_counter()
+            lis_torch.select_forward(h, wq, bq, wk, bk, budget)
+            times.append(time.perf_counter() - t0)
+        total += len(times)
+        if best is None or min(times) < best[0]:
+            best = (min(times), threads, sorted(times)[len(times) // 2])
+    return {"value": N_VIS / best[0], "unit": "tokens/s", "cores": best[1], "kind": "port", "host_cpus": ncpu,
+            "sample": f"{total} images of N={N_VIS}, D={D}, Hd={HD} over thread counts {cands}: fp32 reference formulation "
+                      f"(2 GEMMs + NxN matmul + mean + topk + sort + gather) in torch CPU, best-of at {best[1]} threads",
+            "ms_per_image": best[0] * 1e3, "ms_per_image_median": best[2] * 1e3}
 
 
 def main():

@@ -56,6 +56,9 @@ def lib() -> C.CDLL:
     """Load libvsel.so once.  Raises (never falls back) if it has not been built."""
     global _lib
     if _lib is None:
+        # torch first: its bundled HIP runtime must be the one in the process (loading libvsel.so before torch
+        # pulls in /opt/rocm's libamdhip64 instead, which then sees no device under the torch wheel).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -m visionselector_amd.build` "

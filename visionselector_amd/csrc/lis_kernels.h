@@ -12,7 +12,9 @@
 // bit-for-bit with the fp32 CPU oracle on tie-free inputs).
 #pragma once
 #include "common.h"
+#include "proj_bf16x3.h"
 #include <algorithm>
+#include <type_traits>
 #include <math.h>
 
 namespace vsel {
@@ -243,6 +245,24 @@ static __global__ __launch_bounds__(256) void slice_sum_kernel(const float* __re
   out[e] = v;
 }
 
+template <typename T>
+__device__ __forceinline__ float dot_raw(u32x4 raw, const float (&w)[Elem<T>::kVec], float acc);
+template <>
+__device__ __forceinline__ float dot_raw<bf16_t>(u32x4 raw, const float (&w)[8], float acc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    acc = fmaf(__uint_as_float(raw[i] << 16), w[2 * i], acc);
+    acc = fmaf(__uint_as_float(raw[i] & 0xffff0000u), w[2 * i + 1], acc);
+  }
+  return acc;
+}
+template <>
+__device__ __forceinline__ float dot_raw<float>(u32x4 raw, const float (&w)[4], float acc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc = fmaf(__uint_as_float(raw[i]), w[i], acc);
+  return acc;
+}
+
 // =================================================================================================
 // K4  scores[row] = (x_row . w[s] + c[s]) / sqrt(Hd).  grid (row_chunks, n_seg), block 256.
 //     ITERS > 0: D == ITERS * 64 * V exactly and w[s] lives in registers; ITERS == 0: generic.
@@ -273,24 +293,23 @@ __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, Seg
         for (int z = 0; z < 4; ++z) wr[it][q + z] = t4[z];
       }
     }
+    // rows are kept as raw 16-byte vectors until the FMAs (4 VGPRs per load instead of 8 converted floats)
     const T* base = h + r0 * (int64_t)d + lane * V;
     int r = rb + wave;
     for (; r + 4 < re; r += 8) {
       const T* p0 = base + (int64_t)r * d;
       const T* p1 = base + (int64_t)(r + 4) * d;
-      float x0[ITERS][V], x1[ITERS][V];
+      u32x4 x0[ITERS], x1[ITERS];
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) load_vec(p0 + it * 64 * V, x0[it]);
+      for (int it = 0; it < ITERS; ++it) x0[it] = *reinterpret_cast<const u32x4*>(p0 + it * 64 * V);
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) load_vec(p1 + it * 64 * V, x1[it]);
+      for (int it = 0; it < ITERS; ++it) x1[it] = *reinterpret_cast<const u32x4*>(p1 + it * 64 * V);
       float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it)
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-          a0 = fmaf(x0[it][q], wr[it][q], a0);
-          a1 = fmaf(x1[it][q], wr[it][q], a1);
-        }
+      for (int it = 0; it < ITERS; ++it) {
+        a0 = dot_raw<T>(x0[it], wr[it], a0);
+        a1 = dot_raw<T>(x1[it], wr[it], a1);
+      }
       a0 = wave_sum(a0);
       a1 = wave_sum(a1);
       if (lane == 0) {
@@ -300,14 +319,12 @@ __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, Seg
     }
     for (; r < re; r += 4) {
       const T* p0 = base + (int64_t)r * d;
+      u32x4 x0[ITERS];
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) x0[it] = *reinterpret_cast<const u32x4*>(p0 + it * 64 * V);
       float a0 = 0.f;
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) {
-        float x0[V];
-        load_vec(p0 + it * 64 * V, x0);
-#pragma unroll
-        for (int q = 0; q < V; ++q) a0 = fmaf(x0[q], wr[it][q], a0);
-      }
+      for (int it = 0; it < ITERS; ++it) a0 = dot_raw<T>(x0[it], wr[it], a0);
       a0 = wave_sum(a0);
       if (lane == 0) scores[r0 + r] = (a0 + cs) / sqrt_hd;
     }
@@ -461,25 +478,37 @@ struct LisPlan {
   int row_splits;
   int ks1, kslice1;  // kbar projection  [S, D] x [Hd, D]^T
   int ks2, kslice2;  // w projection     [S, Hd] x [Hd, D]
-  size_t off_partial, off_xbar, off_part1, off_kbar, off_c, off_part2, off_w, total;
+  int n_cpart;       // blocks of 256 over Hd
+  bool mfma_bf16;    // shapes allow the bf16x3 MFMA projections (K % 16 == 0); weights must also be bf16
+  size_t off_partial, off_xbar, off_part1, off_kbar, off_c, off_part2, off_w, off_xs, off_ksp, off_cpart, total;
 };
+
+// Split-K factor: enough waves to cover the chip, partial slab <= ~16 MB, slices a multiple of `quantum`.
+inline void pick_split(int64_t tiles, int64_t target_waves, int64_t m, int64_t n, int64_t k, int quantum, int* ks,
+                       int* kslice) {
+  int64_t want = cdiv(target_waves, tiles);
+  const int64_t cap_bytes = std::max<int64_t>(1, (16ll << 20) / std::max<int64_t>(1, m * n * 4));
+  want = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, cap_bytes), std::max<int64_t>(1, k / (2 * quantum))));
+  *kslice = (int)(cdiv(cdiv(k, want), quantum) * quantum);
+  *ks = (int)cdiv(k, *kslice);
+}
 
 inline LisPlan make_plan(int64_t S, int64_t maxn, int64_t d, int64_t hd) {
   LisPlan p{};
   p.S = S; p.maxn = maxn; p.d = d; p.hd = hd;
-  const int64_t col_tiles = cdiv(d, 512);
-  int64_t rs = cdiv(1024, S * col_tiles);
-  rs = std::max<int64_t>(1, std::min<int64_t>(rs, std::max<int64_t>(1, maxn / 32)));
-  p.row_splits = (int)rs;
+  // sweep 1: 512-column tiles x equal row chunks (128 rows when there is enough work, finer for few segments).
+  // (A whole-row-per-wave variant measured 5 % slower on MI355X: 235 vs 223 us at B=64.)
+  {
+    const int64_t col_tiles = cdiv(d, 512);
+    int64_t rpb = 128;
+    while (rpb > 32 && S * col_tiles * cdiv(maxn, rpb) < 2048) rpb >>= 1;
+    p.row_splits = (int)std::max<int64_t>(1, cdiv(maxn, rpb));
+  }
   const int64_t mt = cdiv(S, 32);
-  int64_t ks1 = cdiv(2048, cdiv(hd, 32) * mt);
-  ks1 = std::max<int64_t>(1, std::min<int64_t>(ks1, std::max<int64_t>(1, d / 64)));
-  p.kslice1 = (int)(cdiv(cdiv(d, ks1), 16) * 16);
-  p.ks1 = (int)cdiv(d, p.kslice1);
-  int64_t ks2 = cdiv(1024, cdiv(d, 256) * mt);
-  ks2 = std::max<int64_t>(1, std::min<int64_t>(ks2, std::max<int64_t>(1, hd / 16)));
-  p.kslice2 = (int)(cdiv(cdiv(hd, ks2), 8) * 8);
-  p.ks2 = (int)cdiv(hd, p.kslice2);
+  p.mfma_bf16 = (d % 16 == 0) && (hd % 16 == 0);
+  pick_split(cdiv(hd, 32) * mt, 1536, S, hd, d, 16, &p.ks1, &p.kslice1);
+  pick_split(cdiv(d, 256) * mt, 768, S, d, hd, 16, &p.ks2, &p.kslice2);
+  p.n_cpart = (int)cdiv(hd, 256);
   size_t o = 0;
   auto take = [&](size_t nfloat) { size_t r = o; o += align_up(nfloat * sizeof(float), 256); return r; };
   p.off_partial = take((size_t)S * p.row_splits * d);
@@ -489,6 +518,9 @@ inline LisPlan make_plan(int64_t S, int64_t maxn, int64_t d, int64_t hd) {
   p.off_c = take((size_t)S);
   p.off_part2 = take((size_t)p.ks2 * S * d);
   p.off_w = take((size_t)S * d);
+  p.off_xs = take(((size_t)3 * S * d + 1) / 2);
+  p.off_ksp = take(((size_t)3 * S * hd + 1) / 2);
+  p.off_cpart = take((size_t)S * p.n_cpart);
   p.total = o;
   return p;
 }
@@ -545,6 +577,15 @@ inline int launch_score(hipStream_t st, const T* h, const SegView& sv, const vse
   return VSEL_OK;
 }
 
+template <typename T>
+inline int launch_colsum(hipStream_t st, const T* h, const SegView& sv, int d, int S, int row_splits, float* partial) {
+  constexpr int V = Elem<T>::kVec;
+  hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3((unsigned)cdiv(d, 64 * V), row_splits, S), dim3(256), 0, st, h, sv, d,
+                     row_splits, partial);
+  VSEL_AFTER_LAUNCH(st, "colsum_partial_kernel");
+  return VSEL_OK;
+}
+
 template <typename T, typename TW>
 inline int run_scores(hipStream_t st, const T* h, const vsel_segments* seg, const vsel_scorer* sc, char* ws,
                       const LisPlan& p, float* scores) {
@@ -559,9 +600,35 @@ inline int run_scores(hipStream_t st, const T* h, const vsel_segments* seg, cons
   float* part2 = (float*)(ws + p.off_part2);
   float* w = (float*)(ws + p.off_w);
 
-  hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3((unsigned)cdiv(d, 64 * V), p.row_splits, S), dim3(256), 0, st, h,
-                     sv, d, p.row_splits, partial);
-  VSEL_AFTER_LAUNCH(st, "colsum_partial_kernel");
+  {
+    int rc = launch_colsum<T>(st, h, sv, d, S, p.row_splits, partial);
+    if (rc) return rc;
+  }
+  if constexpr (std::is_same<TW, bf16_t>::value) {
+    if (p.mfma_bf16) {
+      // bf16x3 MFMA projections (proj_bf16x3.h)
+      uint16_t* xs = (uint16_t*)(ws + p.off_xs);
+      uint16_t* ksp = (uint16_t*)(ws + p.off_ksp);
+      float* cpart = (float*)(ws + p.off_cpart);
+      hipLaunchKernelGGL(colsum_finish_split_kernel, dim3((unsigned)cdiv(d, 256), S), dim3(256), 0, st, partial, sv, d,
+                         p.row_splits, S, xs);
+      VSEL_AFTER_LAUNCH(st, "colsum_finish_split_kernel");
+      hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, dim3((unsigned)cdiv(hd, 32), (unsigned)cdiv(S, 32), p.ks1), dim3(64), 0, st,
+                         xs, (const uint16_t*)sc->wk, S, hd, d, p.kslice1, part1);
+      VSEL_AFTER_LAUNCH(st, "gemm_nt_bf16x3_kernel");
+      hipLaunchKernelGGL(kbar_finish_split_kernel, dim3(p.n_cpart, S), dim3(256), 0, st, part1, p.ks1, S, hd,
+                         (const uint16_t*)sc->bk, (const uint16_t*)sc->bq, kbar, ksp, cpart);
+      VSEL_AFTER_LAUNCH(st, "kbar_finish_split_kernel");
+      hipLaunchKernelGGL(gemm_nn_bf16x3_kernel, dim3((unsigned)cdiv(d, 256), (unsigned)cdiv(S, 32), p.ks2), dim3(64), 0, st,
+                         ksp, (const uint16_t*)sc->wq, S, d, hd, p.kslice2, part2);
+      VSEL_AFTER_LAUNCH(st, "gemm_nn_bf16x3_kernel");
+      hipLaunchKernelGGL(w_finish_kernel, dim3((unsigned)cdiv(d, 256), S), dim3(256), 0, st, part2, p.ks2, S, d, cpart,
+                         p.n_cpart, w, c);
+      VSEL_AFTER_LAUNCH(st, "w_finish_kernel");
+      return launch_score<T>(st, h, sv, seg, d, w, c, hd, scores);
+    }
+  }
+  // generic path: fp32-input MFMA (fp32 weights, or K not a multiple of 16)
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)cdiv(d, 256), S), dim3(256), 0, st, partial, sv, d,
                      p.row_splits, xbar);
   VSEL_AFTER_LAUNCH(st, "colsum_finish_kernel");

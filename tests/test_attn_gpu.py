@@ -1,0 +1,100 @@
+"""GPU parity tests of the var-len causal GQA attention kernel against the eager-formula oracle (oracle/attention.py,
+fp64).  Parity is UNPINNED against flash_attn itself (third party, not in the reference tree) -- see the oracle header."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention as oattn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from visionselector_amd import ops as _ops
+    return _ops
+
+
+def make_qkv(total, hq, hkv, seed, spike=False):
+    rng = np.random.default_rng(seed)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s, dtype=np.float32)).bfloat16()  # noqa: E731
+    q, k, v = f(total, hq, 128), f(total, hkv, 128), f(total, hkv, 128)
+    if spike:      # force large running-max jumps late in the sequence (online-softmax rescale path)
+        k[total // 2] *= 6
+        k[total - 3] *= 9
+    return q, k, v
+
+
+def run_case(ops, lens, hq, hkv, causal, seed, spike=False):
+    total = sum(lens)
+    q, k, v = make_qkv(total, hq, hkv, seed, spike)
+    cu = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    out = ops.varlen_attn(q.cuda(), k.cuda(), v.cuda(), torch.from_numpy(cu).cuda(), max(lens), causal=causal)
+    ref = oattn.varlen_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu, causal=causal)
+    got = out.float().cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref)
+    return err.max(), err.mean(), np.abs(ref).max()
+
+
+# TOLERANCE.  Inputs are bf16, P is rounded to bf16 before P.V (as flash-attn does) and the output is stored as bf16
+# (unit roundoff 2^-9 = 2e-3 relative).  Against the fp64 eager formula that gives max |err| of a few 1e-3 for
+# |O| <= ~3 and a mean |err| < 1e-3; the gates are max <= 8e-3 * max(1, |O|max) and mean <= 1e-3.
+def check(err_max, err_mean, omax):
+    assert err_max <= 8e-3 * max(1.0, omax), (err_max, err_mean, omax)
+    assert err_mean <= 1e-3, (err_max, err_mean, omax)
+
+
+@pytest.mark.parametrize("lens,hq,hkv", [([100], 4, 2), ([128], 2, 2), ([129], 4, 1), ([1], 2, 1), ([64, 65, 3, 200], 4, 2),
+                                         ([524], 28, 4), ([37, 300, 5], 8, 8)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_attention_matches_eager_oracle(ops, lens, hq, hkv, causal):
+    check(*run_case(ops, lens, hq, hkv, causal, seed=len(lens) * 7 + hq))
+
+
+def test_attention_rescale_path(ops):
+    """Keys with huge logits late in the sequence force the running max to jump (online-softmax rescale)."""
+    check(*run_case(ops, [700], 4, 2, True, seed=5, spike=True))
+    check(*run_case(ops, [333, 260], 4, 4, False, seed=6, spike=True))
+
+
+def test_attention_transpose_read_equals_plain_reads(ops):
+    """The ds_read_b64_tr_b16 V^T fragments and plain 16-bit column reads give bit-identical outputs."""
+    from visionselector_amd import _native
+    lib = _native.lib()
+    q, k, v = make_qkv(600, 8, 2, 11)
+    cu = torch.tensor([0, 250, 600], dtype=torch.int32).cuda()
+    a = ops.varlen_attn(q.cuda(), k.cuda(), v.cuda(), cu, 350)
+    lib.vsel_debug_attn_use_tr(ctypes.c_int(0))
+    try:
+        b = ops.varlen_attn(q.cuda(), k.cuda(), v.cuda(), cu, 350)
+    finally:
+        lib.vsel_debug_attn_use_tr(ctypes.c_int(1))
+    assert torch.equal(a, b)
+
+
+def test_attention_full_size_properties(ops):
+    """Qwen2.5-VL-7B geometry at the uncompressed length (N + 64 = 2368): rows are convex combinations of V rows
+    (|O| <= max|V|), first token attends only to itself, batch-of-sequences == separate calls."""
+    hq, hkv = 28, 4
+    lens = [2368, 524]
+    q, k, v = make_qkv(sum(lens), hq, hkv, 3)
+    cu = torch.tensor([0, lens[0], sum(lens)], dtype=torch.int32).cuda()
+    qg, kg, vg = q.cuda(), k.cuda(), v.cuda()
+    out = ops.varlen_attn(qg, kg, vg, cu, max(lens))
+    assert bool(torch.isfinite(out.float()).all())
+    assert float(out.float().abs().max()) <= float(v.float().abs().max()) * 1.01
+    for s0 in (0, lens[0]):
+        exp = vg[s0].float().repeat_interleave(hq // hkv, dim=0)
+        assert float((out[s0].float() - exp).abs().max()) <= 2e-2        # softmax over one key = that V row (bf16)
+    o2 = ops.varlen_attn(qg[lens[0]:].contiguous(), kg[lens[0]:].contiguous(), vg[lens[0]:].contiguous(),
+                         torch.tensor([0, lens[1]], dtype=torch.int32).cuda(), lens[1])
+    assert torch.equal(out[lens[0]:], o2)
+    # spot-check a slice against the oracle (one kv group, last 64 queries of the long sequence)
+    sl = slice(lens[0] - 64, lens[0])
+    ref = oattn.varlen_attention(q[:lens[0], :7].float().numpy(), k[:lens[0], :1].float().numpy(),
+                                 v[:lens[0], :1].float().numpy(), np.array([0, lens[0]]))[sl]
+    err = np.abs(out[sl, :7].float().cpu().numpy() - ref)
+    check(err.max(), err.mean(), np.abs(ref).max())

@@ -1,8 +1,242 @@
-// Var-len causal GQA attention forward (placeholder until the MFMA kernel lands in this round).
+// Var-len causal GQA attention forward for the compressed-sequence prefill (gfx950, bf16, head_dim 128).
+//
+// Replaces flash_attn_varlen_func / the FA2 prefill the reference reaches through
+//   qwen-vl-finetune/qwenvl/train/trainer.py:101-113          (cu_seqlens passed as `attention_mask`)
+//   qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py:900       (Qwen2_5_VLFlashAttention2.forward)
+//   llava-ov-15/llavaonevision1_5/modeling_llavaonevision1_5.py:686
+// Math = the in-tree eager path (modeling_qwen2_5_vl.py:777-797): softmax(q k^T / sqrt(d) + causal) v, fp32 softmax,
+// GQA by head // (Hq / Hkv) (repeat_kv, :693-702).  q/k arrive already rotated (M-RoPE / 1-D RoPE upstream).
+//
+// Structure: one workgroup = 4 waves = 128 queries of one (sequence, q-head); a wave owns 32 queries.
+//   S^T = K Q^T   (v_mfma_f32_32x32x16_bf16, A = K tile from LDS, B = Q^T held in registers) so that one lane holds
+//                 one query's scores -> row max / sum need a single cross-half exchange (lane ^ 32)
+//   O^T += V^T P^T (A = V^T fragment via ds_read_b64_tr_b16 from the row-major V tile, B = P^T packed to bf16 in
+//                 registers; the K rows are permuted (bits 2<->3) so each lane's P registers are 8 consecutive keys)
+//   K/V tiles of 64 keys are double-buffered in LDS, global loads for tile t+1 are issued before the math of tile t
+//   (register staged), K is XOR-swizzled (conflict-free ds_read_b128), V rows are padded to 320 B (conflict-free
+//   transpose reads).  Online softmax in exp2 domain, fp32.
 #include "common.h"
+
+namespace vsel {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kHeadDim = 128;
+constexpr int kBlockQ = 128;
+constexpr int kTileK = 64;
+constexpr int kKRowBytes = 256;
+constexpr int kVRowBytes = 320;
+constexpr int kKBuf = kTileK * kKRowBytes;   // 16 KiB
+constexpr int kVBuf = kTileK * kVRowBytes;   // 20 KiB
+constexpr int kLds = 2 * kKBuf + 2 * kVBuf;  // 72 KiB
+
+__device__ __forceinline__ bf16x8_t to_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8_t, v); }
+
+template <bool USE_TR>
+__global__ __launch_bounds__(256) void varlen_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                              const uint16_t* __restrict__ v,
+                                                              const int32_t* __restrict__ cu, int hq, int hkv,
+                                                              float scale_log2e, int causal, uint16_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) char smem[kLds];
+  char* const k_sm = smem;
+  char* const v_sm = smem + 2 * kKBuf;
+
+  const int seq = blockIdx.z, head = blockIdx.y;
+  const int qtile = gridDim.x - 1 - blockIdx.x;   // heaviest (last) query tiles are dispatched first
+  const int qs = cu[seq];
+  const int len = cu[seq + 1] - qs;
+  const int q0 = qtile * kBlockQ;
+  if (q0 >= len) return;
+  const int kvh = head / (hq / hkv);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  const int my_q = min(q0 + wave * 32 + j, len - 1);          // clamped: padding lanes replay the last query
+  const bool q_valid = (q0 + wave * 32 + j) < len;
+  const int wave_qmax = min(q0 + wave * 32 + 31, len - 1);
+
+  // Q^T fragments (B operand of S^T = K Q^T): lane (j, hh) holds q[my_q][16*step + 8*hh .. +7]
+  u32x4 qf[8];
+  {
+    const uint16_t* qp = q + ((int64_t)(qs + my_q) * hq + head) * kHeadDim + 8 * hh;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) qf[st] = *reinterpret_cast<const u32x4*>(qp + 16 * st);
+  }
+  f32x16 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int kv_end = causal ? min(len, q0 + kBlockQ) : len;
+  const int n_tiles = (kv_end + kTileK - 1) / kTileK;
+
+  // staging: 1024 16-byte chunks per tile per tensor, 4 per thread
+  u32x4 kreg[4], vreg[4];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = tid + 256 * u;
+      const int key = c >> 4, part = c & 15;
+      const int64_t row = qs + min(t * kTileK + key, len - 1);
+      const int64_t off = (row * hkv + kvh) * kHeadDim + part * 8;
+      kreg[u] = *reinterpret_cast<const u32x4*>(k + off);
+      vreg[u] = *reinterpret_cast<const u32x4*>(v + off);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = tid + 256 * u;
+      const int key = c >> 4, part = c & 15;
+      *reinterpret_cast<u32x4*>(k_sm + buf * kKBuf + key * kKRowBytes + ((part ^ (key & 15)) << 4)) = kreg[u];
+      *reinterpret_cast<u32x4*>(v_sm + buf * kVBuf + key * kVRowBytes + part * 16) = vreg[u];
+    }
+  };
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  // A-row i of the K operand holds key pi(i) (bits 2 and 3 swapped) so that C registers 8m..8m+7 of lane half hh are
+  // the 8 consecutive keys 16m + 8hh .. +7 of the 32-key block.
+  const int key_row = (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1);
+
+  for (int t = 0; t < n_tiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < n_tiles) load_tile(t + 1);
+    const bool wave_active = !causal || (t * kTileK <= wave_qmax);
+    if (wave_active) {
+      // ---- S^T = K Q^T ----------------------------------------------------------------------------------------
+      f32x16 s[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+        const int kl = 32 * kb + key_row;
+        const char* krow = k_sm + cur * kKBuf + kl * kKRowBytes;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          const int part = 2 * st + hh;
+          const u32x4 a = *reinterpret_cast<const u32x4*>(krow + ((part ^ (kl & 15)) << 4));
+          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(a), to_bf16x8(qf[st]), s[kb], 0, 0, 0);
+        }
+      }
+      // ---- mask + online softmax (exp2 domain) ----------------------------------------------------------------
+      const bool need_mask = (t * kTileK + kTileK > len) || (causal && (t * kTileK + kTileK - 1 > q0 + wave * 32));
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float val = s[kb][r] * scale_log2e;
+          if (need_mask) {
+            const int key = t * kTileK + 32 * kb + 16 * (r >> 3) + 8 * hh + (r & 7);
+            const bool ok = key < len && (!causal || key <= my_q);
+            val = ok ? val : -INFINITY;
+          }
+          s[kb][r] = val;
+          mx = fmaxf(mx, val);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.f;
+      bf16x8_t pf[2][2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+          psum += p;
+          pf[kb][r >> 3][r & 7] = (__bf16)p;
+        }
+      l_run = l_run * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      // ---- O^T += V^T P^T -------------------------------------------------------------------------------------
+      const char* vbase = v_sm + cur * kVBuf;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+          const int kbase = 32 * kb + 16 * mm + 8 * hh;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            bf16x8_t vf;
+            if constexpr (USE_TR) {
+              // 16-lane group: lane p supplies the address of row (p >> 2), 4-column chunk (p & 3) of a [4 keys x 16 d]
+              // block and receives column p (4 keys) -- hardware transpose read
+              const int p16 = lane & 15;
+              const int d0 = 32 * dt + 16 * ((lane >> 4) & 1);
+              const char* a0 = vbase + (kbase + (p16 >> 2)) * kVRowBytes + (d0 + 4 * (p16 & 3)) * 2;
+              typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
+              const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0));
+              const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0 + 4 * kVRowBytes));
+              vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            } else {
+              const int dcol = 32 * dt + j;
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                vf[e] = *reinterpret_cast<const __bf16*>(vbase + (kbase + e) * kVRowBytes + dcol * 2);
+            }
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][mm], o[dt], 0, 0, 0);
+          }
+        }
+    }
+    if (t + 1 < n_tiles) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: O^T[d][query] / l, 4 consecutive d per store ------------------------------------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (q_valid) {
+    uint16_t* op = out + ((int64_t)(qs + my_q) * hq + head) * kHeadDim;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d0 = 32 * dt + 8 * g4 + 4 * hh;
+        const uint32_t w0 = f32_to_bf16_bits(o[dt][4 * g4] * inv) | (f32_to_bf16_bits(o[dt][4 * g4 + 1] * inv) << 16);
+        const uint32_t w1 = f32_to_bf16_bits(o[dt][4 * g4 + 2] * inv) | (f32_to_bf16_bits(o[dt][4 * g4 + 3] * inv) << 16);
+        uint2 pk;
+        pk.x = w0;
+        pk.y = w1;
+        *reinterpret_cast<uint2*>(op + d0) = pk;
+      }
+  }
+}
+
+}  // namespace vsel
+
 using namespace vsel;
+
+static bool g_attn_use_tr = true;
+extern "C" void vsel_debug_attn_use_tr(int on) { g_attn_use_tr = on != 0; }
+
 extern "C" int vsel_varlen_attn_fwd(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens,
                                     int64_t n_seq, int64_t max_seqlen, int64_t total, int64_t hq, int64_t hkv, int64_t d,
                                     float scale, int causal, void* out) {
-  return fail(VSEL_ERR_UNSUPPORTED, "vsel_varlen_attn_fwd: kernel not built yet");
+  if (!q || !k || !v || !cu_seqlens || !out) return fail(VSEL_ERR_INVALID, "NULL pointer");
+  if (d != kHeadDim) return fail(VSEL_ERR_UNSUPPORTED, "head_dim %lld != 128", (long long)d);
+  if (n_seq < 1 || max_seqlen < 1 || total < 1 || hq < 1 || hkv < 1 || hq % hkv != 0 || n_seq > 65535 || hq > 65535)
+    return fail(VSEL_ERR_INVALID, "bad attention shape (n_seq=%lld max_seqlen=%lld total=%lld hq=%lld hkv=%lld)",
+                (long long)n_seq, (long long)max_seqlen, (long long)total, (long long)hq, (long long)hkv);
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return fail(VSEL_ERR_INVALID, "q/k/v/out must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(st);
+  const dim3 grid((unsigned)cdiv(max_seqlen, kBlockQ), (unsigned)hq, (unsigned)n_seq);
+  const float sl2 = scale * 1.4426950408889634f;
+  if (g_attn_use_tr)
+    hipLaunchKernelGGL((varlen_attn_fwd_kernel<true>), grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k,
+                       (const uint16_t*)v, cu_seqlens, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out);
+  else
+    hipLaunchKernelGGL((varlen_attn_fwd_kernel<false>), grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k,
+                       (const uint16_t*)v, cu_seqlens, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out);
+  VSEL_AFTER_LAUNCH(st, "varlen_attn_fwd_kernel");
+  return VSEL_OK;
 }

@@ -1,0 +1,203 @@
+"""End-to-end drop-in checks on a tiny random Qwen2.5-VL (installed transformers classes) on the GPU:
+the *_Selector inference classes (splice + prefill) and the bound training forwards (soft mask + constraint loss +
+gradients) against an eager torch restatement of the reference block run through the same stock model."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+IMG, VID, VSTART, VEND = 10, 11, 12, 13
+
+
+def tiny_config():
+    from transformers import Qwen2_5_VLConfig
+    return Qwen2_5_VLConfig(
+        text_config=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                         num_key_value_heads=2, vocab_size=64, max_position_embeddings=4096,
+                         rope_parameters=dict(rope_type="default", mrope_section=[4, 6, 6], rope_theta=10000.0)),
+        vision_config=dict(depth=2, hidden_size=64, num_heads=4, intermediate_size=128, out_hidden_size=128, patch_size=14,
+                           spatial_merge_size=2, temporal_patch_size=2, window_size=112, fullatt_block_indexes=[1],
+                           in_channels=3),
+        image_token_id=IMG, video_token_id=VID, vision_start_token_id=VSTART, vision_end_token_id=VEND)
+
+
+def make_inputs(grid=(1, 16, 16), n_pre=5, n_post=9, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    n_patches = grid[0] * grid[1] * grid[2]
+    n_vis = n_patches // 4
+    pix = torch.randn(n_patches, 3 * 2 * 14 * 14, generator=g)
+    pre = torch.randint(20, 60, (n_pre,), generator=g)
+    post = torch.randint(20, 60, (n_post,), generator=g)
+    ids = torch.cat((pre, torch.tensor([VSTART]), torch.full((n_vis,), IMG), torch.tensor([VEND]), post))[None]
+    mm = (ids == IMG).int()
+    return dict(input_ids=ids.cuda(), attention_mask=torch.ones_like(ids).cuda(), pixel_values=pix.cuda(),
+                image_grid_thw=torch.tensor([list(grid)]).cuda(), mm_token_type_ids=mm.cuda()), n_vis
+
+
+def randomize_scorer(scorer, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in scorer.parameters():
+            p.copy_((0.05 * torch.randn(p.shape, generator=g)).to(p.device))
+
+
+def eager_scores(h, scorer):
+    """reference formulation in torch (selector_scorer.py:47-53), the checker for this file"""
+    k = F.linear(h, scorer.k_proj.weight, scorer.k_proj.bias)
+    q = F.linear(h, scorer.q_proj.weight, scorer.q_proj.bias)
+    return (q @ k.T / scorer.hidden_dim ** 0.5).mean(-1)
+
+
+@pytest.fixture(scope="module")
+def selector_model():
+    assert torch.cuda.is_available()
+    from visionselector_amd.hf_qwen25vl import Qwen2_5_VLForConditionalGeneration_Selector
+    torch.manual_seed(0)
+    m = Qwen2_5_VLForConditionalGeneration_Selector(tiny_config()).cuda().float().eval()
+    randomize_scorer(m.visual.importance_scorer)
+    return m
+
+
+def test_selector_state_dict_keys(selector_model):
+    keys = [k for k in selector_model.state_dict() if "importance_scorer" in k]
+    assert sorted(k.split("importance_scorer.")[1] for k in keys) == ["k_proj.bias", "k_proj.weight", "q_proj.bias", "q_proj.weight"]
+    assert all(k.startswith("model.visual.importance_scorer.") for k in keys)
+
+
+@pytest.mark.parametrize("budget", [0.25, 0.5])
+def test_selector_prefill_matches_manual_splice(selector_model, budget):
+    from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as hf
+    m = selector_model
+    m.visual.budgets = budget
+    m.model.rope_deltas = None
+    inp, n_vis = make_inputs()
+    with torch.no_grad():
+        out = m(**inp)
+        k = max(1, int(n_vis * budget))
+        idx = m.visual.last_selected_indices
+        assert idx.shape == (k,) and bool((idx[1:] > idx[:-1]).all())
+        assert abs(float(m.visual.last_combined_scores.sum()) - k) < 1e-2
+        L = inp["input_ids"].shape[1]
+        assert out.logits.shape[1] == L - n_vis + k
+        # manual path through the STOCK classes: merged tokens -> eager scores -> topk/sort -> spliced embeds/positions
+        merged = hf.Qwen2_5_VisionTransformerPretrainedModel.forward(m.visual, inp["pixel_values"], inp["image_grid_thw"]).pooler_output
+        s = eager_scores(merged, m.visual.importance_scorer)
+        ref_idx = s.topk(k).indices.sort().values
+        assert torch.equal(ref_idx, idx), "kept indices = eager reference formulation"
+        ids = inp["input_ids"]
+        img_pos = torch.where(ids == IMG)[1]
+        sel = torch.cat((img_pos[ref_idx], torch.where(ids != IMG)[1])).sort().values
+        emb = m.get_input_embeddings()(ids)
+        emb[0, img_pos] = merged
+        emb = emb[:, sel]
+        m.model.rope_deltas = None
+        pos, _ = m.model.get_rope_index(ids, image_grid_thw=inp["image_grid_thw"], attention_mask=inp["attention_mask"],
+                                        mm_token_type_ids=inp["mm_token_type_ids"])
+        ref = hf.Qwen2_5_VLForConditionalGeneration.forward(
+            m, inputs_embeds=emb, position_ids=pos[:, :, sel], attention_mask=inp["attention_mask"][:, sel])
+        assert float((out.logits - ref.logits).abs().max()) <= 1e-4 * max(1.0, float(ref.logits.abs().max()))
+
+
+def test_selector_generate_runs_on_compressed_cache(selector_model):
+    m = selector_model
+    m.visual.budgets = 0.25
+    m.model.rope_deltas = None
+    inp, n_vis = make_inputs(seed=3)
+    with torch.no_grad():
+        first = m(**inp).logits[0, -1].argmax()
+        m.model.rope_deltas = None
+        gen = m.generate(**inp, max_new_tokens=4, do_sample=False)
+    L = inp["input_ids"].shape[1]
+    assert gen.shape[1] == L + 4
+    assert int(gen[0, L]) == int(first)
+
+
+def test_training_forward_backward_matches_eager_block():
+    """install_selector on a stock model: loss = CE + w * BCE and the scorer gradients equal autograd through an eager
+    torch restatement of the block (reference formulation + 64-step bisection + TopK.backward closed form)."""
+    from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as hf
+    from visionselector_amd.hf_qwen25vl import install_selector
+    torch.manual_seed(0)
+    model = hf.Qwen2_5_VLForConditionalGeneration(tiny_config()).cuda().float().train()
+    install_selector(model, budget=0.25, regularization_weight=0.7)
+    visual = model.model.visual
+    randomize_scorer(visual.importance_scorer, seed=2)
+    for n, p in model.named_parameters():
+        p.requires_grad = "importance_scorer" in n                 # set_model(): only the compressor is tuned
+    inp, n_vis = make_inputs(seed=5)
+    labels = inp["input_ids"].clone()
+    labels[inp["input_ids"] == IMG] = -100
+    out = model(**inp, labels=labels)
+    out.loss.backward()
+    got = {n: p.grad.clone() for n, p in visual.importance_scorer.named_parameters()}
+
+    # ---- eager checker ---------------------------------------------------------------------------------------
+    class TopKRef(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, xs, k):
+            lo = -xs.max(dim=1, keepdims=True).values - 10
+            hi = -xs.min(dim=1, keepdims=True).values + 10
+            for _ in range(64):
+                mid = (hi + lo) / 2
+                mask = torch.sigmoid(xs + mid).sum(dim=1) < k
+                lo[mask] = mid[mask]
+                hi[~mask] = mid[~mask]
+            ts = (lo + hi) / 2
+            ctx.save_for_backward(xs, ts)
+            return torch.sigmoid(xs + ts)
+
+        @staticmethod
+        def backward(ctx, g):
+            xs, ts = ctx.saved_tensors
+            p = torch.sigmoid(xs + ts)
+            v = p * (1 - p)
+            uv = g * v
+            return uv - uv.sum(dim=1, keepdims=True) * v / v.sum(dim=1, keepdims=True), None
+
+    for p in visual.importance_scorer.parameters():
+        p.grad = None
+    merged = hf.Qwen2_5_VisionTransformerPretrainedModel.forward(visual, inp["pixel_values"], inp["image_grid_thw"]).pooler_output.detach()
+    s = eager_scores(merged, visual.importance_scorer)
+    k = int(n_vis * 0.25)
+    ps = TopKRef.apply(s[None], k)[0]
+    y = torch.zeros_like(s).scatter_(0, s.topk(k).indices, 1.0)
+    emb = model.get_input_embeddings()(inp["input_ids"]).detach()
+    emb = emb.masked_scatter((inp["input_ids"] == IMG)[..., None].expand_as(emb), ps[:, None] * merged)
+    ref = hf.Qwen2_5_VLForConditionalGeneration.forward(model, input_ids=inp["input_ids"], inputs_embeds=emb,
+                                                        attention_mask=inp["attention_mask"], labels=labels,
+                                                        image_grid_thw=inp["image_grid_thw"],
+                                                        mm_token_type_ids=inp["mm_token_type_ids"])
+    ref_loss = ref.loss + 0.7 * F.binary_cross_entropy(ps, y)
+    ref_loss.backward()
+    assert abs(float(out.loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss)))
+    for n, p in visual.importance_scorer.named_parameters():
+        scale = max(float(p.grad.abs().max()), 1e-8)
+        # TOLERANCE 2e-3 of the tensor's max: fp32 eager autograd through the N x N matmul vs the closed form
+        assert float((got[n] - p.grad).abs().max()) <= 2e-3 * scale + 1e-7, n
+    with pytest.raises(ValueError, match="do not match"):        # reference: ValueError on token-count mismatch
+        bad = dict(inp)
+        bad["input_ids"] = inp["input_ids"].clone()
+        bad["input_ids"][0, 0] = IMG
+        model(**bad)
+
+
+def test_attention_interface_registration():
+    from transformers import AttentionInterface
+    from visionselector_amd.attention import ATTN_NAME, replace_qwen2_vl_attention_class, vsel_attention_forward
+    assert replace_qwen2_vl_attention_class() == ATTN_NAME
+    assert AttentionInterface()[ATTN_NAME] is vsel_attention_forward
+    # prefill call in the interface layout: [B, H, L, d]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    q = torch.randn(2, 8, 200, 128, device="cuda", generator=g).bfloat16()
+    k = torch.randn(2, 2, 200, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(2, 2, 200, 128, device="cuda", generator=g).bfloat16()
+    with torch.no_grad():
+        out, _ = vsel_attention_forward(None, q, k, v, None, scaling=128 ** -0.5, is_causal=True)
+        ref = F.scaled_dot_product_attention(q.float(), k.float().repeat_interleave(4, 1), v.float().repeat_interleave(4, 1),
+                                             is_causal=True).transpose(1, 2)
+    assert out.shape == (2, 200, 8, 128)
+    assert float((out.float() - ref).abs().max()) <= 2e-2 and float((out.float() - ref).abs().mean()) <= 1e-3
+    with pytest.raises(RuntimeError, match="forward pass only"):
+        vsel_attention_forward(None, q.requires_grad_(True), k, v, None)

@@ -1,0 +1,153 @@
+"""Host-side logic on CPU: module API / state-dict compatibility, curriculum, splice index algebra vs the goldens,
+monkeypatch call shapes, and the data-parallel gradient exchange over a world_size-2 gloo group."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import inputs as oin
+from oracle import lis as olis
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+IMAGE_TOKEN, VIDEO_TOKEN = 151655, 151656
+
+
+def test_scorer_module_matches_reference_layout():
+    from visionselector_amd.selector import TransformerScorer
+    torch.manual_seed(0)
+    m = TransformerScorer(in_features=3584)                      # reference default hidden_dim=1792
+    assert (m.in_features, m.hidden_dim) == (3584, 1792)
+    sd = m.state_dict()
+    assert sorted(sd) == ["k_proj.bias", "k_proj.weight", "q_proj.bias", "q_proj.weight"]
+    assert sd["q_proj.weight"].shape == (1792, 3584) and sd["k_proj.bias"].shape == (1792,)
+    assert sum(p.numel() for p in m.parameters()) == 12_848_640   # README.md:47 "12.85M"
+    assert float(sd["q_proj.bias"].abs().max()) == 0.0 and float(sd["k_proj.bias"].abs().max()) == 0.0
+    assert 0.5e-4 < float(sd["q_proj.weight"].std()) < 1.5e-4     # init_scale 1e-4
+    m2 = TransformerScorer(2048, 1024)
+    m2.load_state_dict({k: torch.zeros_like(v) for k, v in m2.state_dict().items()})
+    with pytest.raises(RuntimeError, match="GPU only"):           # no CPU fallback
+        m2(torch.zeros(1, 4, 2048))
+
+
+def test_dropin_import_paths():
+    sys.path.insert(0, os.path.join(ROOT, "visionselector_amd", "dropin"))
+    try:
+        from compression_method.selector_model import (TopK, _find_ts, qwen25vl_generation_forward_selector,  # noqa: F401
+                                                       qwen25vl_vision_tower_forward_selector, topk)
+        from compression_method.selector_scorer import TransformerScorer  # noqa: F401
+        from token_compression.monkeypatch import replace_qwen25vl
+        from token_compression.selector_model import (Qwen2_5_VisionTransformerPretrainedModel_Selector,  # noqa: F401
+                                                      Qwen2_5_VLForConditionalGeneration_Selector)
+        from compression_method.monkeypatch import replace_llavaov15
+    finally:
+        sys.path.pop(0)
+    sentinel = object()
+    assert replace_qwen25vl(None, sentinel, "selector") is sentinel       # reference: no branch for selector
+    assert replace_llavaov15(None, sentinel, "selector") is sentinel
+    with pytest.raises(NotImplementedError):
+        replace_qwen25vl(None, sentinel, "fastv")
+    with pytest.raises(ValueError):
+        replace_qwen25vl(None, sentinel, "nonsense")
+
+
+def test_curriculum_weight_matches_oracle():
+    from visionselector_amd.selector import curriculum_weight
+    for step, total in [(0, 100), (1, 3), (50, 100), (100, 100), (170, 100), (5, 0), (5, -1)]:
+        assert curriculum_weight(step, total, 0.1, 2.0) == olis.curriculum_weight(step, total, 0.1, 2.0)
+    assert curriculum_weight(10, 10) == pytest.approx(3.0)        # class defaults 0.1 -> 3.0 (train_qwen_selector.py:61)
+
+
+def _embed(ids, d_llm):
+    ar = torch.arange(d_llm, dtype=torch.int64)
+    return ((ids[..., None] * 31 + ar * 17) % 257).float() / 257.0
+
+
+@pytest.mark.parametrize("name", ["image_a", "image_b", "video_a"])
+def test_splice_torch_matches_reference_golden(golden_dir, name):
+    from visionselector_amd.selector import slice_positions, splice_image, splice_video
+    g = np.load(os.path.join(golden_dir, f"splice_{name}.npz"))
+    kind = str(g["kind"])
+    vis = IMAGE_TOKEN if kind == "image" else VIDEO_TOKEN
+    ids = torch.from_numpy(oin.make_prompt(int(g["n_visual"]), int(g["n_pre"]), int(g["n_post"]), vis, int(g["seed"])))
+    emb = _embed(ids, int(g["d_llm"]))
+    idx = torch.from_numpy(g["all_idx"])
+    ve = torch.from_numpy(g["vis_embeds"])
+    if kind == "image":
+        sel, new_ids, new_emb = splice_image(ids, emb, vis, idx, ve)
+    else:
+        sel, new_ids, new_emb, timask = splice_video(ids, emb, vis, idx, ve)
+        assert int(timask.sum()) == new_ids.shape[1] - int(g["k"])
+    assert np.array_equal(new_emb.numpy(), g["inputs_embeds"])
+    pos, am = slice_positions(torch.from_numpy(g["position_ids_full"]), torch.ones_like(ids), sel)
+    assert np.array_equal(pos.numpy(), g["position_ids"])
+    assert np.array_equal(am.numpy(), g["attention_mask"])
+
+
+def test_shard_units_round_robin():
+    from visionselector_amd.ddp import shard_units
+    got = sorted(i for r in range(8) for i in shard_units(37, r, 8))
+    assert got == list(range(37))
+    assert list(shard_units(10, 3, 4)) == [3, 7]
+
+
+# ---------------------------------------------------------------------------------------------------
+# multi-rank gradient exchange (gloo, world_size 2)
+# ---------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from visionselector_amd.ddp import LisGradSync
+        from visionselector_amd.selector import TransformerScorer
+        torch.manual_seed(100 + rank)                      # different init per rank on purpose
+        m = TransformerScorer(64, 32, init_scale=0.02)
+        sync = LisGradSync(m.parameters())
+        assert sync.numel == 2 * (64 * 32 + 32)
+        sync.broadcast_parameters(0)
+        g = torch.Generator().manual_seed(7 + rank)
+        for p in m.parameters():
+            p.grad = torch.randn(p.shape, generator=g)
+        if rank == 1:
+            m.q_proj.bias.grad = None                      # a rank without a grad contributes zeros
+        sync.sync()
+        torch.save({"params": [p.detach().clone() for p in m.parameters()],
+                    "grads": [p.grad.clone() for p in m.parameters()]}, os.path.join(out_dir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_lis_grad_sync_gloo_world2(tmp_path):
+    world = 2
+    mp.spawn(_ddp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)                           # broadcast from rank 0
+    for a, b in zip(r0["grads"], r1["grads"]):
+        assert torch.equal(a, b)                           # identical after the all-reduce
+    # expected mean of the per-rank grads (single-process accumulation)
+    from visionselector_amd.selector import TransformerScorer
+    shapes = [p.shape for p in TransformerScorer(64, 32).parameters()]
+    names = [n for n, _ in TransformerScorer(64, 32).named_parameters()]
+    per_rank = []
+    for rank in range(world):
+        g = torch.Generator().manual_seed(7 + rank)
+        per_rank.append([torch.randn(s, generator=g) for s in shapes])
+    per_rank[1][names.index("q_proj.bias")] = torch.zeros(32)
+    for i, got in enumerate(r0["grads"]):
+        exp = (per_rank[0][i] + per_rank[1][i]) / world
+        assert torch.allclose(got, exp, atol=1e-7)

@@ -1,0 +1,100 @@
+"""Var-len attention entry points with the reference's call shapes, backed by vsel_varlen_attn_fwd.
+
+  _flash_attention_forward(...)          qwen-vl-finetune/qwenvl/train/trainer.py:29-120  (attention_mask IS cu_seqlens)
+  _update_causal_mask(...)               qwen-vl-finetune/qwenvl/train/trainer.py:123-131
+  replace_qwen2_vl_attention_class()     qwen-vl-finetune/qwenvl/train/trainer.py:134-149
+  vsel_attention_forward(...)            transformers-5.x AttentionInterface signature (prefill of the *_Selector models;
+                                         replaces Qwen2_5_VLFlashAttention2.forward -> flash_attn of
+                                         qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py:827-918)
+Forward only (inference prefill + frozen-LLM activations are out of this round's backward scope): tensors that require
+grad are rejected loudly rather than silently detached.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+ATTN_NAME = "vsel_varlen"
+
+
+def _check_no_grad(*ts):
+    if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
+        raise RuntimeError("vsel var-len attention implements the forward pass only; run under torch.no_grad() "
+                           "or keep the LLM's attention on its stock implementation for training")
+
+
+def _flash_attention_forward(query_states, key_states, value_states, attention_mask, query_length, is_causal,
+                             dropout: float = 0.0, position_ids=None, softmax_scale: Optional[float] = None,
+                             sliding_window=None, use_top_left_mask: bool = False, softcap=None, deterministic=None,
+                             cu_seq_lens_q=None, cu_seq_lens_k=None, max_length_q=None, max_length_k=None,
+                             target_dtype=None, **kwargs):
+    """Packed batch: query/key/value [1, T, H, d]; `attention_mask` carries cu_seqlens (data_qwen.py:586-595)."""
+    assert query_states.size(0) == key_states.size(0) == value_states.size(0) == 1          # trainer.py:75
+    if dropout:
+        raise NotImplementedError("attention dropout is not supported")
+    if softcap is not None or sliding_window is not None:
+        raise NotImplementedError("softcap / sliding_window are not supported")
+    _check_no_grad(query_states, key_states, value_states)
+    q, k, v = (t.squeeze(0).contiguous() for t in (query_states, key_states, value_states))
+    cu_seqlens = attention_mask.to(torch.int32).contiguous()                                # :79
+    with torch.no_grad():
+        max_seqlen = int((cu_seqlens[1:] - cu_seqlens[:-1]).max().item())                  # :81-87 (host sync, as the reference)
+    causal = is_causal if not use_top_left_mask else (is_causal and query_length != 1)      # :89-93
+    out = ops.varlen_attn(q, k, v, cu_seqlens, max_seqlen, causal=bool(causal), softmax_scale=softmax_scale)
+    return out.unsqueeze(0)
+
+
+def _update_causal_mask(self, attention_mask, input_tensor, cache_position, past_key_values, output_attentions):
+    return attention_mask                                                                   # trainer.py:123-131
+
+
+def vsel_attention_forward(module, query, key, value, attention_mask, dropout: float = 0.0, scaling: Optional[float] = None,
+                           is_causal: Optional[bool] = None, **kwargs):
+    """transformers AttentionInterface function.  query [B, Hq, Lq, d], key/value [B, Hkv, Lk, d].
+
+    Prefill (Lq == Lk): every batch row is one causal sequence -> one var-len call with cu_seqlens = [0, L, 2L, ...]
+    (or the packed cu_seq_lens_q kwarg when the batch is flattened).  Returns (attn_output [B, Lq, Hq, d], None)."""
+    if dropout:
+        raise NotImplementedError("attention dropout is not supported")
+    _check_no_grad(query, key, value)
+    b, hq, lq, d = query.shape
+    lk = key.shape[2]
+    if lq != lk:
+        raise NotImplementedError("vsel var-len attention covers the prefill (Lq == Lk); use the stock kernel for decode")
+    q = query.transpose(1, 2).reshape(b * lq, hq, d).contiguous()
+    k = key.transpose(1, 2).reshape(b * lk, key.shape[1], d).contiguous()
+    v = value.transpose(1, 2).reshape(b * lk, value.shape[1], d).contiguous()
+    cu = kwargs.get("cu_seq_lens_q")
+    if cu is not None:
+        cu = cu.to(torch.int32).contiguous()
+        max_len = int(kwargs.get("max_length_q") or (cu[1:] - cu[:-1]).max().item())
+    else:
+        cu = torch.arange(0, (b + 1) * lq, lq, dtype=torch.int32, device=query.device)
+        max_len = lq
+    causal = True if is_causal is None else bool(is_causal)
+    out = ops.varlen_attn(q, k, v, cu, max_len, causal=causal, softmax_scale=scaling)
+    return out.view(b, lq, hq, d), None
+
+
+def replace_qwen2_vl_attention_class():
+    """Install the var-len kernel where the reference installs its flash-attn wrapper (trainer.py:134-149).
+
+    transformers >= 4.48 dispatches attention through AttentionInterface: the function is registered under
+    `vsel_varlen`; select it with `config._attn_implementation = "vsel_varlen"` (or `attn_implementation=` at load).
+    Older module-level hooks are patched too when they exist."""
+    import transformers
+    from transformers import AttentionInterface
+    AttentionInterface.register(ATTN_NAME, vsel_attention_forward)
+    for mod_name, cls_name in (("qwen2_vl", "Qwen2VLModel"), ("qwen2_5_vl", "Qwen2_5_VLModel")):
+        mod = getattr(getattr(transformers.models, mod_name, None), f"modeling_{mod_name}", None)
+        if mod is None:
+            continue
+        if hasattr(mod, "_flash_attention_forward"):
+            mod._flash_attention_forward = _flash_attention_forward
+        cls = getattr(mod, cls_name, None)
+        if cls is not None and hasattr(cls, "_update_causal_mask"):
+            cls._update_causal_mask = _update_causal_mask
+    return ATTN_NAME

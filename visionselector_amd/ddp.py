@@ -1,0 +1,73 @@
+"""Data-parallel exchange of the LIS gradients (the only trainable parameters; backbone frozen).
+
+Reference: DeepSpeed ZeRO-2/3 reduce-scatter / all-reduce over NCCL driven by HF Trainer
+(qwen-vl-finetune/scripts/sft_7b.sh:9-12,71-74 + zero3.json; set_model freezes all but the scorer,
+qwen-vl-finetune/qwenvl/train/train_qwen_selector.py:127-157).  Here: one process per GPU, torch.distributed
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests), ONE flat fp32 bucket holding
+{q_proj.weight, q_proj.bias, k_proj.weight, k_proj.bias}.grad -- 12 848 640 elements = 51.4 MB at 7B -- so the exchange
+is a single large all-reduce per optimizer step (xGMI is point-to-point: few, large collectives).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class LisGradSync:
+    """Average the scorer's gradients over the data-parallel group with one bucketed all-reduce."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters to synchronise")
+        self.group = group
+        self.numel = sum(p.numel() for p in self.params)
+        self._bucket: Optional[torch.Tensor] = None
+
+    def _flat(self, device) -> torch.Tensor:
+        if self._bucket is None or self._bucket.device != device:
+            self._bucket = torch.empty(self.numel, dtype=torch.float32, device=device)
+        return self._bucket
+
+    @torch.no_grad()
+    def sync(self) -> None:
+        """grad <- mean over ranks (what DDP / ZeRO do before the optimizer step).  Missing grads count as zeros."""
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            return
+        bucket = self._flat(self.params[0].device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                bucket[off:off + n].zero_()
+            else:
+                bucket[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+        bucket.div_(world)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            g = bucket[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+
+    @torch.no_grad()
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """Make every rank start from rank `src`'s scorer (DDP's initial broadcast)."""
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return
+        for p in self.params:
+            dist.broadcast(p.data, src=src, group=self.group)
+
+
+def shard_units(n_units: int, rank: int, world: int) -> range:
+    """Round-robin sharding of independent units (images / samples) over ranks -- the eval harness's accelerate DDP
+    split (qwen-evaluation/run_selector.sh:11-18), no data-path collective."""
+    return range(rank, n_units, world)

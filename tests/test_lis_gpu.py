@@ -220,3 +220,33 @@ def test_full_size_properties(ops, budget):
         # boundary-tie tolerant: symmetric difference only among scores within fp32 noise of the threshold
         diff = np.setxor1d(ridx, idx[bi].cpu().numpy())
         assert all(abs(ref[j] - np.sort(ref)[::-1][k - 1]) <= 1e-5 for j in diff)
+
+
+def test_two_half_pipeline_equals_single_stream(ops):
+    """The aux-stream software pipeline (>= 8 segments) must give bit-identical results to the single-stream order."""
+    import ctypes
+    from visionselector_amd import _native
+    lib = _native.lib()
+    c = oin.make_case(2048, 1024, 300, 5, batch=35)
+    h, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    a = ops.lis_select(h, wq, bq, wk, bk, 77)
+    lens = [300, 17, 1000, 64, 5, 700, 33, 900, 12] * 4
+    ks = [max(1, n // 5) for n in lens]
+    c2 = oin.make_case(2048, 1024, sum(lens), 6)
+    h2 = dev(c2["h"], torch.bfloat16)
+    a2 = ops.lis_select_varlen(h2, lens, ks, wq, bq, wk, bk)
+    lib.vsel_debug_set_pipeline(ctypes.c_int(0))
+    try:
+        b = ops.lis_select(h, wq, bq, wk, bk, 77)
+        b2 = ops.lis_select_varlen(h2, lens, ks, wq, bq, wk, bk)
+    finally:
+        lib.vsel_debug_set_pipeline(ctypes.c_int(1))
+    torch.cuda.synchronize()
+    for x, y in zip(a + a2, b + b2):
+        assert torch.equal(x, y)
+    # back-to-back calls on the same stream reuse the aux stream / events correctly
+    outs = [ops.lis_select(h, wq, bq, wk, bk, 77) for _ in range(20)]
+    torch.cuda.synchronize()
+    for o in outs:
+        for x, y in zip(o, a):
+            assert torch.equal(x, y)

@@ -7,9 +7,112 @@ int check_segments(const vsel_segments* seg, bool need_k) { return check_segment
 
 using namespace vsel;
 
+// ---- two-half software pipeline ----------------------------------------------------------------------------------
+// With >= kPipelineMinSegments segments the batch is split in two halves that run on the caller's stream and on a
+// library-owned auxiliary stream (fork / join with events): the small latency-bound kernels of one half (projections,
+// finish kernels, radix select) execute underneath the HBM-bound sweeps of the other half.  Results are identical to
+// the single-stream order (each half is self-contained, every kernel is deterministic).
+constexpr int64_t kPipelineMinSegments = 32;
+
+struct AuxStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork[8], join[8];
+  unsigned next = 0;
+  bool ok = false;
+};
+
+static AuxStream* aux_for_current_device() {
+  static AuxStream table[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  AuxStream& a = table[dev];
+  if (!a.ok) {
+    if (hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    for (int i = 0; i < 8; ++i) {
+      if (hipEventCreateWithFlags(&a.fork[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&a.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    a.ok = true;
+  }
+  return &a;
+}
+
+static int g_pipeline_enabled = 1;
+extern "C" void vsel_debug_set_pipeline(int on) { g_pipeline_enabled = on; }
+
+template <typename T, typename TW>
+static int select_half(hipStream_t st, const T* h, const vsel_segments* seg, const vsel_scorer* sc, char* ws, const LisPlan& p,
+                       T* out, int64_t* idx, float* scores, bool skip_colsum) {
+  int rc = VSEL_OK;
+  if (!skip_colsum) rc = run_colsum<T>(st, h, seg, (int)sc->d, ws, p);
+  if (rc) return rc;
+  rc = run_proj<TW>(st, seg, sc, ws, p);
+  if (rc) return rc;
+  rc = run_score<T>(st, h, seg, sc, ws, p, scores);
+  if (rc) return rc;
+  rc = launch_select(st, scores, seg, idx, nullptr);
+  if (rc) return rc;
+  return launch_gather<T>(st, h, (int)sc->d, seg, idx, out);
+}
+
+template <typename T, typename TW>
+static int lis_select_impl(hipStream_t st, const T* h, const vsel_segments* seg, const vsel_scorer* sc, char* ws, T* out,
+                           int64_t* idx, float* scores) {
+  const int64_t S = seg->n_seg, d = sc->d;
+  AuxStream* aux = (g_pipeline_enabled && S >= kPipelineMinSegments && !prof_enabled()) ? aux_for_current_device() : nullptr;
+  if (!aux) {
+    const LisPlan p = make_plan(S, seg->rows_per_seg, d, sc->hd);
+    return select_half<T, TW>(st, h, seg, sc, ws, p, out, idx, scores, false);
+  }
+  // halves A = [0, s0), B = [s0, S).  Uniform segments address rows relative to the half's base pointer; ragged
+  // segments keep absolute offsets (seg_rows / seg_out are advanced instead).
+  const int64_t s0 = S / 2;
+  vsel_segments a = *seg, b = *seg;
+  a.n_seg = s0;
+  b.n_seg = S - s0;
+  const T* hb = h;
+  T* outb = out;
+  int64_t* idxb = idx;
+  float* scb = scores;
+  if (seg->seg_rows) {
+    b.seg_rows = seg->seg_rows + s0;
+    b.seg_out = seg->seg_out + s0;
+    a.total_rows = b.total_rows = seg->total_rows;   // informational only in the ragged form
+  } else {
+    a.total_rows = s0 * seg->rows_per_seg;
+    a.total_out = s0 * seg->k;
+    b.total_rows = (S - s0) * seg->rows_per_seg;
+    b.total_out = (S - s0) * seg->k;
+    hb = h + a.total_rows * d;
+    outb = out + a.total_out * d;
+    idxb = idx + a.total_out;
+    scb = scores + a.total_rows;
+  }
+  const LisPlan pa = make_plan(a.n_seg, seg->rows_per_seg, d, sc->hd);
+  const LisPlan pb = make_plan(b.n_seg, seg->rows_per_seg, d, sc->hd);
+  char* wsa = ws;
+  char* wsb = ws + pa.total;
+  const unsigned e = aux->next++ & 7u;
+  int rc = run_colsum<T>(st, h, &a, (int)d, wsa, pa);
+  if (rc) return rc;
+  VSEL_HIP_CHECK(hipEventRecord(aux->fork[e], st));
+  VSEL_HIP_CHECK(hipStreamWaitEvent(aux->stream, aux->fork[e], 0));
+  rc = select_half<T, TW>(aux->stream, h, &a, sc, wsa, pa, out, idx, scores, true);
+  if (rc) return rc;
+  VSEL_HIP_CHECK(hipEventRecord(aux->join[e], aux->stream));
+  rc = select_half<T, TW>(st, hb, &b, sc, wsb, pb, outb, idxb, scb, false);
+  if (rc) return rc;
+  VSEL_HIP_CHECK(hipStreamWaitEvent(st, aux->join[e], 0));
+  return VSEL_OK;
+}
+
 extern "C" size_t vsel_lis_workspace_bytes(const vsel_segments* seg, int64_t d, int64_t hd) {
   if (!seg || seg->n_seg < 1 || d < 1 || hd < 1) return 0;
-  return make_plan(seg->n_seg, seg->rows_per_seg, d, hd).total;
+  const size_t whole = make_plan(seg->n_seg, seg->rows_per_seg, d, hd).total;
+  if (seg->n_seg < kPipelineMinSegments) return whole;
+  const int64_t s0 = seg->n_seg / 2;
+  const size_t halves = make_plan(s0, seg->rows_per_seg, d, hd).total + make_plan(seg->n_seg - s0, seg->rows_per_seg, d, hd).total;
+  return std::max(whole, halves);
 }
 
 static int lis_common_checks(const void* h, const vsel_segments* seg, const vsel_scorer* sc, vsel_dtype hdtype,
@@ -74,18 +177,16 @@ extern "C" int vsel_lis_select(void* stream, const void* h, vsel_dtype hdtype, c
   if (st) return st;
   if (!out || !idx || !scores) return fail(VSEL_ERR_INVALID, "out / idx / scores is NULL");
   if ((uintptr_t)out & 15) return fail(VSEL_ERR_INVALID, "out must be 16-byte aligned");
+  if (ws_bytes < vsel_lis_workspace_bytes(seg, sc->d, sc->hd))
+    return fail(VSEL_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, vsel_lis_workspace_bytes(seg, sc->d, sc->hd));
   hipStream_t s = (hipStream_t)stream;
   VSEL_PROF_BEGIN(s);
   if (hdtype == VSEL_BF16) {
-    st = run_scores_w<bf16_t>(s, (const bf16_t*)h, seg, sc, (char*)ws, p, scores);
-    if (st) return st;
-    st = launch_select(s, scores, seg, idx, nullptr);
-    if (st) return st;
-    return launch_gather<bf16_t>(s, (const bf16_t*)h, (int)sc->d, seg, idx, (bf16_t*)out);
+    if (sc->wdtype == VSEL_BF16)
+      return lis_select_impl<bf16_t, bf16_t>(s, (const bf16_t*)h, seg, sc, (char*)ws, (bf16_t*)out, idx, scores);
+    return lis_select_impl<bf16_t, float>(s, (const bf16_t*)h, seg, sc, (char*)ws, (bf16_t*)out, idx, scores);
   }
-  st = run_scores_w<float>(s, (const float*)h, seg, sc, (char*)ws, p, scores);
-  if (st) return st;
-  st = launch_select(s, scores, seg, idx, nullptr);
-  if (st) return st;
-  return launch_gather<float>(s, (const float*)h, (int)sc->d, seg, idx, (float*)out);
+  if (sc->wdtype == VSEL_BF16)
+    return lis_select_impl<float, bf16_t>(s, (const float*)h, seg, sc, (char*)ws, (float*)out, idx, scores);
+  return lis_select_impl<float, float>(s, (const float*)h, seg, sc, (char*)ws, (float*)out, idx, scores);
 }

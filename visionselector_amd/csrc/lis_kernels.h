@@ -20,6 +20,10 @@
 namespace vsel {
 
 // =================================================================================================
+constexpr int kRowsPerChunk = 128;   // sweep-1 row chunk (batch-invariant summation order)
+constexpr int kSliceNT = 256;        // split-K slice of the kbar projection (fixed => batch-invariant)
+constexpr int kSliceNN = 128;        // split-K slice of the w projection
+
 // K1  partial column sums.  grid (col_tiles, row_splits, n_seg), block 256 (4 waves).
 //     A wave reads 64 lanes x 16 B = 1 KiB contiguous of one row; the block's 4 waves interleave rows.
 // =================================================================================================
@@ -32,9 +36,10 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   const int col = (blockIdx.x * 64 + lane) * V;
   const int n = sv.n_rows(s);
   const int64_t r0 = sv.row_begin(s);
-  const int rows_per = (n + row_splits - 1) / row_splits;
-  const int rb = rs * rows_per;
-  const int re = min(n, rb + rows_per);
+  // fixed 128-row chunks: a segment's partial sums (and therefore its scores, bit for bit) do not depend on what
+  // else is in the batch; chunks past the segment's end contribute exact zeros
+  const int rb = rs * kRowsPerChunk;
+  const int re = min(n, rb + kRowsPerChunk);
   float acc[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) acc[i] = 0.f;
@@ -483,31 +488,18 @@ struct LisPlan {
   size_t off_partial, off_xbar, off_part1, off_kbar, off_c, off_part2, off_w, off_xs, off_ksp, off_cpart, total;
 };
 
-// Split-K factor: enough waves to cover the chip, partial slab <= ~16 MB, slices a multiple of `quantum`.
-inline void pick_split(int64_t tiles, int64_t target_waves, int64_t m, int64_t n, int64_t k, int quantum, int* ks,
-                       int* kslice) {
-  int64_t want = cdiv(target_waves, tiles);
-  const int64_t cap_bytes = std::max<int64_t>(1, (16ll << 20) / std::max<int64_t>(1, m * n * 4));
-  want = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, cap_bytes), std::max<int64_t>(1, k / (2 * quantum))));
-  *kslice = (int)(cdiv(cdiv(k, want), quantum) * quantum);
-  *ks = (int)cdiv(k, *kslice);
-}
-
 inline LisPlan make_plan(int64_t S, int64_t maxn, int64_t d, int64_t hd) {
   LisPlan p{};
   p.S = S; p.maxn = maxn; p.d = d; p.hd = hd;
-  // sweep 1: 512-column tiles x equal row chunks (128 rows when there is enough work, finer for few segments).
-  // (A whole-row-per-wave variant measured 5 % slower on MI355X: 235 vs 223 us at B=64.)
-  {
-    const int64_t col_tiles = cdiv(d, 512);
-    int64_t rpb = 128;
-    while (rpb > 32 && S * col_tiles * cdiv(maxn, rpb) < 2048) rpb >>= 1;
-    p.row_splits = (int)std::max<int64_t>(1, cdiv(maxn, rpb));
-  }
-  const int64_t mt = cdiv(S, 32);
+  // Batch-invariant plan: the summation tree of one segment never depends on how many segments share the call
+  // (fixed 128-row chunks in sweep 1, fixed split-K slices in the projections), so batching, the two-half pipeline
+  // and the ragged form all reproduce a single-image call bit for bit.
+  p.row_splits = (int)std::max<int64_t>(1, cdiv(maxn, kRowsPerChunk));
   p.mfma_bf16 = (d % 16 == 0) && (hd % 16 == 0);
-  pick_split(cdiv(hd, 32) * mt, 1536, S, hd, d, 16, &p.ks1, &p.kslice1);
-  pick_split(cdiv(d, 256) * mt, 768, S, d, hd, 16, &p.ks2, &p.kslice2);
+  p.kslice1 = (int)std::min<int64_t>(kSliceNT, cdiv(d, 16) * 16);
+  p.ks1 = (int)cdiv(d, p.kslice1);
+  p.kslice2 = (int)std::min<int64_t>(kSliceNN, cdiv(hd, 16) * 16);
+  p.ks2 = (int)cdiv(hd, p.kslice2);
   p.n_cpart = (int)cdiv(hd, 256);
   size_t o = 0;
   auto take = [&](size_t nfloat) { size_t r = o; o += align_up(nfloat * sizeof(float), 256); return r; };
@@ -586,10 +578,15 @@ inline int launch_colsum(hipStream_t st, const T* h, const SegView& sv, int d, i
   return VSEL_OK;
 }
 
-template <typename T, typename TW>
-inline int run_scores(hipStream_t st, const T* h, const vsel_segments* seg, const vsel_scorer* sc, char* ws,
-                      const LisPlan& p, float* scores) {
-  constexpr int V = Elem<T>::kVec;
+// stage 1: sweep 1 (column-sum partials)
+template <typename T>
+inline int run_colsum(hipStream_t st, const T* h, const vsel_segments* seg, int d, char* ws, const LisPlan& p) {
+  return launch_colsum<T>(st, h, make_view(seg), d, (int)seg->n_seg, p.row_splits, (float*)(ws + p.off_partial));
+}
+
+// stage 2: partials -> xbar -> kbar -> (w, c)   (small, latency-bound kernels)
+template <typename TW>
+inline int run_proj(hipStream_t st, const vsel_segments* seg, const vsel_scorer* sc, char* ws, const LisPlan& p) {
   const SegView sv = make_view(seg);
   const int d = (int)sc->d, hd = (int)sc->hd, S = (int)seg->n_seg;
   float* partial = (float*)(ws + p.off_partial);
@@ -599,11 +596,6 @@ inline int run_scores(hipStream_t st, const T* h, const vsel_segments* seg, cons
   float* c = (float*)(ws + p.off_c);
   float* part2 = (float*)(ws + p.off_part2);
   float* w = (float*)(ws + p.off_w);
-
-  {
-    int rc = launch_colsum<T>(st, h, sv, d, S, p.row_splits, partial);
-    if (rc) return rc;
-  }
   if constexpr (std::is_same<TW, bf16_t>::value) {
     if (p.mfma_bf16) {
       // bf16x3 MFMA projections (proj_bf16x3.h)
@@ -625,7 +617,7 @@ inline int run_scores(hipStream_t st, const T* h, const vsel_segments* seg, cons
       hipLaunchKernelGGL(w_finish_kernel, dim3((unsigned)cdiv(d, 256), S), dim3(256), 0, st, part2, p.ks2, S, d, cpart,
                          p.n_cpart, w, c);
       VSEL_AFTER_LAUNCH(st, "w_finish_kernel");
-      return launch_score<T>(st, h, sv, seg, d, w, c, hd, scores);
+      return VSEL_OK;
     }
   }
   // generic path: fp32-input MFMA (fp32 weights, or K not a multiple of 16)
@@ -644,7 +636,25 @@ inline int run_scores(hipStream_t st, const T* h, const vsel_segments* seg, cons
   hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)cdiv((int64_t)S * d, 256)), dim3(256), 0, st, part2, p.ks2,
                      (int64_t)S * d, w);
   VSEL_AFTER_LAUNCH(st, "slice_sum_kernel");
-  return launch_score<T>(st, h, sv, seg, d, w, c, hd, scores);
+  return VSEL_OK;
+}
+
+// stage 3: sweep 2 (scores)
+template <typename T>
+inline int run_score(hipStream_t st, const T* h, const vsel_segments* seg, const vsel_scorer* sc, char* ws, const LisPlan& p,
+                     float* scores) {
+  return launch_score<T>(st, h, make_view(seg), seg, (int)sc->d, (const float*)(ws + p.off_w), (const float*)(ws + p.off_c),
+                         (int)sc->hd, scores);
+}
+
+template <typename T, typename TW>
+inline int run_scores(hipStream_t st, const T* h, const vsel_segments* seg, const vsel_scorer* sc, char* ws,
+                      const LisPlan& p, float* scores) {
+  int rc = run_colsum<T>(st, h, seg, (int)sc->d, ws, p);
+  if (rc) return rc;
+  rc = run_proj<TW>(st, seg, sc, ws, p);
+  if (rc) return rc;
+  return run_score<T>(st, h, seg, sc, ws, p, scores);
 }
 
 template <typename T>

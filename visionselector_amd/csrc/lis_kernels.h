@@ -500,18 +500,19 @@ inline LisPlan make_plan(int64_t S, int64_t maxn, int64_t d, int64_t hd) {
   p.ks1 = (int)cdiv(d, p.kslice1);
   p.kslice2 = (int)std::min<int64_t>(kSliceNN, cdiv(hd, 16) * 16);
   p.ks2 = (int)cdiv(hd, p.kslice2);
-  p.n_cpart = (int)cdiv(hd, 256);
+  p.n_cpart = (int)cdiv(hd, 8);
+  const int64_t m_pad = 32 * cdiv(S, 32);
   size_t o = 0;
   auto take = [&](size_t nfloat) { size_t r = o; o += align_up(nfloat * sizeof(float), 256); return r; };
   p.off_partial = take((size_t)S * p.row_splits * d);
   p.off_xbar = take((size_t)S * d);
-  p.off_part1 = take((size_t)p.ks1 * S * hd);
+  p.off_part1 = take((size_t)p.ks1 * m_pad * hd);
   p.off_kbar = take((size_t)S * hd);
   p.off_c = take((size_t)S);
-  p.off_part2 = take((size_t)p.ks2 * S * d);
+  p.off_part2 = take((size_t)p.ks2 * m_pad * d);
   p.off_w = take((size_t)S * d);
-  p.off_xs = take(((size_t)3 * S * d + 1) / 2);
-  p.off_ksp = take(((size_t)3 * S * hd + 1) / 2);
+  p.off_xs = take(((size_t)3 * m_pad * d + 1) / 2);
+  p.off_ksp = take(((size_t)3 * m_pad * hd + 1) / 2);
   p.off_cpart = take((size_t)S * p.n_cpart);
   p.total = o;
   return p;
@@ -605,17 +606,19 @@ inline int run_proj(hipStream_t st, const vsel_segments* seg, const vsel_scorer*
       hipLaunchKernelGGL(colsum_finish_split_kernel, dim3((unsigned)cdiv(d, 256), S), dim3(256), 0, st, partial, sv, d,
                          p.row_splits, S, xs);
       VSEL_AFTER_LAUNCH(st, "colsum_finish_split_kernel");
-      hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, dim3((unsigned)cdiv(hd, 32), (unsigned)cdiv(S, 32), p.ks1), dim3(64), 0, st,
-                         xs, (const uint16_t*)sc->wk, S, hd, d, p.kslice1, part1);
+      const unsigned mtiles = (unsigned)cdiv(S, 32);
+      const int m_pad = 32 * (int)mtiles;
+      hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, dim3((unsigned)cdiv(hd, 64), mtiles, p.ks1), dim3(64), 0, st, xs,
+                         (const uint16_t*)sc->wk, S, hd, d, p.kslice1, part1);
       VSEL_AFTER_LAUNCH(st, "gemm_nt_bf16x3_kernel");
-      hipLaunchKernelGGL(kbar_finish_split_kernel, dim3(p.n_cpart, S), dim3(256), 0, st, part1, p.ks1, S, hd,
+      hipLaunchKernelGGL(kbar_finish_split_kernel, dim3(mtiles, p.n_cpart), dim3(256), 0, st, part1, p.ks1, S, hd, m_pad,
                          (const uint16_t*)sc->bk, (const uint16_t*)sc->bq, kbar, ksp, cpart);
       VSEL_AFTER_LAUNCH(st, "kbar_finish_split_kernel");
-      hipLaunchKernelGGL(gemm_nn_bf16x3_kernel, dim3((unsigned)cdiv(d, 256), (unsigned)cdiv(S, 32), p.ks2), dim3(64), 0, st,
-                         ksp, (const uint16_t*)sc->wq, S, d, hd, p.kslice2, part2);
+      hipLaunchKernelGGL(gemm_nn_bf16x3_kernel, dim3((unsigned)cdiv(d, 256), mtiles, p.ks2), dim3(64), 0, st, ksp,
+                         (const uint16_t*)sc->wq, S, d, hd, p.kslice2, part2);
       VSEL_AFTER_LAUNCH(st, "gemm_nn_bf16x3_kernel");
-      hipLaunchKernelGGL(w_finish_kernel, dim3((unsigned)cdiv(d, 256), S), dim3(256), 0, st, part2, p.ks2, S, d, cpart,
-                         p.n_cpart, w, c);
+      hipLaunchKernelGGL(w_finish_kernel, dim3(mtiles, (unsigned)cdiv(d, 8)), dim3(256), 0, st, part2, p.ks2, S, d, m_pad,
+                         cpart, p.n_cpart, w, c);
       VSEL_AFTER_LAUNCH(st, "w_finish_kernel");
       return VSEL_OK;
     }

@@ -10,6 +10,14 @@
 //
 // MFMA operand layout (32x32x16): lane = 32*kg + i holds A[i][8*kg .. 8*kg+7] / B[8*kg .. +7][i]; the same
 // k-assignment is used for both operands, C[row][col]: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+//
+// Memory shapes chosen for the load/store path, not the math (the MFMA work is ~1 us of chip time; the first version
+// spent 20-40 us in 32-rows-x-32-bytes fragment-shaped loads and 4-byte scattered slab stores):
+//   * the activation planes are produced by our own finish kernels, so they are stored FRAGMENT-MAJOR:
+//       plane[p][m_tile][k_step][lane][8]  ->  a wave's B operand for one k-step is ONE contiguous 1 KiB load
+//   * split-K slabs are stored [ks][n][m_pad] (m fastest): an MFMA C column (32 lanes = 32 consecutive m) is one
+//     128-byte line per store instead of 32 scattered dwords
+//   * the NT kernel covers two 32-row weight tiles per wave, halving the re-reads of the activation planes
 #pragma once
 #include "common.h"
 
@@ -42,7 +50,13 @@ __device__ __forceinline__ float strided_sum(const float* __restrict__ p, int n,
   return acc;
 }
 
-// xs[p][m][c] (bf16 planes) = split3( sum_rs partial[m][rs][c] / N_m )
+// fragment-major offset (in bf16 elements) of activation element (m, k) of plane p; K % 16 == 0
+__device__ __forceinline__ int64_t frag_off(int p, int m, int k, int m_tiles, int k_steps) {
+  const int mt = m >> 5, i = m & 31, ks = k >> 4, kg = (k >> 3) & 1, e = k & 7;
+  return ((((int64_t)p * m_tiles + mt) * k_steps + ks) * 64 + (32 * kg + i)) * 8 + e;
+}
+
+// xs (fragment-major bf16x3 planes) = split3( sum_rs partial[m][rs][c] / N_m )
 static __global__ __launch_bounds__(256) void colsum_finish_split_kernel(const float* __restrict__ partial, SegView sv,
                                                                          int d, int row_splits, int M,
                                                                          uint16_t* __restrict__ xs) {
@@ -53,97 +67,118 @@ static __global__ __launch_bounds__(256) void colsum_finish_split_kernel(const f
   const float x = strided_sum(p, row_splits, d) / (float)sv.n_rows(s);
   uint32_t b1, b2, b3;
   split3(x, b1, b2, b3);
-  const int64_t plane = (int64_t)M * d;
-  xs[(int64_t)s * d + c] = (uint16_t)b1;
-  xs[plane + (int64_t)s * d + c] = (uint16_t)b2;
-  xs[2 * plane + (int64_t)s * d + c] = (uint16_t)b3;
+  const int mt = (M + 31) >> 5, ksteps = d >> 4;
+  xs[frag_off(0, s, c, mt, ksteps)] = (uint16_t)b1;
+  xs[frag_off(1, s, c, mt, ksteps)] = (uint16_t)b2;
+  xs[frag_off(2, s, c, mt, ksteps)] = (uint16_t)b3;
 }
 
-// NT: part[ks][m][n] = sum_{k in slice} x[m][k] w[n][k].  grid (N/32, M/32, KS), one wave per block.
-// Requires K % 16 == 0.  Rows beyond N / M are clamped (their results are never stored).
+// NT: part[ks][n][m_pad] = sum_{k in slice} x[m][k] w[n][k].  grid (ceil(N/64), m_tiles, KS), one wave per block:
+// two 32-row weight tiles x one 32-column activation tile.  Requires K % 16 == 0.  m_pad = 32 * m_tiles.
 static __global__ __launch_bounds__(64) void gemm_nt_bf16x3_kernel(const uint16_t* __restrict__ xs,
                                                                    const uint16_t* __restrict__ w, int M, int N, int K,
                                                                    int kslice, float* __restrict__ part) {
   const int lane = threadIdx.x;
   const int i = lane & 31, kg = lane >> 5;
-  const int n_row = min(blockIdx.x * 32 + i, N - 1);
-  const int m_row = min(blockIdx.y * 32 + i, M - 1);
+  const int mt = blockIdx.y, m_tiles = gridDim.y, ksteps = K >> 4;
+  const int n0 = blockIdx.x * 64;
+  const int row0 = min(n0 + i, N - 1), row1 = min(n0 + 32 + i, N - 1);
   const int ks = blockIdx.z;
   const int k_begin = ks * kslice;
   const int k_end = min(K, k_begin + kslice);
-  const int64_t plane = (int64_t)M * K;
-  const uint16_t* wp = w + (int64_t)n_row * K + 8 * kg;
-  const uint16_t* xp = xs + (int64_t)m_row * K + 8 * kg;
-  f32x16 acc;
+  const uint16_t* wp0 = w + (int64_t)row0 * K + 8 * kg;
+  const uint16_t* wp1 = w + (int64_t)row1 * K + 8 * kg;
+  const int64_t plane = (int64_t)m_tiles * ksteps * 512;          // elements per plane
+  const uint16_t* xp = xs + ((int64_t)mt * ksteps * 64 + lane) * 8;
+  f32x16 acc0, acc1;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  // 4 k-steps (64 k) per iteration: 16 independent 16-byte loads in flight per lane before the 12 MFMAs
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  // The kernel is latency-bound (one wave per block, ~400 waves): issue the loads of 8 k-steps (40 x 16 B per lane)
+  // back to back, then run their 48 MFMAs; a 256-wide k-slice is two such round trips.
   int k0 = k_begin;
-  for (; k0 + 64 <= k_end; k0 += 64) {
-    u32x4 a[4], b1[4], b2[4], b3[4];
+  constexpr int KB = 8;
+  for (; k0 + 16 * KB <= k_end; k0 += 16 * KB) {
+    u32x4 a0[KB], a1[KB], b1[KB], b2[KB], b3[KB];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      a[u] = *reinterpret_cast<const u32x4*>(wp + k0 + 16 * u);
-      b1[u] = *reinterpret_cast<const u32x4*>(xp + k0 + 16 * u);
-      b2[u] = *reinterpret_cast<const u32x4*>(xp + plane + k0 + 16 * u);
-      b3[u] = *reinterpret_cast<const u32x4*>(xp + 2 * plane + k0 + 16 * u);
+    for (int u = 0; u < KB; ++u) {
+      const int64_t xo = (int64_t)((k0 >> 4) + u) * 512;
+      a0[u] = *reinterpret_cast<const u32x4*>(wp0 + k0 + 16 * u);
+      a1[u] = *reinterpret_cast<const u32x4*>(wp1 + k0 + 16 * u);
+      b1[u] = *reinterpret_cast<const u32x4*>(xp + xo);
+      b2[u] = *reinterpret_cast<const u32x4*>(xp + plane + xo);
+      b3[u] = *reinterpret_cast<const u32x4*>(xp + 2 * plane + xo);
     }
+    __builtin_amdgcn_sched_barrier(0);   // keep all loads above the MFMAs (the scheduler otherwise sinks them to save VGPRs)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[u]), as_bf16x8(b3[u]), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[u]), as_bf16x8(b2[u]), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[u]), as_bf16x8(b1[u]), acc, 0, 0, 0);
+    for (int u = 0; u < KB; ++u) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0[u]), as_bf16x8(b3[u]), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[u]), as_bf16x8(b3[u]), acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0[u]), as_bf16x8(b2[u]), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[u]), as_bf16x8(b2[u]), acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0[u]), as_bf16x8(b1[u]), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[u]), as_bf16x8(b1[u]), acc1, 0, 0, 0);
     }
   }
   for (; k0 < k_end; k0 += 16) {
-    const u32x4 a = *reinterpret_cast<const u32x4*>(wp + k0);
-    const u32x4 b1 = *reinterpret_cast<const u32x4*>(xp + k0);
-    const u32x4 b2 = *reinterpret_cast<const u32x4*>(xp + plane + k0);
-    const u32x4 b3 = *reinterpret_cast<const u32x4*>(xp + 2 * plane + k0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b3), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b2), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b1), acc, 0, 0, 0);
+    const int64_t xo = (int64_t)(k0 >> 4) * 512;
+    const u32x4 a0 = *reinterpret_cast<const u32x4*>(wp0 + k0);
+    const u32x4 a1 = *reinterpret_cast<const u32x4*>(wp1 + k0);
+    const u32x4 b1 = *reinterpret_cast<const u32x4*>(xp + xo);
+    const u32x4 b2 = *reinterpret_cast<const u32x4*>(xp + plane + xo);
+    const u32x4 b3 = *reinterpret_cast<const u32x4*>(xp + 2 * plane + xo);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(b3), acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(b3), acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(b2), acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(b2), acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(b1), acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(b1), acc1, 0, 0, 0);
   }
-  const int m = blockIdx.y * 32 + (lane & 31);
-  if (m < M) {
-    float* dst = part + ((int64_t)ks * M + m) * N + blockIdx.x * 32;
+  // C[row = n][col = m]; slab layout [ks][n][m_pad]: 32 lanes of one C row -> 128 contiguous bytes
+  const int m_pad = 32 * m_tiles;
+  float* dst = part + ((int64_t)ks * N) * m_pad + 32 * mt + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
-      if (blockIdx.x * 32 + row < N) dst[row] = acc[r];
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
+    if (n0 + row < N) dst[(int64_t)(n0 + row) * m_pad] = acc0[r];
+    if (n0 + 32 + row < N) dst[(int64_t)(n0 + 32 + row) * m_pad] = acc1[r];
   }
 }
 
-// kbar[m][h] = sum_ks part[ks][m][h] + bk[h]  -> fp32 copy + bf16x3 planes; cpart[m][bx] = sum_{h in block} bq[h] kbar[m][h]
+// kbar[m][h] = sum_ks part[ks][h][m] + bk[h]  -> fp32 copy + fragment-major bf16x3 planes;
+// cpart[m][by] = sum_{h in block} bq[h] kbar[m][h].  grid (ceil(m_pad/32), ceil(N/8)), block 256 = 32 m x 8 h.
 static __global__ __launch_bounds__(256) void kbar_finish_split_kernel(const float* __restrict__ part, int KS, int M, int N,
-                                                                       const uint16_t* __restrict__ bk,
+                                                                       int m_pad, const uint16_t* __restrict__ bk,
                                                                        const uint16_t* __restrict__ bq,
                                                                        float* __restrict__ kbar, uint16_t* __restrict__ ksp,
                                                                        float* __restrict__ cpart) {
-  const int m = blockIdx.y;
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  float cacc = 0.f;
-  if (n < N) {
-    float v = strided_sum(part + (int64_t)m * N + n, KS, (int64_t)M * N);
+  const int m = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int n = blockIdx.y * 8 + (threadIdx.x >> 5);
+  float cterm = 0.f;
+  if (m < M && n < N) {
+    float v = strided_sum(part + (int64_t)n * m_pad + m, KS, (int64_t)N * m_pad);
     v += bf16_to_f32(bk[n]);
     kbar[(int64_t)m * N + n] = v;
     uint32_t b1, b2, b3;
     split3(v, b1, b2, b3);
-    const int64_t plane = (int64_t)M * N;
-    ksp[(int64_t)m * N + n] = (uint16_t)b1;
-    ksp[plane + (int64_t)m * N + n] = (uint16_t)b2;
-    ksp[2 * plane + (int64_t)m * N + n] = (uint16_t)b3;
-    cacc = bf16_to_f32(bq[n]) * v;
+    const int mt = m_pad >> 5, ksteps = N >> 4;
+    ksp[frag_off(0, m, n, mt, ksteps)] = (uint16_t)b1;
+    ksp[frag_off(1, m, n, mt, ksteps)] = (uint16_t)b2;
+    ksp[frag_off(2, m, n, mt, ksteps)] = (uint16_t)b3;
+    cterm = bf16_to_f32(bq[n]) * v;
   }
-  cacc = wave_sum(cacc);
-  __shared__ float red[4];
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cacc;
+  // per-m sum over the block's 8 h values, fixed order
+  __shared__ float red[8][33];
+  red[threadIdx.x >> 5][threadIdx.x & 31] = cterm;
   __syncthreads();
-  if (threadIdx.x == 0) cpart[(int64_t)m * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x < 32 && m < M) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += red[j][threadIdx.x];
+    cpart[(int64_t)m * gridDim.y + blockIdx.y] = t;
+  }
 }
 
-// NN: part[ks][m][n] = sum_{k in slice} x[m][k] w[k][n], w row-major [K, N].  grid (N/256, M/32, KS), one wave.
+// NN: part[ks][n][m_pad] = sum_{k in slice} x[m][k] w[k][n], w row-major [K, N].  grid (ceil(N/256), m_tiles, KS), one wave.
 // Lane (i, kg) owns 8 consecutive n (n0 + 8i .. +7) and k rows k0 + 8kg .. +7: eight 16-byte row loads, then a
 // register transpose (v_perm_b32) builds, for each t in 0..7, the A fragment {w[k0+8kg+e][n0+8i+t]}_e of the
 // 32x32 tile "n = n0 + 8*i' + t".  Requires K % 16 == 0 and N % 8 == 0.
@@ -152,34 +187,21 @@ static __global__ __launch_bounds__(64) void gemm_nn_bf16x3_kernel(const uint16_
                                                                    int kslice, float* __restrict__ part) {
   const int lane = threadIdx.x;
   const int i = lane & 31, kg = lane >> 5;
+  const int mt = blockIdx.y, m_tiles = gridDim.y, ksteps = K >> 4;
   const int nb = min(blockIdx.x * 256 + 8 * i, N - 8);
-  const int m_row = min(blockIdx.y * 32 + i, M - 1);
   const int ks = blockIdx.z;
   const int k_begin = ks * kslice;
   const int k_end = min(K, k_begin + kslice);
-  const int64_t plane = (int64_t)M * K;
-  const uint16_t* xp = xs + (int64_t)m_row * K + 8 * kg;
+  const int64_t plane = (int64_t)m_tiles * ksteps * 512;
+  const uint16_t* xp = xs + ((int64_t)mt * ksteps * 64 + lane) * 8;
   const uint16_t* wp = w + (int64_t)(8 * kg) * N + nb;
   f32x16 acc[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  u32x4 wv[8], b1, b2, b3;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) wv[e] = *reinterpret_cast<const u32x4*>(wp + (int64_t)(k_begin + e) * N);
-  b1 = *reinterpret_cast<const u32x4*>(xp + k_begin);
-  b2 = *reinterpret_cast<const u32x4*>(xp + plane + k_begin);
-  b3 = *reinterpret_cast<const u32x4*>(xp + 2 * plane + k_begin);
-  for (int k0 = k_begin; k0 < k_end; k0 += 16) {
-    // software prefetch of the next step (the last iteration re-reads its own step)
-    const int kn = (k0 + 16 < k_end) ? k0 + 16 : k0;
-    u32x4 nwv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) nwv[e] = *reinterpret_cast<const u32x4*>(wp + (int64_t)(kn + e) * N);
-    const u32x4 nb1 = *reinterpret_cast<const u32x4*>(xp + kn);
-    const u32x4 nb2 = *reinterpret_cast<const u32x4*>(xp + plane + kn);
-    const u32x4 nb3 = *reinterpret_cast<const u32x4*>(xp + 2 * plane + kn);
+  // latency-bound like the NT kernel: the loads of KB k-steps (KB x 11 x 16 B per lane) are issued together
+  auto step = [&](const u32x4 (&wv)[8], u32x4 b1, u32x4 b2, u32x4 b3) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       // element t of vector e sits in dword t>>1, half t&1; pack (e even -> low half, e odd -> high half)
@@ -191,39 +213,65 @@ static __global__ __launch_bounds__(64) void gemm_nn_bf16x3_kernel(const uint16_
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b2), acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b1), acc[t], 0, 0, 0);
     }
+  };
+  constexpr int KB = 4;
+  int k0 = k_begin;
+  for (; k0 + 16 * KB <= k_end; k0 += 16 * KB) {
+    u32x4 wv[KB][8], b1[KB], b2[KB], b3[KB];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) wv[e] = nwv[e];
-    b1 = nb1; b2 = nb2; b3 = nb3;
+    for (int u = 0; u < KB; ++u) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wv[u][e] = *reinterpret_cast<const u32x4*>(wp + (int64_t)(k0 + 16 * u + e) * N);
+      const int64_t xo = (int64_t)((k0 >> 4) + u) * 512;
+      b1[u] = *reinterpret_cast<const u32x4*>(xp + xo);
+      b2[u] = *reinterpret_cast<const u32x4*>(xp + plane + xo);
+      b3[u] = *reinterpret_cast<const u32x4*>(xp + 2 * plane + xo);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < KB; ++u) step(wv[u], b1[u], b2[u], b3[u]);
   }
-  const int m = blockIdx.y * 32 + (lane & 31);
-  if (m < M) {
-    float* dst = part + ((int64_t)ks * M + m) * N + blockIdx.x * 256;
+  for (; k0 < k_end; k0 += 16) {
+    u32x4 wv[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int irow = (r & 3) + 8 * (r >> 2) + 4 * kg;
-      if (blockIdx.x * 256 + 8 * irow < N) {
-        f32x4 lo = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-        f32x4 hi = {acc[4][r], acc[5][r], acc[6][r], acc[7][r]};
-        *reinterpret_cast<f32x4*>(dst + 8 * irow) = lo;
-        *reinterpret_cast<f32x4*>(dst + 8 * irow + 4) = hi;
-      }
+    for (int e = 0; e < 8; ++e) wv[e] = *reinterpret_cast<const u32x4*>(wp + (int64_t)(k0 + e) * N);
+    const int64_t xo = (int64_t)(k0 >> 4) * 512;
+    step(wv, *reinterpret_cast<const u32x4*>(xp + xo), *reinterpret_cast<const u32x4*>(xp + plane + xo),
+         *reinterpret_cast<const u32x4*>(xp + 2 * plane + xo));
+  }
+  // acc[t][r] = C[n = n0 + 8*irow + t][m = 32*mt + (lane & 31)]; slab [ks][n][m_pad]
+  const int m_pad = 32 * m_tiles;
+  float* dst = part + ((int64_t)ks * N) * m_pad + 32 * mt + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int irow = (r & 3) + 8 * (r >> 2) + 4 * kg;
+    const int n = blockIdx.x * 256 + 8 * irow;
+    if (n < N) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) dst[(int64_t)(n + t) * m_pad] = acc[t][r];
     }
   }
 }
 
-// w[m][n] = sum_ks part[ks][m][n];  c[m] = sum_j cpart[m][j]  (block x == 0 of each m)
-static __global__ __launch_bounds__(256) void w_finish_kernel(const float* __restrict__ part, int KS, int M, int N,
+// w[m][n] = sum_ks part[ks][n][m];  c[m] = sum_j cpart[m][j].  grid (ceil(m_pad/32), ceil(N/8)), block 256 = 32 m x 8 n.
+static __global__ __launch_bounds__(256) void w_finish_kernel(const float* __restrict__ part, int KS, int M, int N, int m_pad,
                                                               const float* __restrict__ cpart, int n_cpart,
                                                               float* __restrict__ w, float* __restrict__ c) {
-  const int m = blockIdx.y;
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n < N) {
-    w[(int64_t)m * N + n] = strided_sum(part + (int64_t)m * N + n, KS, (int64_t)M * N);
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float t = 0.f;
-    for (int j = 0; j < n_cpart; ++j) t += cpart[(int64_t)m * n_cpart + j];
-    c[m] = t;
+  const int m = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int n = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (m < M && n < N) w[(int64_t)m * N + n] = strided_sum(part + (int64_t)n * m_pad + m, KS, (int64_t)N * m_pad);
+  if (blockIdx.y == 0) {
+    // c[m]: thread (m, nj) sums cpart[m][nj], [nj + 8], ... then the 8 partials are added in fixed order
+    const int nj = threadIdx.x >> 5;
+    __shared__ float red[8][33];
+    red[nj][threadIdx.x & 31] = (m < M && nj < n_cpart) ? strided_sum(cpart + (int64_t)m * n_cpart + nj, (n_cpart - nj + 7) / 8, 8) : 0.f;
+    __syncthreads();
+    if (threadIdx.x < 32 && m < M) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t += red[j][threadIdx.x];
+      c[m] = t;
+    }
   }
 }
 

@@ -81,12 +81,23 @@ def cpu_baseline(budget, seconds_budget=14.0):
             "ms_per_image": best[0] * 1e3, "ms_per_image_median": best[2] * 1e3}
 
 
+def pmc_traffic(kernel, b):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json; separate
+    FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if that (kernel, B) was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            tab = json.load(f)
+        return tab.get(str(b), {}).get(kernel, {}).get("hbm_bytes")
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--images", type=int, default=64, help="images per step per GPU (B)")
+    ap.add_argument("--images", type=int, default=128, help="images per step per GPU (B)")
     ap.add_argument("--budget", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-attn", action="store_true")
@@ -183,9 +194,10 @@ def main():
         avg_s = prof[dom][0] / prof[dom][1] * 1e-3
         ach = (kb / avg_s / 1e9) if kb else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None,
+                    "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": pmc_traffic(dom, b),
                     "algorithmic_bytes_per_launch": kb, "avg_launch_us": avg_s * 1e6,
-                    "note": "achieved = algorithmic bytes of this kernel / its HIP-event duration; traffic (PMC) in profiles/"}
+                    "note": "achieved = algorithmic bytes of this kernel / its HIP-event duration (instrumented single-stream pass); "
+                            "traffic = bytes/launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json)"}
     path_bytes = algorithmic_bytes(b, n, d, hd, k)
     path = {"algorithmic_bytes_per_step": path_bytes, "achieved_GBps": path_bytes / (ms_per_step * 1e-3) / 1e9,
             "frac_of_8TBps": path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}

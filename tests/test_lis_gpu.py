@@ -229,6 +229,7 @@ def test_two_half_pipeline_equals_single_stream(ops):
     lib = _native.lib()
     c = oin.make_case(2048, 1024, 300, 5, batch=35)
     h, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    lib.vsel_debug_set_pipeline(ctypes.c_int(1))
     a = ops.lis_select(h, wq, bq, wk, bk, 77)
     lens = [300, 17, 1000, 64, 5, 700, 33, 900, 12] * 4
     ks = [max(1, n // 5) for n in lens]
@@ -247,6 +248,7 @@ def test_two_half_pipeline_equals_single_stream(ops):
     # back-to-back calls on the same stream reuse the aux stream / events correctly
     outs = [ops.lis_select(h, wq, bq, wk, bk, 77) for _ in range(20)]
     torch.cuda.synchronize()
+    lib.vsel_debug_set_pipeline(ctypes.c_int(0))
     for o in outs:
         for x, y in zip(o, a):
             assert torch.equal(x, y)

@@ -34,7 +34,7 @@ constexpr int kLds = 2 * kKBuf + 2 * kVBuf;  // 72 KiB
 __device__ __forceinline__ bf16x8_t to_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 
 template <bool USE_TR>
-__global__ __launch_bounds__(256) void varlen_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+__global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                               const uint16_t* __restrict__ v,
                                                               const int32_t* __restrict__ cu, int hq, int hkv,
                                                               float scale_log2e, int causal, uint16_t* __restrict__ out) {

@@ -1,6 +1,8 @@
 // C-ABI entry points of the LIS inference path (kernels in lis_kernels.h).
 #include "lis_kernels.h"
 
+#include <stdlib.h>
+
 namespace vsel {
 int check_segments(const vsel_segments* seg, bool need_k) { return check_segments_impl(seg, need_k); }
 }  // namespace vsel
@@ -37,7 +39,13 @@ static AuxStream* aux_for_current_device() {
   return &a;
 }
 
-static int g_pipeline_enabled = 1;
+// OFF by default: VSEL_PIPELINE=1 in the environment (or vsel_debug_set_pipeline(1)) turns it on.  Measured +4 % tokens/s
+// at B=128 on MI355X; it is opt-in because concurrent half-batch launches make per-kernel durations (rocprofv3, HIP
+// events) incomparable with the single-stream roofline numbers bench.py reports.
+static int g_pipeline_enabled = [] {
+  const char* e = getenv("VSEL_PIPELINE");
+  return (e && e[0] == '1') ? 1 : 0;
+}();
 extern "C" void vsel_debug_set_pipeline(int on) { g_pipeline_enabled = on; }
 
 template <typename T, typename TW>

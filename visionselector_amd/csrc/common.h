@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <type_traits>
 
 #include "../../include/vsel.h"
 
@@ -102,21 +103,28 @@ __device__ __forceinline__ void store_elem(bf16_t* p, float v) { p->bits = (uint
 __device__ __forceinline__ void store_elem(float* p, float v) { *p = v; }
 
 // ---- wave64 reductions (fixed order => deterministic) -----------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+// DPP instead of __shfl_xor: hipcc lowers every __shfl_xor to ds_bpermute_b32 (an LDS-crossbar round trip, ~6 dependent
+// ones per reduction); quad_perm / row_mirror DPP modifiers ride on the VALU op itself.  After 4 DPP steps every lane
+// holds its 16-lane row's result; the 4 rows are combined through v_readlane (uniform values).
+template <typename Op>
+__device__ __forceinline__ float wave_reduce_dpp(float v, Op op) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));    // quad_perm [1,0,3,2]
+  v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));    // quad_perm [2,3,0,1]
+  v = op(v, dpp(v, std::integral_constant<int, 0x141>{}));   // row_half_mirror
+  v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));   // row_mirror
+  const int vi = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+  return op(op(r0, r1), op(r2, r3));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-  return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_reduce_dpp(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ float wave_max(float v) { return wave_reduce_dpp(v, [](float a, float b) { return fmaxf(a, b); }); }
+__device__ __forceinline__ float wave_min(float v) { return wave_reduce_dpp(v, [](float a, float b) { return fminf(a, b); }); }
 
 // ---- segments -----------------------------------------------------------------------------------
 struct SegView {

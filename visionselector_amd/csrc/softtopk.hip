@@ -27,20 +27,36 @@ __device__ __forceinline__ float block_sum(float v, float (*red)[NW], int slot) 
   return t;
 }
 
-template <int NT>
+// EPT > 0: the row lives in registers (EPT elements per thread, n <= NT * EPT); EPT == 0: re-read from global (huge rows).
+// Early exit: once `mid` equals `lo` or `hi` (adjacent floats) the remaining iterations of the reference's fixed 64-step
+// loop cannot change (lo, hi) any more, so stopping there returns the same ts bit for bit.
+template <int NT, int EPT>
 __global__ __launch_bounds__(NT) void soft_topk_fwd_kernel(const float* __restrict__ xs, int n, int k,
                                                            float* __restrict__ ps, float* __restrict__ ts) {
   constexpr int NW = NT / 64;
+  constexpr int E = EPT > 0 ? EPT : 1;
   __shared__ float red[4][NW];
   const int row = blockIdx.x;
   const float* x = xs + (int64_t)row * n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
+  float xr[E];
   float mx = -INFINITY, mn = INFINITY;
-  for (int i = tid; i < n; i += NT) {
-    const float v = x[i];
-    mx = fmaxf(mx, v);
-    mn = fminf(mn, v);
+  if constexpr (EPT > 0) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = tid + e * NT;
+      const bool ok = i < n;
+      const float v = ok ? x[i] : 0.f;
+      xr[e] = ok ? v : -INFINITY;            // sigmoid(-inf + t) = 0: padding never contributes
+      if (ok) { mx = fmaxf(mx, v); mn = fminf(mn, v); }
+    }
+  } else {
+    for (int i = tid; i < n; i += NT) {
+      const float v = x[i];
+      mx = fmaxf(mx, v);
+      mn = fminf(mn, v);
+    }
   }
   mx = wave_max(mx);
   mn = wave_min(mn);
@@ -56,13 +72,28 @@ __global__ __launch_bounds__(NT) void soft_topk_fwd_kernel(const float* __restri
   for (int it = 0; it < 64; ++it) {             // :80
     const float mid = (hi + lo) / 2.0f;         // :81
     float acc = 0.f;
-    for (int i = tid; i < n; i += NT) acc += sigmoidf_ref(x[i] + mid);
+    if constexpr (EPT > 0) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc += sigmoidf_ref(xr[e] + mid);
+    } else {
+      for (int i = tid; i < n; i += NT) acc += sigmoidf_ref(x[i] + mid);
+    }
     const float sum = block_sum<NW>(acc, red, it & 1);
+    const bool fixed_point = (mid == lo) || (mid == hi);
     if (sum < kf) lo = mid; else hi = mid;      // :82-84
+    if (fixed_point) break;
   }
   const float t = (lo + hi) / 2.0f;             // :85
   if (tid == 0) ts[row] = t;
-  for (int i = tid; i < n; i += NT) ps[(int64_t)row * n + i] = sigmoidf_ref(x[i] + t);  // :86
+  if constexpr (EPT > 0) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = tid + e * NT;
+      if (i < n) ps[(int64_t)row * n + i] = sigmoidf_ref(xr[e] + t);   // :86
+    }
+  } else {
+    for (int i = tid; i < n; i += NT) ps[(int64_t)row * n + i] = sigmoidf_ref(x[i] + t);
+  }
 }
 
 template <int NT>
@@ -95,10 +126,14 @@ __global__ __launch_bounds__(NT) void soft_topk_bwd_kernel(const float* __restri
 }
 
 int launch_soft_topk_fwd(hipStream_t st, const float* xs, int64_t b, int64_t n, int64_t k, float* ps, float* ts) {
-  if (n <= 4096)
-    hipLaunchKernelGGL((soft_topk_fwd_kernel<256>), dim3((unsigned)b), dim3(256), 0, st, xs, (int)n, (int)k, ps, ts);
+  if (n <= 1024)
+    hipLaunchKernelGGL((soft_topk_fwd_kernel<256, 4>), dim3((unsigned)b), dim3(256), 0, st, xs, (int)n, (int)k, ps, ts);
+  else if (n <= 4096)
+    hipLaunchKernelGGL((soft_topk_fwd_kernel<1024, 4>), dim3((unsigned)b), dim3(1024), 0, st, xs, (int)n, (int)k, ps, ts);
+  else if (n <= 16384)
+    hipLaunchKernelGGL((soft_topk_fwd_kernel<1024, 16>), dim3((unsigned)b), dim3(1024), 0, st, xs, (int)n, (int)k, ps, ts);
   else
-    hipLaunchKernelGGL((soft_topk_fwd_kernel<1024>), dim3((unsigned)b), dim3(1024), 0, st, xs, (int)n, (int)k, ps, ts);
+    hipLaunchKernelGGL((soft_topk_fwd_kernel<1024, 0>), dim3((unsigned)b), dim3(1024), 0, st, xs, (int)n, (int)k, ps, ts);
   VSEL_AFTER_LAUNCH(st, "soft_topk_fwd_kernel");
   return VSEL_OK;
 }

@@ -178,6 +178,7 @@ def main():
 
     if rank != 0:
         if dist:
+            dist.barrier()              # rank 0 is still producing the report (attention leg); leave together
             dist.destroy_process_group()
         return
 
@@ -225,8 +226,9 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.budget)
         res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
-    print(json.dumps(res))
+    print(json.dumps(res), flush=True)
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

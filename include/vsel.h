@@ -143,6 +143,24 @@ int vsel_lis_scores_bwd(void* stream, const float* g, const void* h, vsel_dtype 
                         const vsel_scorer* scorer, void* workspace, size_t workspace_bytes, float* dwq, float* dbq,
                         float* dwk, float* dbk, void* dh);
 
+/* -------- sequence splice after selection (batch 1, like the reference) ---------------------------
+ * Replaces the index algebra of EV/token_compression/selector_model.py:246-262 (image), :264-290 (video) and the
+ * position_ids / attention_mask slices of :311-320 (OV/compression_method/modeling_selector.py:259-276, 311-314) with two
+ * launches and no host sync.  A position is kept iff it is not `visual_token_id`, or its rank among the visual tokens is
+ * in `all_indices` (ascending, as vsel_lis_select returns it).  L' = seq_len - n_visual + k.
+ *   in : input_ids int64 [L]; all_indices int64 [k]; inputs_embeds [L, d_llm]; visual_embeds [k, d_llm] (kept rows);
+ *        position_ids int64 [pos_rows, L] (3 for M-RoPE, 1 for 1-D, 0 = none); attention_mask int64 [L] or NULL
+ *   out: selected_indices, new_input_ids int64 [L']; new_inputs_embeds [L', d_llm]; new_position_ids [pos_rows, L'];
+ *        new_attention_mask [L'] or NULL; src_scratch int32 [L']; stats int32 [3] = {visual tokens found, rows written,
+ *        kept visual rows} (device; the caller may check them against n_visual / L' / k -- the reference raises
+ *        ValueError on a token-count mismatch, FT/compression_method/selector_model.py:210-213).                      */
+int vsel_splice(void* stream, const int64_t* input_ids, int64_t seq_len, int64_t visual_token_id,
+                const int64_t* all_indices, int64_t k, int64_t n_visual, const void* inputs_embeds,
+                const void* visual_embeds, vsel_dtype dtype, int64_t d_llm, const int64_t* position_ids,
+                int64_t pos_rows, const int64_t* attention_mask, int64_t* selected_indices, int64_t* new_input_ids,
+                void* new_inputs_embeds, int64_t* new_position_ids, int64_t* new_attention_mask,
+                int32_t* src_scratch, int32_t* stats);
+
 /* -------- var-len causal attention (compressed-sequence prefill) --------------------------------
  * Replaces flash_attn_varlen_func as called by FT/qwenvl/train/trainer.py:101-113 and the FA2 prefill
  * of EV/qwen25vl/modeling_qwen2_5_vl.py:900 / OV/llavaonevision1_5/modeling_llavaonevision1_5.py:686.

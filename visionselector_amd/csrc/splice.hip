@@ -1,0 +1,140 @@
+// Sequence splice after selection, on device and without a host sync.
+//
+// Reference (batch 1): qwen-evaluation/token_compression/selector_model.py:246-262 (image), :264-290 (video),
+// :311-320 (M-RoPE position_ids / attention_mask slice); llava-ov-15/compression_method/modeling_selector.py:259-276,311-314.
+// The reference builds the kept-position list with torch.where / cat / sort / index / masked_scatter (a dozen launches and
+// a device->host sync for the dynamic shapes).  Here the output length L' = L - N + k is known on the host, so:
+//   splice_index_kernel   one workgroup: bitmap of kept visual ranks in LDS, then an ordered ballot/popcount scan over the
+//                         L positions emits selected_indices, input_ids', attention_mask', position_ids'[r][.] and a
+//                         source descriptor per output row (text row p, or kept visual row j)
+//   splice_embed_kernel   wave per output row: copy D_llm elements from inputs_embeds[p] or from the kept visual rows
+// A position p is kept iff it is not a visual token, or its rank among the visual tokens is in all_indices.  For the
+// reference's video branch (one contiguous <vision_start> video... <vision_end> block) this is the same set as :284-287.
+#include "common.h"
+
+#include <algorithm>
+
+namespace vsel {
+
+constexpr int kSpliceThreads = 1024;
+constexpr int kMaxVisualBits = 1 << 18;   // 262 144 visual tokens -> 32 KiB bitmap
+
+__global__ __launch_bounds__(kSpliceThreads) void splice_index_kernel(
+    const int64_t* __restrict__ ids, int L, int64_t visual_id, const int64_t* __restrict__ all_indices, int k, int n_visual,
+    const int64_t* __restrict__ pos, int pos_rows, const int64_t* __restrict__ mask, int64_t* __restrict__ sel,
+    int64_t* __restrict__ new_ids, int64_t* __restrict__ new_pos, int64_t* __restrict__ new_mask,
+    int32_t* __restrict__ src, int32_t* __restrict__ stats, int l_out) {
+  extern __shared__ uint32_t bitmap[];
+  __shared__ uint32_t wv[16], wk[16], wj[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int words = (n_visual + 31) >> 5;
+  for (int i = tid; i < words; i += kSpliceThreads) bitmap[i] = 0u;
+  __syncthreads();
+  for (int j = tid; j < k; j += kSpliceThreads) {
+    const int64_t r = all_indices[j];
+    if (r >= 0 && r < n_visual) atomicOr(&bitmap[r >> 5], 1u << (r & 31));
+  }
+  __syncthreads();
+  uint32_t run_vis = 0, run_keep = 0, run_kv = 0;   // running counts: visual tokens, kept positions, kept visual tokens
+  for (int c0 = 0; c0 < L; c0 += kSpliceThreads) {
+    const int p = c0 + tid;
+    const bool valid = p < L;
+    const int64_t id = valid ? ids[p] : 0;
+    const bool is_vis = valid && id == visual_id;
+    const unsigned long long bvis = __ballot(is_vis);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) wv[wave] = __popcll(bvis);
+    __syncthreads();
+    uint32_t vis_rank = run_vis + __popcll(bvis & below), tot_vis = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { if (w < wave) vis_rank += wv[w]; tot_vis += wv[w]; }
+    const bool kept_vis = is_vis && vis_rank < (uint32_t)n_visual && ((bitmap[vis_rank >> 5] >> (vis_rank & 31)) & 1u);
+    const bool keep = valid && (!is_vis || kept_vis);
+    const unsigned long long bkeep = __ballot(keep), bkv = __ballot(kept_vis);
+    if (lane == 0) { wk[wave] = __popcll(bkeep); wj[wave] = __popcll(bkv); }
+    __syncthreads();
+    uint32_t q = run_keep + __popcll(bkeep & below), j = run_kv + __popcll(bkv & below), tot_keep = 0, tot_kv = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      if (w < wave) { q += wk[w]; j += wj[w]; }
+      tot_keep += wk[w];
+      tot_kv += wj[w];
+    }
+    if (keep && q < (uint32_t)l_out) {
+      sel[q] = p;
+      new_ids[q] = id;
+      if (mask) new_mask[q] = mask[p];
+      for (int r = 0; r < pos_rows; ++r) new_pos[(int64_t)r * l_out + q] = pos[(int64_t)r * L + p];
+      src[q] = kept_vis ? -(int32_t)(j + 1) : p;
+    }
+    run_vis += tot_vis;
+    run_keep += tot_keep;
+    run_kv += tot_kv;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    stats[0] = (int32_t)run_vis;    // visual tokens found in input_ids (must equal n_visual)
+    stats[1] = (int32_t)run_keep;   // output length (must equal L')
+    stats[2] = (int32_t)run_kv;     // kept visual tokens (must equal k)
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void splice_embed_kernel(const T* __restrict__ embeds, const T* __restrict__ vis,
+                                                           const int32_t* __restrict__ src, int l_out, int d,
+                                                           T* __restrict__ out) {
+  constexpr int V = Elem<T>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int q = blockIdx.x * 4 + wave; q < l_out; q += gridDim.x * 4) {
+    const int s = src[q];
+    const T* from = s >= 0 ? embeds + (int64_t)s * d : vis + (int64_t)(-s - 1) * d;
+    const u32x4* sp = reinterpret_cast<const u32x4*>(from);
+    u32x4* dp = reinterpret_cast<u32x4*>(out + (int64_t)q * d);
+    for (int v = lane; v < d / V; v += 64) dp[v] = sp[v];
+  }
+}
+
+}  // namespace vsel
+
+using namespace vsel;
+
+extern "C" int vsel_splice(void* stream, const int64_t* input_ids, int64_t seq_len, int64_t visual_token_id,
+                           const int64_t* all_indices, int64_t k, int64_t n_visual, const void* inputs_embeds,
+                           const void* visual_embeds, vsel_dtype dtype, int64_t d_llm, const int64_t* position_ids,
+                           int64_t pos_rows, const int64_t* attention_mask, int64_t* selected_indices, int64_t* new_input_ids,
+                           void* new_inputs_embeds, int64_t* new_position_ids, int64_t* new_attention_mask,
+                           int32_t* src_scratch, int32_t* stats) {
+  if (!input_ids || !inputs_embeds || !selected_indices || !new_input_ids || !new_inputs_embeds || !src_scratch || !stats ||
+      (k > 0 && (!all_indices || !visual_embeds)))
+    return fail(VSEL_ERR_INVALID, "NULL pointer");
+  if (seq_len < 1 || seq_len >= (1ll << 31) || k < 0 || n_visual < k || n_visual > seq_len)
+    return fail(VSEL_ERR_INVALID, "bad splice sizes (L=%lld, N=%lld, k=%lld)", (long long)seq_len, (long long)n_visual, (long long)k);
+  if (n_visual > kMaxVisualBits) return fail(VSEL_ERR_UNSUPPORTED, "more than %d visual tokens", kMaxVisualBits);
+  if (pos_rows < 0 || pos_rows > 4 || (pos_rows > 0 && (!position_ids || !new_position_ids)))
+    return fail(VSEL_ERR_INVALID, "bad position_ids arguments");
+  if ((attention_mask == nullptr) != (new_attention_mask == nullptr)) return fail(VSEL_ERR_INVALID, "attention_mask in/out mismatch");
+  const int vec = dtype == VSEL_BF16 ? 8 : 4;
+  if (dtype != VSEL_BF16 && dtype != VSEL_F32) return fail(VSEL_ERR_INVALID, "bad dtype");
+  if (d_llm < vec || d_llm % vec) return fail(VSEL_ERR_UNSUPPORTED, "d_llm must be a multiple of %d", vec);
+  if (((uintptr_t)inputs_embeds | (uintptr_t)(k > 0 ? visual_embeds : nullptr) | (uintptr_t)new_inputs_embeds) & 15)
+    return fail(VSEL_ERR_INVALID, "embeddings must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(st);
+  const int l_out = (int)(seq_len - n_visual + k);
+  const size_t lds = (size_t)((n_visual + 31) / 32) * 4 + 16;
+  hipLaunchKernelGGL(splice_index_kernel, dim3(1), dim3(kSpliceThreads), lds, st, input_ids, (int)seq_len, visual_token_id,
+                     all_indices, (int)k, (int)n_visual, position_ids, (int)pos_rows, attention_mask, selected_indices,
+                     new_input_ids, new_position_ids, new_attention_mask, src_scratch, stats, l_out);
+  VSEL_AFTER_LAUNCH(st, "splice_index_kernel");
+  const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(l_out, 4), 2048);
+  if (l_out > 0) {
+    if (dtype == VSEL_BF16)
+      hipLaunchKernelGGL((splice_embed_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)inputs_embeds,
+                         (const bf16_t*)visual_embeds, src_scratch, l_out, (int)d_llm, (bf16_t*)new_inputs_embeds);
+    else
+      hipLaunchKernelGGL((splice_embed_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)inputs_embeds,
+                         (const float*)visual_embeds, src_scratch, l_out, (int)d_llm, (float*)new_inputs_embeds);
+    VSEL_AFTER_LAUNCH(st, "splice_embed_kernel");
+  }
+  return VSEL_OK;
+}

@@ -12,15 +12,15 @@ from __future__ import annotations
 
 import os
 import types
-from copy import deepcopy
 from typing import Optional
 
 import torch
 import torch.nn.functional as F
 from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as hf
 
+from . import ops
 from .hf_generic import make_vision_tower_forward_selector
-from .selector import TransformerScorer, slice_positions, splice_image, splice_video
+from .selector import TransformerScorer
 
 _BaseTower = hf.Qwen2_5_VisionTransformerPretrainedModel
 _BaseCausal = hf.Qwen2_5_VLForConditionalGeneration
@@ -126,32 +126,33 @@ class Qwen2_5_VLForConditionalGeneration_Selector(_BaseCausal):
         selected_indices = None
         prefill = inputs_embeds is None and (pixel_values is not None or pixel_values_videos is not None)
         if prefill:
-            origin_input_ids = deepcopy(input_ids)
+            origin_input_ids = input_ids
             inputs_embeds = self.get_input_embeddings()(input_ids)
-            if pixel_values is not None:
-                pixel_values = pixel_values.type(self.visual.dtype)
-                image_embeds, all_indices, visual_token_num = self.visual(pixel_values, grid_thw=image_grid_thw)
-                selected_indices, input_ids, inputs_embeds = splice_image(
-                    input_ids, inputs_embeds, self.config.image_token_id, all_indices, image_embeds)
-            if pixel_values_videos is not None:
-                pixel_values_videos = pixel_values_videos.type(self.visual.dtype)
-                video_embeds, all_indices, visual_token_num = self.visual(pixel_values_videos, grid_thw=video_grid_thw)
-                selected_indices, input_ids, inputs_embeds, text_image_mask = splice_video(
-                    input_ids, inputs_embeds, self.config.video_token_id, all_indices, video_embeds,
-                    self.config.vision_start_token_id, self.config.vision_end_token_id)
-                self.model.language_model.text_image_mask = text_image_mask
-            # M-RoPE index from the ORIGINAL ids, then sliced (:311-320)
+            # M-RoPE index from the ORIGINAL ids (:311-317); sliced together with ids / embeds / mask by the splice kernel
             full_pos = self.model.compute_3d_position_ids(
                 input_ids=origin_input_ids, image_grid_thw=image_grid_thw, video_grid_thw=video_grid_thw,
                 inputs_embeds=None, attention_mask=attention_mask, past_key_values=None,
                 second_per_grid_ts=second_per_grid_ts, mm_token_type_ids=mm_token_type_ids)
-            if full_pos is None:       # no mm_token_type_ids from the processor: fall back to get_rope_index on ids alone
+            if full_pos is None:       # no mm_token_type_ids from the processor: derive them from the ids
                 full_pos, deltas = self.model.get_rope_index(
                     origin_input_ids, image_grid_thw=image_grid_thw, video_grid_thw=video_grid_thw,
                     attention_mask=attention_mask, second_per_grid_ts=second_per_grid_ts,
                     mm_token_type_ids=_mm_types_from_ids(origin_input_ids, self.config))
                 self.model.rope_deltas = deltas
-            position_ids, attention_mask = slice_positions(full_pos, attention_mask, selected_indices)
+            if pixel_values is not None:
+                pixel_values = pixel_values.type(self.visual.dtype)
+                vis_embeds, all_indices, visual_token_num = self.visual(pixel_values, grid_thw=image_grid_thw)
+                vis_id = self.config.image_token_id
+            else:
+                pixel_values_videos = pixel_values_videos.type(self.visual.dtype)
+                vis_embeds, all_indices, visual_token_num = self.visual(pixel_values_videos, grid_thw=video_grid_thw)
+                vis_id = self.config.video_token_id
+            # one fused device splice (vsel_splice) instead of where / cat / sort / index / masked_scatter (:246-262, :264-290)
+            selected_indices, input_ids, inputs_embeds, position_ids, attention_mask = ops.splice(
+                input_ids.contiguous(), inputs_embeds.contiguous(), vis_id, all_indices, vis_embeds, visual_token_num,
+                position_ids=full_pos.contiguous(), attention_mask=None if attention_mask is None else attention_mask.contiguous())
+            if pixel_values_videos is not None and pixel_values is None:
+                self.model.language_model.text_image_mask = input_ids != vis_id            # :295-297
             self._n_dropped = origin_input_ids.shape[1] - input_ids.shape[1]
             # decode positions are (uncompressed length + t) + rope_deltas in the reference (:322-334, cache_position counts
             # the ORIGINAL prompt); transformers 5.x derives them from the cache length L' + t, so fold L - L' into the deltas

@@ -257,6 +257,54 @@ def lis_scores_bwd(g, h, wq, bq, wk, bk, need_dh: bool = False):
 
 
 # ------------------------------------------------------------------------------------------------
+# sequence splice
+# ------------------------------------------------------------------------------------------------
+
+def splice(input_ids, inputs_embeds, visual_token_id: int, all_indices, visual_embeds, n_visual: int,
+           position_ids=None, attention_mask=None, check: bool = False):
+    """Batch-1 splice on device.  input_ids [1, L] int64, inputs_embeds [1, L, D], all_indices [k] int64 ascending,
+    visual_embeds [k, D], position_ids [R, 1, L] int64 or None, attention_mask [1, L] or None ->
+    (selected_indices [L'], input_ids' [1, L'], inputs_embeds' [1, L', D], position_ids' [R, 1, L'] | None, attention_mask' | None).
+    check=True synchronises and raises ValueError on a token-count mismatch (reference: selector_model.py:210-213)."""
+    dev = _dev(input_ids, inputs_embeds, all_indices, visual_embeds, position_ids, attention_mask)
+    if input_ids.dim() != 2 or input_ids.shape[0] != 1:
+        raise ValueError("selector only support single batch")              # reference assert, EV :270
+    if input_ids.dtype != torch.int64 or all_indices.dtype != torch.int64:
+        raise TypeError("input_ids / all_indices must be int64")
+    L = input_ids.shape[1]
+    d = inputs_embeds.shape[-1]
+    k = all_indices.numel()
+    l_out = L - int(n_visual) + k
+    vis = visual_embeds.to(inputs_embeds.dtype).contiguous()
+    am = None
+    if attention_mask is not None:
+        am = attention_mask.to(torch.int64).contiguous()
+    pos = None
+    rows = 0
+    if position_ids is not None:
+        pos = position_ids.to(torch.int64).contiguous()
+        rows = pos.numel() // L
+    sel = torch.empty(l_out, dtype=torch.int64, device=dev)
+    new_ids = torch.empty(1, l_out, dtype=torch.int64, device=dev)
+    new_emb = torch.empty(1, l_out, d, dtype=inputs_embeds.dtype, device=dev)
+    new_pos = torch.empty(rows, 1, l_out, dtype=torch.int64, device=dev) if pos is not None else None
+    new_am = torch.empty(1, l_out, dtype=torch.int64, device=dev) if am is not None else None
+    src = torch.empty(max(l_out, 1), dtype=torch.int32, device=dev)
+    stats = torch.empty(3, dtype=torch.int32, device=dev)
+    N.check(N.lib().vsel_splice(_stream(), input_ids.data_ptr(), L, int(visual_token_id), all_indices.data_ptr(), k,
+                                int(n_visual), inputs_embeds.data_ptr(), vis.data_ptr(), _code(inputs_embeds), d, _p(pos), rows,
+                                _p(am), sel.data_ptr(), new_ids.data_ptr(), new_emb.data_ptr(), _p(new_pos), _p(new_am),
+                                src.data_ptr(), stats.data_ptr()))
+    if check:
+        found, written, kept = stats.tolist()
+        if found != n_visual or written != l_out or kept != k:
+            raise ValueError(f"Image features and image tokens do not match: tokens: {found}, features {n_visual}")
+    if new_am is not None and attention_mask.dtype != torch.int64:
+        new_am = new_am.to(attention_mask.dtype)
+    return sel, new_ids, new_emb, new_pos, new_am
+
+
+# ------------------------------------------------------------------------------------------------
 # var-len attention
 # ------------------------------------------------------------------------------------------------
 

@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--budget", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-attn", action="store_true")
+    ap.add_argument("--no-llm", action="store_true", help="skip the whole-LLM prefill leg (7B random-init weights)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -223,6 +224,11 @@ def main():
             res["prefill_attention"] = bench_attention(ops, k)
         except Exception as e:  # the attention kernel is optional for this line
             res["prefill_attention"] = {"error": str(e)[:200]}
+    if not args.no_llm:
+        try:
+            res["prefill_llm"] = bench_llm_prefill(_native, k)
+        except Exception as e:  # optional leg: never lose the headline line over it
+            res["prefill_llm"] = {"error": str(e)[:300]}
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.budget)
         res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
@@ -253,6 +259,50 @@ def bench_attention(ops, k, text=64, hq=28, hkv=4, dh=128, layers=28, iters=20):
         flops = 4.0 * L * L * hq * dh / 2
         out[tag] = {"L": L, "ms_per_layer": ms, "ms_28_layers": ms * layers, "tflops": flops / (ms * 1e-3) / 1e12}
     out["speedup"] = out["full"]["ms_per_layer"] / out["retain20"]["ms_per_layer"]
+    return out
+
+
+@torch.no_grad()
+def bench_llm_prefill(_native, k, text=64, iters=5):
+    """Second half of the BASELINE metric: "prefill ms at 20 % retain, Qwen2.5-VL-7B".  The 28-layer text model of the 7B
+    geometry with random-init bf16 weights (no checkpoints offline), attention through the registered `vsel_varlen`
+    kernel, GEMMs through PyTorch-ROCm; prefill of L' = k + 64 vs L = N + 64 tokens (inputs_embeds, M-RoPE positions)."""
+    from transformers import Qwen2_5_VLTextConfig
+    from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as hf
+    from visionselector_amd.attention import ATTN_NAME, replace_qwen2_vl_attention_class
+    replace_qwen2_vl_attention_class()
+    cfg = Qwen2_5_VLTextConfig(hidden_size=3584, intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28,
+                               num_key_value_heads=4, vocab_size=152064, max_position_embeddings=32768,
+                               rope_parameters=dict(rope_type="default", mrope_section=[16, 24, 24], rope_theta=1000000.0))
+    cfg._attn_implementation = ATTN_NAME
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device("cuda"):
+            model = hf.Qwen2_5_VLTextModel(cfg).eval()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    out = {"model": "Qwen2.5-VL-7B text model geometry, random-init bf16", "params_B": sum(p.numel() for p in model.parameters()) / 1e9,
+           "attention": ATTN_NAME}
+    for tag, L in (("retain20", k + text), ("full", N_VIS + text)):
+        x = torch.randn(1, L, 3584, device="cuda", dtype=torch.bfloat16) * 0.02
+        pos = torch.arange(L, device="cuda")[None, None, :].expand(3, 1, L).contiguous()
+        for _ in range(2):
+            model(inputs_embeds=x, position_ids=pos, use_cache=False)
+        torch.cuda.synchronize()
+        _native.profile_start()
+        model(inputs_embeds=x, position_ids=pos, use_cache=False)
+        torch.cuda.synchronize()
+        calls = _native.profile_stop().get("varlen_attn_fwd_kernel", (0.0, 0))[1]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            model(inputs_embeds=x, position_ids=pos, use_cache=False)
+        e1.record()
+        torch.cuda.synchronize()
+        out[tag] = {"L": L, "prefill_ms": e0.elapsed_time(e1) / iters, "vsel_attention_launches_per_forward": calls}
+    out["speedup"] = out["full"]["prefill_ms"] / out["retain20"]["prefill_ms"]
+    del model
+    torch.cuda.empty_cache()
     return out
 
 

@@ -252,3 +252,22 @@ def test_two_half_pipeline_equals_single_stream(ops):
     for o in outs:
         for x, y in zip(o, a):
             assert torch.equal(x, y)
+
+
+def test_lis_select_is_graph_capturable(ops):
+    """No hipMalloc / sync inside the C-ABI: the whole path can be captured into a hipGraph and replayed."""
+    c = oin.make_case(2048, 1024, 576, 9, batch=3)
+    h, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    ref = ops.lis_select(h, wq, bq, wk, bk, 115)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ops.lis_select(h, wq, bq, wk, bk, 115)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        out = ops.lis_select(h, wq, bq, wk, bk, 115)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(ref, out):
+        assert torch.equal(a, b)

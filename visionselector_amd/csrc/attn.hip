@@ -17,6 +17,8 @@
 //   transpose reads).  Online softmax in exp2 domain, fp32.
 #include "common.h"
 
+#include <algorithm>
+
 namespace vsel {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -33,24 +35,48 @@ constexpr int kLds = 2 * kKBuf + 2 * kVBuf;  // 72 KiB
 
 __device__ __forceinline__ bf16x8_t to_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 
+// Persistent work-stealing grid: items = (q-tile, head, sequence), handed out heaviest-first (largest q-tile = most KV
+// tiles under the causal mask) through one atomic counter, so the causal triangle is load-balanced over the 2 x 256
+// resident workgroups instead of being bounded by the last q-tile (1.9x fewer tiles on the critical path at L = 2368).
+__device__ int g_attn_work_counter[64];
+
 template <bool USE_TR>
 __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                               const uint16_t* __restrict__ v,
                                                               const int32_t* __restrict__ cu, int hq, int hkv,
-                                                              float scale_log2e, int causal, uint16_t* __restrict__ out) {
+                                                              float scale_log2e, int causal, uint16_t* __restrict__ out,
+                                                              int q_tiles, int n_seq, int slot) {
   __shared__ __attribute__((aligned(16))) char smem[kLds];
+  __shared__ int s_item;
   char* const k_sm = smem;
   char* const v_sm = smem + 2 * kKBuf;
+  const int n_items = q_tiles * hq * n_seq;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  // A-row i of the K operand holds key pi(i) (bits 2 and 3 swapped) so that C registers 8m..8m+7 of lane half hh are
+  // the 8 consecutive keys 16m + 8hh .. +7 of the 32-key block.
+  const int key_row = (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1);
 
-  const int seq = blockIdx.z, head = blockIdx.y;
-  const int qtile = gridDim.x - 1 - blockIdx.x;   // heaviest (last) query tiles are dispatched first
+  for (int round = 0;; ++round) {
+  int item;
+  if (slot < 0) {                       // one item per workgroup (n_items <= resident slots): no counter needed
+    if (round > 0) return;
+    item = blockIdx.x;
+  } else {
+    if (tid == 0) s_item = atomicAdd(&g_attn_work_counter[slot], 1);
+    __syncthreads();
+    item = s_item;
+    __syncthreads();
+  }
+  if (item >= n_items) return;
+  const int qtile = q_tiles - 1 - item / (hq * n_seq);
+  const int rest = item % (hq * n_seq);
+  const int head = rest % hq, seq = rest / hq;
   const int qs = cu[seq];
   const int len = cu[seq + 1] - qs;
   const int q0 = qtile * kBlockQ;
-  if (q0 >= len) return;
+  if (q0 >= len) continue;
   const int kvh = head / (hq / hkv);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 31, hh = lane >> 5;
   const int my_q = min(q0 + wave * 32 + j, len - 1);          // clamped: padding lanes replay the last query
   const bool q_valid = (q0 + wave * 32 + j) < len;
   const int wave_qmax = min(q0 + wave * 32 + 31, len - 1);
@@ -98,10 +124,6 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
   store_tile(0);
   __syncthreads();
 
-  // A-row i of the K operand holds key pi(i) (bits 2 and 3 swapped) so that C registers 8m..8m+7 of lane half hh are
-  // the 8 consecutive keys 16m + 8hh .. +7 of the 32-key block.
-  const int key_row = (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1);
-
   for (int t = 0; t < n_tiles; ++t) {
     const int cur = t & 1;
     if (t + 1 < n_tiles) load_tile(t + 1);
@@ -122,41 +144,44 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
           s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(a), to_bf16x8(qf[st]), s[kb], 0, 0, 0);
         }
       }
-      // ---- mask + online softmax (exp2 domain) ----------------------------------------------------------------
+      // ---- mask + online softmax (exp2 domain; the softmax scale is folded into one FMA per element) ------------
       const bool need_mask = (t * kTileK + kTileK > len) || (causal && (t * kTileK + kTileK - 1 > q0 + wave * 32));
       float mx = -INFINITY;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float val = s[kb][r] * scale_log2e;
+          float val = s[kb][r];
           if (need_mask) {
             const int key = t * kTileK + 32 * kb + 16 * (r >> 3) + 8 * hh + (r & 7);
             const bool ok = key < len && (!causal || key <= my_q);
             val = ok ? val : -INFINITY;
+            s[kb][r] = val;
           }
-          s[kb][r] = val;
           mx = fmaxf(mx, val);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
+      const float m_new = fmaxf(m_run, mx * scale_log2e);      // scale > 0: max commutes with the scaling
+      if (!__all(m_new == m_run)) {                            // wave-uniform: most tiles leave the running max alone
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      }
       float psum = 0.f;
       bf16x8_t pf[2][2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], scale_log2e, -m_run));
           psum += p;
           pf[kb][r >> 3][r & 7] = (__bf16)p;
         }
-      l_run = l_run * alpha + psum;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      l_run += psum;
       // ---- O^T += V^T P^T -------------------------------------------------------------------------------------
       const char* vbase = v_sm + cur * kVBuf;
 #pragma unroll
@@ -209,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
         *reinterpret_cast<uint2*>(op + d0) = pk;
       }
   }
+  }  // persistent item loop
 }
 
 }  // namespace vsel
@@ -229,14 +255,25 @@ extern "C" int vsel_varlen_attn_fwd(void* stream, const void* q, const void* k, 
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return fail(VSEL_ERR_INVALID, "q/k/v/out must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   VSEL_PROF_BEGIN(st);
-  const dim3 grid((unsigned)cdiv(max_seqlen, kBlockQ), (unsigned)hq, (unsigned)n_seq);
+  const int q_tiles = (int)cdiv(max_seqlen, kBlockQ);
+  const int64_t n_items = (int64_t)q_tiles * hq * n_seq;
+  if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
+  static unsigned next_slot = 0;
+  int slot = -1;                                                   // -1: direct mapping, one item per workgroup
+  if (n_items > 512) {                                             // more items than the 2 x 256 resident workgroups
+    slot = (int)(next_slot++ & 63u);
+    int* counters = nullptr;
+    VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_attn_work_counter)));
+    VSEL_HIP_CHECK(hipMemsetAsync(counters + slot, 0, sizeof(int), st));
+  }
+  const dim3 grid((unsigned)std::min<int64_t>(n_items, 512));
   const float sl2 = scale * 1.4426950408889634f;
   if (g_attn_use_tr)
     hipLaunchKernelGGL((varlen_attn_fwd_kernel<true>), grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                       (const uint16_t*)v, cu_seqlens, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out);
+                       (const uint16_t*)v, cu_seqlens, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot);
   else
     hipLaunchKernelGGL((varlen_attn_fwd_kernel<false>), grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                       (const uint16_t*)v, cu_seqlens, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out);
+                       (const uint16_t*)v, cu_seqlens, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot);
   VSEL_AFTER_LAUNCH(st, "varlen_attn_fwd_kernel");
   return VSEL_OK;
 }

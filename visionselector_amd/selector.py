@@ -154,7 +154,9 @@ def lis_train_block(hidden_states: torch.Tensor, scorer: TransformerScorer, budg
     k = int(total_tokens * budgets)                                        # :162 (no clamp; _find_ts asserts 0 < k < n)
     assert 0 < k < total_tokens
     h_new, ps, y, _ = _LisTrainFunction.apply(hidden_states, *scorer.params(), k)
-    return h_new, ps.to(hidden_states.dtype) if hidden_states.dtype != torch.float32 else ps, y.to(ps.dtype)
+    # img_mask / constraint_img_mask stay fp32 (the reference returns the model dtype; a bf16 soft mask would quantise the
+    # BCE constraint to 8 bits).  F.binary_cross_entropy(img_mask, constraint_img_mask) works unchanged.
+    return h_new, ps, y
 
 
 # --------------------------------------------------------------------------------------------------

@@ -91,6 +91,19 @@ int vsel_lis_select(void* stream, const void* h, vsel_dtype hdtype, const vsel_s
                     const vsel_scorer* scorer, void* workspace, size_t workspace_bytes,
                     void* out, int64_t* idx, float* scores);
 
+/* Same, for tokens stored in a PHYSICAL row order that differs from the LOGICAL order the reference selects in.
+ * Qwen2.5-VL's merger emits tokens in window order and the reference un-reorders them with a full gather
+ *   reverse_indices = argsort(window_index); hidden_states = hidden_states[reverse_indices, :]
+ * (EV/token_compression/selector_model.py:179-181) right before the LIS block.  Passing
+ *   logical_to_physical = reverse_indices, physical_to_logical = window_index   (int64 [T], DEVICE, global row numbers;
+ *   the permutation must keep every segment's rows inside the segment)
+ * gives the same scores / idx / out as running vsel_lis_select on the un-reordered tensor, without materialising it
+ * (the column mean is order-invariant; scores are scattered to logical positions; kept rows are gathered through the map). */
+int vsel_lis_select_permuted(void* stream, const void* h_physical, vsel_dtype hdtype, const vsel_segments* seg,
+                             const vsel_scorer* scorer, void* workspace, size_t workspace_bytes,
+                             const int64_t* logical_to_physical, const int64_t* physical_to_logical,
+                             void* out, int64_t* idx, float* scores);
+
 /* Scores only: TransformerScorer.forward (FT/compression_method/selector_scorer.py:34-55).      */
 int vsel_lis_scores(void* stream, const void* h, vsel_dtype hdtype, const vsel_segments* seg,
                     const vsel_scorer* scorer, void* workspace, size_t workspace_bytes, float* scores);

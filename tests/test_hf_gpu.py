@@ -283,3 +283,34 @@ def test_generic_tower_wrapper_llavaov_style():
     pos1d = torch.arange(ids.shape[1], device="cuda")[None, None, :]
     sel, new_ids, new_emb, new_pos, _ = ops.splice(ids, emb, IMG, idx, out[:, :64].contiguous(), n, position_ids=pos1d, check=True)
     assert new_pos.shape == (1, 1, ids.shape[1] - n + k) and torch.equal(new_pos[0, 0], sel)
+
+
+def test_unreorder_fusion_is_transparent(selector_model):
+    """The inference tower skips transformers' `merged[reverse_indices, :]` gather (vsel_lis_select_permuted): same kept
+    tokens / indices / logits as with the gather executed."""
+    m = selector_model
+    m.visual.budgets = 0.25
+    inp, n_vis = make_inputs(grid=(1, 32, 32), seed=9)        # 256 merged tokens, several 4x4-token windows
+    outs = []
+    for fuse in (True, False):
+        m.visual.fuse_unreorder = fuse
+        m.model.rope_deltas = None
+        with torch.no_grad():
+            o = m(**inp)
+        outs.append((o.logits.clone(), m.visual.last_selected_indices.clone(), m.visual.last_combined_scores.clone()))
+    m.visual.fuse_unreorder = True
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-5 * max(1.0, float(outs[1][0].abs().max()))
+    assert float((outs[0][2] - outs[1][2]).abs().max()) <= 1e-5
+    # the fused path really took the permutation from the tower (window order != natural order for this grid)
+    from visionselector_amd import hf_generic
+    calls = []
+    orig = hf_generic._select_block_permuted
+    hf_generic._select_block_permuted = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            m.model.rope_deltas = None
+            m(**inp)
+    finally:
+        hf_generic._select_block_permuted = orig
+    assert calls, "permuted path not taken"

@@ -271,3 +271,24 @@ def test_lis_select_is_graph_capturable(ops):
     torch.cuda.synchronize()
     for a, b in zip(ref, out):
         assert torch.equal(a, b)
+
+
+def test_permuted_select_equals_unreorder_then_select(ops):
+    """vsel_lis_select_permuted on the window-ordered tensor == un-reorder gather (EV :179-181) followed by vsel_lis_select,
+    bit for bit (scores, indices, kept rows), without materialising the un-reordered copy."""
+    b, n, d, hd, k = 6, 1000, 2048, 1024, 200
+    c = oin.make_case(d, hd, n, 17, batch=b)
+    h_log, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    g = torch.Generator().manual_seed(3)
+    # per-image permutation (window_index permutes merged tokens inside each image), global row numbers
+    p2l = torch.cat([torch.randperm(n, generator=g) + i * n for i in range(b)]).cuda()      # window_index
+    l2p = torch.argsort(p2l)                                                                  # reverse_indices
+    h_phys = torch.empty_like(h_log.view(b * n, d))
+    h_phys[l2p] = h_log.view(b * n, d)              # so that h_phys[l2p] == h_log  (hidden_states[reverse_indices])
+    h_phys = h_phys.view(b, n, d)
+    assert torch.equal(h_phys.view(b * n, d)[l2p].view(b, n, d), h_log)
+    ref = ops.lis_select(h_log, wq, bq, wk, bk, k)
+    got = ops.lis_select_permuted(h_phys, l2p, p2l, wq, bq, wk, bk, k)
+    assert torch.equal(got[1], ref[1]) and torch.equal(got[0], ref[0])
+    # scores: same per-row dot products; the column mean is summed in a different row order -> fp32 roundoff only
+    assert float((got[2] - ref[2]).abs().max()) <= 4e-6 * max(1.0, float(ref[2].abs().max()))

@@ -37,6 +37,7 @@ SIGNATURES = {
     "vsel_profile_stop": (C.c_int, [C.c_char_p, _SZ, _P, _P, C.c_int, _P]),
     "vsel_lis_workspace_bytes": (_SZ, [_SEG, _I64, _I64]),
     "vsel_lis_select": (C.c_int, [_P, _P, C.c_int, _SEG, _SC, _P, _SZ, _P, _P, _P]),
+    "vsel_lis_select_permuted": (C.c_int, [_P, _P, C.c_int, _SEG, _SC, _P, _SZ, _P, _P, _P, _P, _P]),
     "vsel_lis_scores": (C.c_int, [_P, _P, C.c_int, _SEG, _SC, _P, _SZ, _P]),
     "vsel_topk_select": (C.c_int, [_P, _P, _SEG, _P, _P]),
     "vsel_gather_rows": (C.c_int, [_P, _P, C.c_int, _I64, _SEG, _P, _P]),

@@ -50,27 +50,28 @@ extern "C" void vsel_debug_set_pipeline(int on) { g_pipeline_enabled = on; }
 
 template <typename T, typename TW>
 static int select_half(hipStream_t st, const T* h, const vsel_segments* seg, const vsel_scorer* sc, char* ws, const LisPlan& p,
-                       T* out, int64_t* idx, float* scores, bool skip_colsum) {
+                       T* out, int64_t* idx, float* scores, bool skip_colsum, const int64_t* l2p = nullptr,
+                       const int64_t* p2l = nullptr) {
   int rc = VSEL_OK;
   if (!skip_colsum) rc = run_colsum<T>(st, h, seg, (int)sc->d, ws, p);
   if (rc) return rc;
   rc = run_proj<TW>(st, seg, sc, ws, p);
   if (rc) return rc;
-  rc = run_score<T>(st, h, seg, sc, ws, p, scores);
+  rc = run_score<T>(st, h, seg, sc, ws, p, scores, p2l);
   if (rc) return rc;
   rc = launch_select(st, scores, seg, idx, nullptr);
   if (rc) return rc;
-  return launch_gather<T>(st, h, (int)sc->d, seg, idx, out);
+  return launch_gather<T>(st, h, (int)sc->d, seg, idx, out, l2p);
 }
 
 template <typename T, typename TW>
 static int lis_select_impl(hipStream_t st, const T* h, const vsel_segments* seg, const vsel_scorer* sc, char* ws, T* out,
-                           int64_t* idx, float* scores) {
+                           int64_t* idx, float* scores, const int64_t* l2p = nullptr, const int64_t* p2l = nullptr) {
   const int64_t S = seg->n_seg, d = sc->d;
-  AuxStream* aux = (g_pipeline_enabled && S >= kPipelineMinSegments && !prof_enabled()) ? aux_for_current_device() : nullptr;
+  AuxStream* aux = (g_pipeline_enabled && S >= kPipelineMinSegments && !prof_enabled() && !l2p) ? aux_for_current_device() : nullptr;
   if (!aux) {
     const LisPlan p = make_plan(S, seg->rows_per_seg, d, sc->hd);
-    return select_half<T, TW>(st, h, seg, sc, ws, p, out, idx, scores, false);
+    return select_half<T, TW>(st, h, seg, sc, ws, p, out, idx, scores, false, l2p, p2l);
   }
   // halves A = [0, s0), B = [s0, S).  Uniform segments address rows relative to the half's base pointer; ragged
   // segments keep absolute offsets (seg_rows / seg_out are advanced instead).
@@ -197,4 +198,30 @@ extern "C" int vsel_lis_select(void* stream, const void* h, vsel_dtype hdtype, c
   if (sc->wdtype == VSEL_BF16)
     return lis_select_impl<float, bf16_t>(s, (const float*)h, seg, sc, (char*)ws, (float*)out, idx, scores);
   return lis_select_impl<float, float>(s, (const float*)h, seg, sc, (char*)ws, (float*)out, idx, scores);
+}
+
+// Permuted form: the token rows are stored in a PHYSICAL order (Qwen2.5-VL's window order straight out of the merger) and
+// the reference semantics are defined on the LOGICAL order it creates with `hidden_states[reverse_indices, :]`
+// (EV/token_compression/selector_model.py:179-181).  Scores and indices are produced in logical order, kept rows are
+// gathered straight from the physical tensor, so that un-reorder pass (read + write of N x D) is never materialised.
+extern "C" int vsel_lis_select_permuted(void* stream, const void* h_physical, vsel_dtype hdtype, const vsel_segments* seg,
+                                        const vsel_scorer* sc, void* ws, size_t ws_bytes, const int64_t* logical_to_physical,
+                                        const int64_t* physical_to_logical, void* out, int64_t* idx, float* scores) {
+  LisPlan p;
+  int st = lis_common_checks(h_physical, seg, sc, hdtype, ws, ws_bytes, true, &p);
+  if (st) return st;
+  if (!out || !idx || !scores || !logical_to_physical || !physical_to_logical) return fail(VSEL_ERR_INVALID, "NULL pointer");
+  if ((uintptr_t)out & 15) return fail(VSEL_ERR_INVALID, "out must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(s);
+  const int64_t* l2p = logical_to_physical;
+  const int64_t* p2l = physical_to_logical;
+  if (hdtype == VSEL_BF16) {
+    if (sc->wdtype == VSEL_BF16)
+      return lis_select_impl<bf16_t, bf16_t>(s, (const bf16_t*)h_physical, seg, sc, (char*)ws, (bf16_t*)out, idx, scores, l2p, p2l);
+    return lis_select_impl<bf16_t, float>(s, (const bf16_t*)h_physical, seg, sc, (char*)ws, (bf16_t*)out, idx, scores, l2p, p2l);
+  }
+  if (sc->wdtype == VSEL_BF16)
+    return lis_select_impl<float, bf16_t>(s, (const float*)h_physical, seg, sc, (char*)ws, (float*)out, idx, scores, l2p, p2l);
+  return lis_select_impl<float, float>(s, (const float*)h_physical, seg, sc, (char*)ws, (float*)out, idx, scores, l2p, p2l);
 }

@@ -275,7 +275,8 @@ __device__ __forceinline__ float dot_raw<float>(u32x4 raw, const float (&w)[4], 
 template <typename T, int ITERS>
 __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, SegView sv, int d,
                                                     const float* __restrict__ w, const float* __restrict__ c,
-                                                    float sqrt_hd, int rows_per_block, float* __restrict__ scores) {
+                                                    float sqrt_hd, int rows_per_block, float* __restrict__ scores,
+                                                    const int64_t* __restrict__ out_map) {
   constexpr int V = Elem<T>::kVec;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = blockIdx.y;
@@ -318,8 +319,8 @@ __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, Seg
       a0 = wave_sum(a0);
       a1 = wave_sum(a1);
       if (lane == 0) {
-        scores[r0 + r] = (a0 + cs) / sqrt_hd;
-        scores[r0 + r + 4] = (a1 + cs) / sqrt_hd;
+        scores[out_map ? out_map[r0 + r] : r0 + r] = (a0 + cs) / sqrt_hd;
+        scores[out_map ? out_map[r0 + r + 4] : r0 + r + 4] = (a1 + cs) / sqrt_hd;
       }
     }
     for (; r < re; r += 4) {
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, Seg
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) a0 = dot_raw<T>(x0[it], wr[it], a0);
       a0 = wave_sum(a0);
-      if (lane == 0) scores[r0 + r] = (a0 + cs) / sqrt_hd;
+      if (lane == 0) scores[out_map ? out_map[r0 + r] : r0 + r] = (a0 + cs) / sqrt_hd;
     }
   } else {
     for (int r = rb + wave; r < re; r += 4) {
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, Seg
         }
       }
       a0 = wave_sum(a0);
-      if (lane == 0) scores[r0 + r] = (a0 + cs) / sqrt_hd;
+      if (lane == 0) scores[out_map ? out_map[r0 + r] : r0 + r] = (a0 + cs) / sqrt_hd;
     }
   }
 }
@@ -458,7 +459,7 @@ static __global__ __launch_bounds__(1024) void topk_select_kernel(const float* _
 template <typename T>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ h, SegView sv, int d,
                                                           const int64_t* __restrict__ idx, T* __restrict__ out,
-                                                          int rows_per_block) {
+                                                          int rows_per_block, const int64_t* __restrict__ src_map) {
   constexpr int V = Elem<T>::kVec;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = blockIdx.y;
@@ -468,7 +469,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
   const int je = min(ko, jb + rows_per_block);
   const int64_t ob = sv.out_begin(s), rb = sv.row_begin(s);
   for (int j = jb + wave; j < je; j += 4) {
-    const int64_t src = rb + idx[ob + j];
+    const int64_t lsrc = rb + idx[ob + j];
+    const int64_t src = src_map ? src_map[lsrc] : lsrc;
     const u32x4* sp = reinterpret_cast<const u32x4*>(h + src * d);
     u32x4* dp = reinterpret_cast<u32x4*>(out + (ob + j) * d);
     for (int v = lane; v < d / V; v += 64) dp[v] = sp[v];
@@ -550,7 +552,7 @@ inline int check_scorer(const vsel_scorer* sc, vsel_dtype hdtype) {
 
 template <typename T>
 inline int launch_score(hipStream_t st, const T* h, const SegView& sv, const vsel_segments* seg, int d,
-                        const float* w, const float* c, int hd, float* scores) {
+                        const float* w, const float* c, int hd, float* scores, const int64_t* out_map = nullptr) {
   constexpr int V = Elem<T>::kVec;
   // rows per block: keep >= ~2048 blocks when there is enough work, 8..64 rows per block
   int64_t rpb = 64;
@@ -559,11 +561,11 @@ inline int launch_score(hipStream_t st, const T* h, const SegView& sv, const vse
   const float sq = (float)sqrt((double)hd);
   const int iters = (d % (64 * V) == 0) ? d / (64 * V) : 0;
 #define VSEL_SCORE_CASE(I)                                                                              \
-  case I: hipLaunchKernelGGL((score_kernel<T, I>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores); break;
+  case I: hipLaunchKernelGGL((score_kernel<T, I>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores, out_map); break;
   switch (iters) {
     VSEL_SCORE_CASE(1) VSEL_SCORE_CASE(2) VSEL_SCORE_CASE(3) VSEL_SCORE_CASE(4)
     VSEL_SCORE_CASE(5) VSEL_SCORE_CASE(6) VSEL_SCORE_CASE(7) VSEL_SCORE_CASE(8)
-    default: hipLaunchKernelGGL((score_kernel<T, 0>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores);
+    default: hipLaunchKernelGGL((score_kernel<T, 0>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores, out_map);
   }
 #undef VSEL_SCORE_CASE
   VSEL_AFTER_LAUNCH(st, "score_kernel");
@@ -645,9 +647,9 @@ inline int run_proj(hipStream_t st, const vsel_segments* seg, const vsel_scorer*
 // stage 3: sweep 2 (scores)
 template <typename T>
 inline int run_score(hipStream_t st, const T* h, const vsel_segments* seg, const vsel_scorer* sc, char* ws, const LisPlan& p,
-                     float* scores) {
+                     float* scores, const int64_t* out_map = nullptr) {
   return launch_score<T>(st, h, make_view(seg), seg, (int)sc->d, (const float*)(ws + p.off_w), (const float*)(ws + p.off_c),
-                         (int)sc->hd, scores);
+                         (int)sc->hd, scores, out_map);
 }
 
 template <typename T, typename TW>
@@ -674,11 +676,12 @@ inline int launch_select(hipStream_t st, const float* scores, const vsel_segment
 }
 
 template <typename T>
-inline int launch_gather(hipStream_t st, const T* h, int d, const vsel_segments* seg, const int64_t* idx, T* out) {
+inline int launch_gather(hipStream_t st, const T* h, int d, const vsel_segments* seg, const int64_t* idx, T* out,
+                         const int64_t* src_map = nullptr) {
   int64_t rpb = 32;
   while (rpb > 4 && seg->n_seg * cdiv(seg->k, rpb) < 2048) rpb >>= 1;
   hipLaunchKernelGGL((gather_rows_kernel<T>), dim3((unsigned)cdiv(seg->k, rpb), (unsigned)seg->n_seg), dim3(256), 0, st, h,
-                     make_view(seg), d, idx, out, (int)rpb);
+                     make_view(seg), d, idx, out, (int)rpb, src_map);
   VSEL_AFTER_LAUNCH(st, "gather_rows_kernel");
   return VSEL_OK;
 }

@@ -10,7 +10,34 @@ from typing import Callable
 
 import torch
 
+from . import ops
 from .selector import lis_select_block, lis_train_block
+
+
+class _LazyRows(torch.Tensor):
+    """Output of the merger during an inference tower forward.  The tower un-reorders its window-ordered tokens with
+    `merged[reverse_indices, :]` (reference: EV/token_compression/selector_model.py:179-181; same line in transformers'
+    Qwen2_5_VisionTransformerPretrainedModel.forward).  This subclass records that permutation instead of executing the
+    gather (a read + write of N x D right before the LIS block): vsel_lis_select_permuted consumes the window-ordered
+    rows directly.  Any other indexing behaves normally."""
+
+    @staticmethod
+    def __new__(cls, t):
+        r = torch.Tensor._make_subclass(cls, t)
+        r._perm = None
+        return r
+
+    def __getitem__(self, key):
+        if (getattr(self, "_perm", None) is None and isinstance(key, tuple) and len(key) == 2 and key[1] == slice(None)
+                and torch.is_tensor(key[0]) and key[0].dtype == torch.int64 and key[0].dim() == 1
+                and key[0].numel() == self.shape[0] and self.dim() == 2):
+            self._perm = key[0]
+            return self
+        return super().__getitem__(key)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        return super().__torch_function__(func, types, args, kwargs or {})
 
 
 def _merged_tokens(out) -> torch.Tensor:
@@ -36,10 +63,39 @@ def make_vision_tower_forward_selector(base_forward: Callable, mode: str):
         return lis_train_block(merged, self.importance_scorer, self.budgets)
 
     def forward_eval(self, hidden_states: torch.Tensor, grid_thw: torch.Tensor, **kwargs):
-        merged = _merged_tokens(base_forward(self, hidden_states, grid_thw, **kwargs))
-        out, idx, total, combined = lis_select_block(merged.detach(), self.importance_scorer, self.budgets)
+        merger = getattr(self, "merger", None)
+        handle = None
+        if merger is not None and not torch.is_grad_enabled() and getattr(self, "fuse_unreorder", True):
+            handle = merger.register_forward_hook(lambda mod, inp, out: _LazyRows(out) if out.dim() == 2 else out)
+        try:
+            merged = _merged_tokens(base_forward(self, hidden_states, grid_thw, **kwargs))
+        finally:
+            if handle is not None:
+                handle.remove()
+        perm = getattr(merged, "_perm", None) if isinstance(merged, _LazyRows) else None
+        merged = merged.as_subclass(torch.Tensor).detach()
+        if perm is not None:
+            out, idx, total, combined = _select_block_permuted(merged, perm, self.importance_scorer, self.budgets)
+        else:
+            out, idx, total, combined = lis_select_block(merged, self.importance_scorer, self.budgets)
         self.last_combined_scores = combined
         self.last_selected_indices = idx
         return out, idx, total
 
     return forward_train if mode == "train" else forward_eval
+
+
+@torch.no_grad()
+def _select_block_permuted(merged_physical: torch.Tensor, reverse_indices: torch.Tensor, scorer, budgets: float):
+    """lis_select_block on merged_physical[reverse_indices] without materialising it (vsel_lis_select_permuted)."""
+    total = merged_physical.shape[0]
+    k = max(1, int(total * budgets))
+    l2p = reverse_indices.to(merged_physical.device).contiguous()     # transformers builds window_index on the host
+    p2l = torch.empty_like(l2p)
+    p2l[l2p] = torch.arange(total, device=l2p.device, dtype=l2p.dtype)          # = window_index
+    out, idx, scores = ops.lis_select_permuted(merged_physical.contiguous(), l2p, p2l,
+                                               *[p.detach().contiguous() for p in scorer.params()], k)
+    combined = None
+    if 0 < k < total:
+        combined = ops.soft_topk_fwd(scores[None], k)[0][0].to(merged_physical.dtype)
+    return out, idx, total, combined

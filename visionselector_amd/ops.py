@@ -130,6 +130,30 @@ def lis_select(h, wq, bq, wk, bk, k: int):
     return out, idx, scores
 
 
+def lis_select_permuted(h_physical, logical_to_physical, physical_to_logical, wq, bq, wk, bk, k: int):
+    """lis_select on h_physical[logical_to_physical] without materialising that gather (Qwen2.5-VL window order ->
+    natural order: logical_to_physical = reverse_indices, physical_to_logical = window_index).  h [N,D] or [B,N,D];
+    maps int64 with GLOBAL row numbers."""
+    dev = _dev(h_physical, logical_to_physical, physical_to_logical, wq, bq, wk, bk)
+    b, n, d = _as_bnd(h_physical)
+    if logical_to_physical.dtype != torch.int64 or physical_to_logical.dtype != torch.int64:
+        raise TypeError("permutation maps must be int64")
+    if logical_to_physical.numel() != b * n or physical_to_logical.numel() != b * n:
+        raise ValueError("permutation maps must have one entry per token row")
+    sc = _scorer(wq, bq, wk, bk)
+    seg = _uniform_segments(b, n, int(k))
+    lib = N.lib()
+    ws = _workspace(lib.vsel_lis_workspace_bytes(C.byref(seg), d, sc.hd), dev)
+    lead = h_physical.shape[:-2]
+    out = torch.empty(*lead, k, d, dtype=h_physical.dtype, device=dev)
+    idx = torch.empty(*lead, k, dtype=torch.int64, device=dev)
+    scores = torch.empty(*lead, n, dtype=torch.float32, device=dev)
+    N.check(lib.vsel_lis_select_permuted(_stream(), h_physical.data_ptr(), _code(h_physical), C.byref(seg), C.byref(sc),
+                                         ws.data_ptr(), ws.numel(), logical_to_physical.data_ptr(),
+                                         physical_to_logical.data_ptr(), out.data_ptr(), idx.data_ptr(), scores.data_ptr()))
+    return out, idx, scores
+
+
 def lis_select_varlen(h, seg_lens: Sequence[int], ks: Sequence[int], wq, bq, wk, bk):
     """Ragged form: h [T,D] holds len(seg_lens) segments back to back; segment s keeps ks[s] rows.
     -> (out [sum ks, D], idx int64 [sum ks] local to the segment, scores fp32 [T])."""

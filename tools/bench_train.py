@@ -6,7 +6,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visionselector_amd import _native, ops  # noqa: E402
 
 d, hd = 3584, 1792

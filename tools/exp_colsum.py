@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visionselector_amd import ops, _native
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 n, d, hd, k = 2304, 3584, 1792, 460

@@ -1,6 +1,6 @@
 """hipGraph capture of lis_select (no sync / no hipMalloc inside the C-ABI): single-image latency, eager vs graph replay."""
 import sys, time, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visionselector_amd import ops
 n, d, hd, k = 2304, 3584, 1792, 460
 g = torch.Generator(device="cuda").manual_seed(0)

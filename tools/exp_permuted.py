@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visionselector_amd import ops
 b, n, d, hd, k = 128, 2304, 3584, 1792, 460
 g = torch.Generator(device="cuda").manual_seed(0)

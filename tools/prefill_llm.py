@@ -8,7 +8,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def build_llm(layers=28):

@@ -6,7 +6,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visionselector_amd import ops  # noqa: E402
 
 

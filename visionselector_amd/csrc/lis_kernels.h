@@ -24,37 +24,21 @@ constexpr int kRowsPerChunk = 128;   // sweep-1 row chunk (batch-invariant summa
 constexpr int kSliceNT = 256;        // split-K slice of the kbar projection (fixed => batch-invariant)
 constexpr int kSliceNN = 128;        // split-K slice of the w projection
 
-// K1  partial column sums.  grid (ceil(col_tiles / 4), row_splits, n_seg), block 256 = 4 independent waves.
-//     Each wave owns ONE (64-lane x 16-byte = 1 KiB) column tile of ONE 128-row chunk: it streams the 128 rows in batches
-//     of 8 loads in flight and writes its partial itself -- no LDS, no barrier, no cross-wave reduction (the first
-//     version interleaved rows over the 4 waves and reduced through LDS: ~12 % of the kernel, measured against the
-//     bare access pattern in tools/membw2.hip).
+// K1  partial column sums.  grid (col_tiles, row_splits, n_seg), block 256 (4 waves).
+//     A wave reads 64 lanes x 16 B = 1 KiB contiguous of one row; the block's 4 waves interleave rows and reduce through
+//     LDS.  (A barrier-free variant -- each wave owning a whole column tile of the chunk -- is 2 % faster in isolation
+//     but 2 % slower inside the pipeline, where sweep 1 overlaps the write-back of the previous gather; tools/membw2.hip
+//     shows the bare access pattern reaches the 6.2-6.3 TB/s ceiling either way.)
 // =================================================================================================
-template <typename T>
-__device__ __forceinline__ void add_raw(u32x4 raw, float (&acc)[Elem<T>::kVec]);
-template <>
-__device__ __forceinline__ void add_raw<bf16_t>(u32x4 raw, float (&acc)[8]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    acc[2 * i] += __uint_as_float(raw[i] << 16);
-    acc[2 * i + 1] += __uint_as_float(raw[i] & 0xffff0000u);
-  }
-}
-template <>
-__device__ __forceinline__ void add_raw<float>(u32x4 raw, float (&acc)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] += __uint_as_float(raw[i]);
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ h, SegView sv, int d,
                                                              int row_splits, float* __restrict__ partial) {
   constexpr int V = Elem<T>::kVec;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = blockIdx.z, rs = blockIdx.y;
-  const int col = ((blockIdx.x * 4 + wave) * 64 + lane) * V;
-  if (col >= d) return;
+  const int col = (blockIdx.x * 64 + lane) * V;
   const int n = sv.n_rows(s);
+  const int64_t r0 = sv.row_begin(s);
   // fixed 128-row chunks: a segment's partial sums (and therefore its scores, bit for bit) do not depend on what
   // else is in the batch; chunks past the segment's end contribute exact zeros
   const int rb = rs * kRowsPerChunk;
@@ -62,21 +46,39 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   float acc[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) acc[i] = 0.f;
-  const T* base = h + (sv.row_begin(s) * (int64_t)d + col);
-  int r = rb;
-  for (; r + 8 <= re; r += 8) {
-    u32x4 raw[8];
+  if (col < d) {
+    const T* base = h + (r0 * (int64_t)d + col);
+    int r = rb + wave;
+    for (; r + 12 < re; r += 16) {
+      float v0[V], v1[V], v2[V], v3[V];
+      load_vec(base + (int64_t)r * d, v0);
+      load_vec(base + (int64_t)(r + 4) * d, v1);
+      load_vec(base + (int64_t)(r + 8) * d, v2);
+      load_vec(base + (int64_t)(r + 12) * d, v3);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const u32x4*>(base + (int64_t)(r + u) * d);
+      for (int i = 0; i < V; ++i) acc[i] = ((acc[i] + v0[i]) + v1[i]) + (v2[i] + v3[i]);
+    }
+    for (; r < re; r += 4) {
+      float v0[V];
+      load_vec(base + (int64_t)r * d, v0);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) add_raw<T>(raw[u], acc);
+      for (int i = 0; i < V; ++i) acc[i] += v0[i];
+    }
   }
-  for (; r < re; ++r) add_raw<T>(*reinterpret_cast<const u32x4*>(base + (int64_t)r * d), acc);
-  float* dst = partial + ((int64_t)(s * row_splits + rs) * d + col);
+  __shared__ float red[4][64][V + 1];
 #pragma unroll
-  for (int i = 0; i < V; i += 4) {
-    f32x4 o = {acc[i], acc[i + 1], acc[i + 2], acc[i + 3]};
-    *reinterpret_cast<f32x4*>(dst + i) = o;
+  for (int i = 0; i < V; ++i) red[wave][lane][i] = acc[i];
+  __syncthreads();
+  if (wave == 0 && col < d) {
+    float out[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) out[i] = (red[0][lane][i] + red[1][lane][i]) + (red[2][lane][i] + red[3][lane][i]);
+    float* dst = partial + ((int64_t)(s * row_splits + rs) * d + col);
+#pragma unroll
+    for (int i = 0; i < V; i += 4) {
+      f32x4 o = {out[i], out[i + 1], out[i + 2], out[i + 3]};
+      *reinterpret_cast<f32x4*>(dst + i) = o;
+    }
   }
 }
 
@@ -576,7 +578,7 @@ inline int launch_score(hipStream_t st, const T* h, const SegView& sv, const vse
 template <typename T>
 inline int launch_colsum(hipStream_t st, const T* h, const SegView& sv, int d, int S, int row_splits, float* partial) {
   constexpr int V = Elem<T>::kVec;
-  hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3((unsigned)cdiv(d, 4 * 64 * V), row_splits, S), dim3(256), 0, st, h, sv, d,
+  hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3((unsigned)cdiv(d, 64 * V), row_splits, S), dim3(256), 0, st, h, sv, d,
                      row_splits, partial);
   VSEL_AFTER_LAUNCH(st, "colsum_partial_kernel");
   return VSEL_OK;

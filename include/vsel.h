@@ -184,6 +184,17 @@ int vsel_varlen_attn_fwd(void* stream, const void* q, const void* k, const void*
                          int64_t n_seq, int64_t max_seqlen, int64_t total, int64_t hq, int64_t hkv, int64_t d,
                          float scale, int causal, void* out);
 
+/* Same kernel against a PAGED key/value cache (serving): queries are a packed var-len batch (cu_seqlens_q), sequence s
+ * has seqlens_k[s] keys living in pages block_table[s][0 .. ceil(seqlens_k[s] / page_size)) of the pools
+ * k_cache / v_cache [n_pages, page_size, Hkv, d] bf16.  Causal masking is bottom-right aligned (query i of a sequence sees
+ * keys <= i + (seqlens_k - q_len)), i.e. chunked prefill / prefill-with-prefix / decode against the compressed cache.
+ * No reference counterpart beyond the flash-attn call sites above (the reference keeps a contiguous HF DynamicCache);
+ * the north-star asks for a "paged / var-len" kernel.  Rows that see no key output zeros.                               */
+int vsel_paged_attn_fwd(void* stream, const void* q, const void* k_cache, const void* v_cache,
+                        const int32_t* cu_seqlens_q, const int32_t* seqlens_k, const int32_t* block_table,
+                        int64_t max_pages_per_seq, int64_t page_size, int64_t n_seq, int64_t max_seqlen_q, int64_t hq,
+                        int64_t hkv, int64_t d, float scale, int causal, void* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,3 +49,38 @@ def varlen_attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, cu_seqlens: np
             p /= p.sum(axis=1, keepdims=True)                                     # :795 softmax fp32 (here fp64)
             out[a:b, h, :] = p @ vv                                               # :797
     return out
+
+
+def paged_attention(q: np.ndarray, k_cache: np.ndarray, v_cache: np.ndarray, cu_seqlens_q: np.ndarray,
+                    seqlens_k: np.ndarray, block_table: np.ndarray, causal: bool = True,
+                    softmax_scale: float | None = None) -> np.ndarray:
+    """Same math with the keys of sequence s gathered from pages block_table[s][:] of k_cache / v_cache
+    [n_pages, page_size, Hkv, d]; bottom-right aligned causal mask (query i sees keys <= i + klen - qlen, the
+    flash-attn >= 2.1 convention the reference's call sites rely on, trainer.py:89-93); rows without a visible key -> 0."""
+    q = np.asarray(q, np.float64)
+    t, hq, d = q.shape
+    page = k_cache.shape[1]
+    hkv = k_cache.shape[2]
+    rep = hq // hkv
+    scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(d)
+    out = np.zeros_like(q)
+    for s in range(len(seqlens_k)):
+        a, b = int(cu_seqlens_q[s]), int(cu_seqlens_q[s + 1])
+        nq, nk = b - a, int(seqlens_k[s])
+        if nq <= 0 or nk <= 0:
+            continue
+        rows = [int(block_table[s][p // page]) * page + p % page for p in range(nk)]
+        kk_all = np.asarray(k_cache, np.float64).reshape(-1, hkv, d)[rows]
+        vv_all = np.asarray(v_cache, np.float64).reshape(-1, hkv, d)[rows]
+        for h in range(hq):
+            w = (q[a:b, h, :] @ kk_all[:, h // rep, :].T) * scale
+            if causal:
+                vis = np.arange(nk)[None, :] <= (np.arange(nq)[:, None] + (nk - nq))
+                w = np.where(vis, w, -np.inf)
+            mx = w.max(axis=1, keepdims=True)
+            ok = np.isfinite(mx[:, 0])
+            p_ = np.exp(w - np.where(np.isfinite(mx), mx, 0.0))
+            den = p_.sum(axis=1, keepdims=True)
+            p_ = np.where(den > 0, p_ / np.where(den > 0, den, 1.0), 0.0)
+            out[a:b, h, :] = np.where(ok[:, None], p_ @ vv_all[:, h // rep, :], 0.0)
+    return out

@@ -98,3 +98,52 @@ def test_attention_full_size_properties(ops):
                                  v[:lens[0], :1].float().numpy(), np.array([0, lens[0]]))[sl]
     err = np.abs(out[sl, :7].float().cpu().numpy() - ref)
     check(err.max(), err.mean(), np.abs(ref).max())
+
+
+@pytest.mark.parametrize("page_size", [16, 64, 100])
+@pytest.mark.parametrize("causal", [True, False])
+def test_paged_attention_matches_oracle(ops, page_size, causal):
+    """Paged KV cache, per-sequence key lengths != query lengths: chunked prefill (q < k), plain prefill (q == k),
+    decode (q = 1) and a degenerate q > k sequence (leading rows see no key -> zeros)."""
+    hq, hkv = 8, 2
+    qlens = [70, 200, 1, 40]
+    klens = [300, 200, 517, 25]
+    rng = np.random.default_rng(page_size)
+    pages_per = [-(-k // page_size) for k in klens]
+    max_pages = max(pages_per)
+    n_pages = sum(pages_per) + 3
+    perm = rng.permutation(n_pages)                      # scattered physical pages
+    bt = np.zeros((len(qlens), max_pages), np.int32)
+    cur = 0
+    for s, pp in enumerate(pages_per):
+        bt[s, :pp] = perm[cur:cur + pp]
+        cur += pp
+    f = lambda *sh: torch.from_numpy(rng.standard_normal(sh, dtype=np.float32)).bfloat16()  # noqa: E731
+    q = f(sum(qlens), hq, 128)
+    kc, vc = f(n_pages, page_size, hkv, 128), f(n_pages, page_size, hkv, 128)
+    cu_q = np.concatenate(([0], np.cumsum(qlens))).astype(np.int32)
+    out = ops.paged_attn(q.cuda(), kc.cuda(), vc.cuda(), torch.from_numpy(cu_q).cuda(),
+                         torch.tensor(klens, dtype=torch.int32).cuda(), torch.from_numpy(bt).cuda(), max(qlens), causal=causal)
+    ref = oattn.paged_attention(q.float().numpy(), kc.float().numpy(), vc.float().numpy(), cu_q, np.array(klens), bt, causal=causal)
+    err = np.abs(out.float().cpu().numpy().astype(np.float64) - ref)
+    check(err.max(), err.mean(), np.abs(ref).max())
+    if causal:   # q > k sequence: its first qlen - klen rows see no key
+        a = int(cu_q[3])
+        assert float(out[a:a + 15].float().abs().max()) == 0.0
+
+
+def test_paged_equals_contiguous_when_pages_are_in_order(ops):
+    """Identity page table + seqlens_k == query lengths reproduces vsel_varlen_attn_fwd bit for bit."""
+    lens = [130, 257, 64]
+    q, k, v = make_qkv(sum(lens), 8, 2, 31)
+    cu = torch.tensor(np.concatenate(([0], np.cumsum(lens))), dtype=torch.int32).cuda()
+    a = ops.varlen_attn(q.cuda(), k.cuda(), v.cuda(), cu, max(lens))
+    page = 1
+    bt = torch.zeros(len(lens), max(lens), dtype=torch.int32)
+    off = 0
+    for s, n in enumerate(lens):
+        bt[s, :n] = torch.arange(off, off + n, dtype=torch.int32)
+        off += n
+    b = ops.paged_attn(q.cuda(), k.cuda().view(-1, page, 2, 128), v.cuda().view(-1, page, 2, 128), cu,
+                       torch.tensor(lens, dtype=torch.int32).cuda(), bt.cuda(), max(lens))
+    assert torch.equal(a, b)

@@ -49,6 +49,7 @@ SIGNATURES = {
     "vsel_lis_scores_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _SC, _P, _SZ, _P, _P, _P, _P, _P]),
     "vsel_splice": (C.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, C.c_int, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vsel_varlen_attn_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, C.c_int, _P]),
+    "vsel_paged_attn_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, C.c_int, _P]),
 }
 
 _lib = None

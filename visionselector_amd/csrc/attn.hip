@@ -40,12 +40,21 @@ __device__ __forceinline__ bf16x8_t to_bf16x8(u32x4 v) { return __builtin_bit_ca
 // resident workgroups instead of being bounded by the last q-tile (1.9x fewer tiles on the critical path at L = 2368).
 __device__ int g_attn_work_counter[64];
 
+// Optional paged-KV / separate key lengths.  Contiguous var-len prefill (the reference's call sites) leaves it empty.
+struct PagedKV {
+  const int32_t* seqlens_k;     // [n_seq] key length per sequence (NULL: same cu_seqlens as the queries)
+  const int32_t* block_table;   // [n_seq, max_pages] physical page of logical page p (NULL: keys contiguous at cu_k)
+  const int32_t* cu_k;          // [n_seq + 1] key row offsets when keys are contiguous but differ from the queries (or NULL)
+  int max_pages;
+  int page_size;
+};
+
 template <bool USE_TR>
 __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                               const uint16_t* __restrict__ v,
                                                               const int32_t* __restrict__ cu, int hq, int hkv,
                                                               float scale_log2e, int causal, uint16_t* __restrict__ out,
-                                                              int q_tiles, int n_seq, int slot) {
+                                                              int q_tiles, int n_seq, int slot, PagedKV pg) {
   __shared__ __attribute__((aligned(16))) char smem[kLds];
   __shared__ int s_item;
   char* const k_sm = smem;
@@ -73,13 +82,18 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
   const int rest = item % (hq * n_seq);
   const int head = rest % hq, seq = rest / hq;
   const int qs = cu[seq];
-  const int len = cu[seq + 1] - qs;
+  const int qlen = cu[seq + 1] - qs;
   const int q0 = qtile * kBlockQ;
-  if (q0 >= len) continue;
+  if (q0 >= qlen) continue;
+  // keys: same rows as the queries (prefill), or their own length / base / page table (KV cache).  Causal masking is
+  // bottom-right aligned when the key sequence is longer: query i sees keys <= i + (klen - qlen)  (flash-attn >= 2.1).
+  const int len = pg.seqlens_k ? pg.seqlens_k[seq] : qlen;
+  const int shift = len - qlen;
+  const int ks = pg.cu_k ? pg.cu_k[seq] : qs;
   const int kvh = head / (hq / hkv);
-  const int my_q = min(q0 + wave * 32 + j, len - 1);          // clamped: padding lanes replay the last query
-  const bool q_valid = (q0 + wave * 32 + j) < len;
-  const int wave_qmax = min(q0 + wave * 32 + 31, len - 1);
+  const int my_q = min(q0 + wave * 32 + j, qlen - 1);         // clamped: padding lanes replay the last query
+  const bool q_valid = (q0 + wave * 32 + j) < qlen;
+  const int wave_qmax = min(q0 + wave * 32 + 31, qlen - 1);
 
   // Q^T fragments (B operand of S^T = K Q^T): lane (j, hh) holds q[my_q][16*step + 8*hh .. +7]
   u32x4 qf[8];
@@ -95,8 +109,16 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
 
-  const int kv_end = causal ? min(len, q0 + kBlockQ) : len;
+  const int kv_end = causal ? max(0, min(len, q0 + kBlockQ + shift)) : len;
   const int n_tiles = (kv_end + kTileK - 1) / kTileK;
+  if (n_tiles <= 0) {     // no visible key for this whole q-tile (key sequence shorter than the query offset): zeros
+    if (q_valid) {
+      uint16_t* op = out + ((int64_t)(qs + my_q) * hq + head) * kHeadDim + 64 * hh;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) *reinterpret_cast<u32x4*>(op + 8 * c) = u32x4{0u, 0u, 0u, 0u};
+    }
+    continue;
+  }
 
   // staging: 1024 16-byte chunks per tile per tensor, 4 per thread
   u32x4 kreg[4], vreg[4];
@@ -105,7 +127,14 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
     for (int u = 0; u < 4; ++u) {
       const int c = tid + 256 * u;
       const int key = c >> 4, part = c & 15;
-      const int64_t row = qs + min(t * kTileK + key, len - 1);
+      const int kpos = min(t * kTileK + key, len - 1);
+      int64_t row;
+      if (pg.block_table) {
+        const int page = kpos / pg.page_size;
+        row = (int64_t)pg.block_table[(int64_t)seq * pg.max_pages + page] * pg.page_size + (kpos - page * pg.page_size);
+      } else {
+        row = ks + kpos;
+      }
       const int64_t off = (row * hkv + kvh) * kHeadDim + part * 8;
       kreg[u] = *reinterpret_cast<const u32x4*>(k + off);
       vreg[u] = *reinterpret_cast<const u32x4*>(v + off);
@@ -127,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
   for (int t = 0; t < n_tiles; ++t) {
     const int cur = t & 1;
     if (t + 1 < n_tiles) load_tile(t + 1);
-    const bool wave_active = !causal || (t * kTileK <= wave_qmax);
+    const bool wave_active = !causal || (t * kTileK <= wave_qmax + shift);
     if (wave_active) {
       // ---- S^T = K Q^T ----------------------------------------------------------------------------------------
       f32x16 s[2];
@@ -145,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
         }
       }
       // ---- mask + online softmax (exp2 domain; the softmax scale is folded into one FMA per element) ------------
-      const bool need_mask = (t * kTileK + kTileK > len) || (causal && (t * kTileK + kTileK - 1 > q0 + wave * 32));
+      const bool need_mask = (t * kTileK + kTileK > len) || (causal && (t * kTileK + kTileK - 1 > q0 + wave * 32 + shift));
       float mx = -INFINITY;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -154,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
           float val = s[kb][r];
           if (need_mask) {
             const int key = t * kTileK + 32 * kb + 16 * (r >> 3) + 8 * hh + (r & 7);
-            const bool ok = key < len && (!causal || key <= my_q);
+            const bool ok = key < len && (!causal || key <= my_q + shift);
             val = ok ? val : -INFINITY;
             s[kb][r] = val;
           }
@@ -218,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
 
   // ---- epilogue: O^T[d][query] / l, 4 consecutive d per store ------------------------------------------------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;      // a row that sees no key (klen < qlen) outputs zeros
   if (q_valid) {
     uint16_t* op = out + ((int64_t)(qs + my_q) * hq + head) * kHeadDim;
 #pragma unroll
@@ -244,18 +273,9 @@ using namespace vsel;
 static bool g_attn_use_tr = true;
 extern "C" void vsel_debug_attn_use_tr(int on) { g_attn_use_tr = on != 0; }
 
-extern "C" int vsel_varlen_attn_fwd(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens,
-                                    int64_t n_seq, int64_t max_seqlen, int64_t total, int64_t hq, int64_t hkv, int64_t d,
-                                    float scale, int causal, void* out) {
-  if (!q || !k || !v || !cu_seqlens || !out) return fail(VSEL_ERR_INVALID, "NULL pointer");
-  if (d != kHeadDim) return fail(VSEL_ERR_UNSUPPORTED, "head_dim %lld != 128", (long long)d);
-  if (n_seq < 1 || max_seqlen < 1 || total < 1 || hq < 1 || hkv < 1 || hq % hkv != 0 || n_seq > 65535 || hq > 65535)
-    return fail(VSEL_ERR_INVALID, "bad attention shape (n_seq=%lld max_seqlen=%lld total=%lld hq=%lld hkv=%lld)",
-                (long long)n_seq, (long long)max_seqlen, (long long)total, (long long)hq, (long long)hkv);
-  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return fail(VSEL_ERR_INVALID, "q/k/v/out must be 16-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  VSEL_PROF_BEGIN(st);
-  const int q_tiles = (int)cdiv(max_seqlen, kBlockQ);
+static int attn_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
+                       int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg) {
+  const int q_tiles = (int)cdiv(max_seqlen_q, kBlockQ);
   const int64_t n_items = (int64_t)q_tiles * hq * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
   static unsigned next_slot = 0;
@@ -270,10 +290,48 @@ extern "C" int vsel_varlen_attn_fwd(void* stream, const void* q, const void* k, 
   const float sl2 = scale * 1.4426950408889634f;
   if (g_attn_use_tr)
     hipLaunchKernelGGL((varlen_attn_fwd_kernel<true>), grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                       (const uint16_t*)v, cu_seqlens, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot);
+                       (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg);
   else
     hipLaunchKernelGGL((varlen_attn_fwd_kernel<false>), grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                       (const uint16_t*)v, cu_seqlens, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot);
+                       (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg);
   VSEL_AFTER_LAUNCH(st, "varlen_attn_fwd_kernel");
   return VSEL_OK;
+}
+
+static int attn_checks(const void* q, const void* k, const void* v, const int32_t* cu, const void* out, int64_t n_seq,
+                       int64_t max_seqlen, int64_t hq, int64_t hkv, int64_t d) {
+  if (!q || !k || !v || !cu || !out) return fail(VSEL_ERR_INVALID, "NULL pointer");
+  if (d != kHeadDim) return fail(VSEL_ERR_UNSUPPORTED, "head_dim %lld != 128", (long long)d);
+  if (n_seq < 1 || max_seqlen < 1 || hq < 1 || hkv < 1 || hq % hkv != 0 || n_seq > (1 << 24) || hq > 65535)
+    return fail(VSEL_ERR_INVALID, "bad attention shape (n_seq=%lld max_seqlen=%lld hq=%lld hkv=%lld)", (long long)n_seq,
+                (long long)max_seqlen, (long long)hq, (long long)hkv);
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return fail(VSEL_ERR_INVALID, "q/k/v/out must be 16-byte aligned");
+  return VSEL_OK;
+}
+
+extern "C" int vsel_varlen_attn_fwd(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens,
+                                    int64_t n_seq, int64_t max_seqlen, int64_t total, int64_t hq, int64_t hkv, int64_t d,
+                                    float scale, int causal, void* out) {
+  int rc = attn_checks(q, k, v, cu_seqlens, out, n_seq, max_seqlen, hq, hkv, d);
+  if (rc) return rc;
+  if (total < 1) return fail(VSEL_ERR_INVALID, "total must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(st);
+  return attn_launch(st, q, k, v, cu_seqlens, n_seq, max_seqlen, hq, hkv, scale, causal, out, PagedKV{nullptr, nullptr, nullptr, 0, 1});
+}
+
+extern "C" int vsel_paged_attn_fwd(void* stream, const void* q, const void* k_cache, const void* v_cache,
+                                   const int32_t* cu_seqlens_q, const int32_t* seqlens_k, const int32_t* block_table,
+                                   int64_t max_pages_per_seq, int64_t page_size, int64_t n_seq, int64_t max_seqlen_q, int64_t hq,
+                                   int64_t hkv, int64_t d, float scale, int causal, void* out) {
+  int rc = attn_checks(q, k_cache, v_cache, cu_seqlens_q, out, n_seq, max_seqlen_q, hq, hkv, d);
+  if (rc) return rc;
+  if (!seqlens_k || !block_table) return fail(VSEL_ERR_INVALID, "seqlens_k / block_table is NULL");
+  if (page_size < 1 || page_size > (1 << 20) || max_pages_per_seq < 1 || max_pages_per_seq > (1ll << 31) - 1)
+    return fail(VSEL_ERR_INVALID, "bad page geometry (page_size=%lld, max_pages_per_seq=%lld)", (long long)page_size,
+                (long long)max_pages_per_seq);
+  hipStream_t st = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(st);
+  return attn_launch(st, q, k_cache, v_cache, cu_seqlens_q, n_seq, max_seqlen_q, hq, hkv, scale, causal, out,
+                     PagedKV{seqlens_k, block_table, nullptr, (int)max_pages_per_seq, (int)page_size});
 }

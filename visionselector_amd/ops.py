@@ -348,3 +348,26 @@ def varlen_attn(q, k, v, cu_seqlens: torch.Tensor, max_seqlen: int, causal: bool
                                          cu_seqlens.numel() - 1, int(max_seqlen), t, hq, hkv, d, scale, int(causal),
                                          out.data_ptr()))
     return out
+
+
+def paged_attn(q, k_cache, v_cache, cu_seqlens_q: torch.Tensor, seqlens_k: torch.Tensor, block_table: torch.Tensor,
+               max_seqlen_q: int, causal: bool = True, softmax_scale: Optional[float] = None) -> torch.Tensor:
+    """q [Tq,Hq,d] bf16; k_cache / v_cache [n_pages, page_size, Hkv, d] bf16; cu_seqlens_q int32 [S+1];
+    seqlens_k int32 [S]; block_table int32 [S, max_pages] -> out [Tq,Hq,d].  Bottom-right aligned causal mask."""
+    dev = _dev(q, k_cache, v_cache, cu_seqlens_q, seqlens_k, block_table)
+    if q.dtype != torch.bfloat16 or k_cache.dtype != torch.bfloat16 or v_cache.dtype != torch.bfloat16:
+        raise TypeError("paged_attn takes bfloat16 q / k_cache / v_cache")
+    for t in (cu_seqlens_q, seqlens_k, block_table):
+        if t.dtype != torch.int32:
+            raise TypeError("cu_seqlens_q / seqlens_k / block_table must be int32")
+    tq, hq, d = q.shape
+    n_pages, page_size, hkv, _ = k_cache.shape
+    n_seq = seqlens_k.numel()
+    if block_table.dim() != 2 or block_table.shape[0] != n_seq or cu_seqlens_q.numel() != n_seq + 1:
+        raise ValueError("block_table must be [n_seq, max_pages] and cu_seqlens_q [n_seq + 1]")
+    scale = float(softmax_scale) if softmax_scale is not None else d ** -0.5
+    out = torch.empty_like(q)
+    N.check(N.lib().vsel_paged_attn_fwd(_stream(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), cu_seqlens_q.data_ptr(),
+                                        seqlens_k.data_ptr(), block_table.data_ptr(), block_table.shape[1], page_size, n_seq,
+                                        int(max_seqlen_q), hq, hkv, d, scale, int(causal), out.data_ptr()))
+    return out

@@ -122,7 +122,26 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
 
   // staging: 1024 16-byte chunks per tile per tensor, 4 per thread
   u32x4 kreg[4], vreg[4];
+  // per-thread element offsets of its 4 chunks inside tile 0 (contiguous keys); a tile adds a wave-uniform stride
+  int64_t off0[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = tid + 256 * u;
+    off0[u] = ((int64_t)(ks + (c >> 4)) * hkv + kvh) * kHeadDim + (c & 15) * 8;
+  }
+  const int64_t tile_stride = (int64_t)kTileK * hkv * kHeadDim;
   auto load_tile = [&](int t) {
+    const bool tail = __builtin_amdgcn_readfirstlane((int)(t * kTileK + kTileK > len)) != 0;
+    if (!pg.block_table && !tail) {
+      const uint16_t* kp = k + (int64_t)t * tile_stride;
+      const uint16_t* vp = v + (int64_t)t * tile_stride;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        kreg[u] = *reinterpret_cast<const u32x4*>(kp + off0[u]);
+        vreg[u] = *reinterpret_cast<const u32x4*>(vp + off0[u]);
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int c = tid + 256 * u;
@@ -174,21 +193,29 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
         }
       }
       // ---- mask + online softmax (exp2 domain; the softmax scale is folded into one FMA per element) ------------
-      const bool need_mask = (t * kTileK + kTileK > len) || (causal && (t * kTileK + kTileK - 1 > q0 + wave * 32 + shift));
+      // wave-uniform (made explicit with readfirstlane so the compiler emits ONE scalar branch, not an exec-mask dance per
+      // element): only tiles that straddle the causal diagonal or the end of the key sequence pay for the mask
+      const bool need_mask = __builtin_amdgcn_readfirstlane(
+          (int)((t * kTileK + kTileK > len) || (causal && (t * kTileK + kTileK - 1 > q0 + wave * 32 + shift)))) != 0;
       float mx = -INFINITY;
+      if (need_mask) {
+        const int kmax = causal ? min(len - 1, my_q + shift) : len - 1;     // last visible key of this lane's query
+        const int kbase0 = t * kTileK + 8 * hh;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float val = s[kb][r];
-          if (need_mask) {
-            const int key = t * kTileK + 32 * kb + 16 * (r >> 3) + 8 * hh + (r & 7);
-            const bool ok = key < len && (!causal || key <= my_q + shift);
-            val = ok ? val : -INFINITY;
+          for (int r = 0; r < 16; ++r) {
+            const int key = kbase0 + 32 * kb + 16 * (r >> 3) + (r & 7);
+            const float val = key <= kmax ? s[kb][r] : -INFINITY;
             s[kb][r] = val;
+            mx = fmaxf(mx, val);
           }
-          mx = fmaxf(mx, val);
-        }
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx * scale_log2e);      // scale > 0: max commutes with the scaling
       if (!__all(m_new == m_run)) {                            // wave-uniform: most tiles leave the running max alone

@@ -1,0 +1,104 @@
+"""Property / fuzz tests (hypothesis) of the integer-exact kernels against the oracle: hard top-k select (ties, NaN,
+infinities, signed zeros, every k), the device splice (arbitrary visual-token layouts) and the soft top-k invariants."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from oracle import lis as olis
+from oracle import splice as osplice
+
+pytestmark = pytest.mark.gpu
+SETTINGS = dict(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+IMG = 151655
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from visionselector_amd import ops as _ops
+    return _ops
+
+
+specials = st.sampled_from([0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1.0, -1.0, 1e-38, -1e-38, 3.4e38])
+score_values = st.one_of(st.floats(width=32, allow_nan=True, allow_infinity=True), specials,
+                         st.integers(-3, 3).map(float))            # small integers -> many exact ties
+
+
+@settings(**SETTINGS)
+@given(data=st.data())
+def test_hard_topk_matches_oracle_on_arbitrary_floats(ops, data):
+    n = data.draw(st.integers(1, 3000))
+    vals = data.draw(st.lists(score_values, min_size=n, max_size=n))
+    k = data.draw(st.integers(1, n))
+    s = np.array(vals, np.float32)
+    idx, mask = ops.hard_topk(torch.from_numpy(s).cuda(), k, want_mask=True)
+    ref = olis.hard_topk_indices(s, k)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    m = np.zeros(n, np.float32)
+    m[ref] = 1
+    assert np.array_equal(mask.cpu().numpy(), m)
+
+
+@settings(**SETTINGS)
+@given(data=st.data())
+def test_hard_topk_batched_rows(ops, data):
+    b = data.draw(st.integers(1, 9))
+    n = data.draw(st.integers(1, 1500))
+    k = data.draw(st.integers(1, n))
+    seed = data.draw(st.integers(0, 2 ** 31 - 1))
+    rng = np.random.default_rng(seed)
+    s = np.round(rng.standard_normal((b, n)) * 4).astype(np.float32) / 4          # coarse grid: ties everywhere
+    idx = ops.hard_topk(torch.from_numpy(s).cuda(), k).cpu().numpy()
+    for i in range(b):
+        assert np.array_equal(idx[i], olis.hard_topk_indices(s[i], k))
+
+
+@settings(**SETTINGS)
+@given(data=st.data())
+def test_splice_arbitrary_layouts(ops, data):
+    L = data.draw(st.integers(2, 2500))
+    n_vis = data.draw(st.integers(1, L))
+    k = data.draw(st.integers(0, n_vis))
+    seed = data.draw(st.integers(0, 2 ** 31 - 1))
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(0, 50, L).astype(np.int64)
+    ids[np.sort(rng.choice(L, n_vis, replace=False))] = IMG
+    idx = np.sort(rng.choice(n_vis, k, replace=False)).astype(np.int64)
+    d = 8
+    emb = rng.standard_normal((1, L, d), dtype=np.float32)
+    ve = rng.standard_normal((k, d), dtype=np.float32)
+    pos = rng.integers(0, 1 << 40, (3, 1, L)).astype(np.int64)
+    am = rng.integers(0, 2, (1, L)).astype(np.int64)
+    sel, new_ids, new_emb, new_pos, new_am = ops.splice(
+        torch.from_numpy(ids)[None].cuda(), torch.from_numpy(emb).cuda(), IMG, torch.from_numpy(idx).cuda(),
+        torch.from_numpy(ve).cuda(), n_vis, position_ids=torch.from_numpy(pos).cuda(), attention_mask=torch.from_numpy(am).cuda(),
+        check=True)
+    ref_sel, ref_ids = osplice.splice_image(ids[None], IMG, idx)
+    assert np.array_equal(sel.cpu().numpy(), ref_sel) and np.array_equal(new_ids.cpu().numpy(), ref_ids)
+    assert np.array_equal(new_emb.cpu().numpy(), osplice.splice_embeds(emb, ref_ids, ref_sel, IMG, ve))
+    rp, ra = osplice.slice_positions(pos, am, ref_sel)
+    assert np.array_equal(new_pos.cpu().numpy(), rp) and np.array_equal(new_am.cpu().numpy(), ra)
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(data=st.data())
+def test_soft_topk_invariants(ops, data):
+    """sum(ps) = k (to fp32 resolution), monotone in the scores, identical rows give identical masks, and the HIP
+    bisection agrees with the oracle's 64-step loop."""
+    n = data.draw(st.integers(3, 5000))
+    k = data.draw(st.integers(1, n - 1))
+    scale = data.draw(st.sampled_from([1e-4, 0.1, 1.0, 8.0]))
+    seed = data.draw(st.integers(0, 2 ** 31 - 1))
+    x = (np.random.default_rng(seed).standard_normal((2, n)) * scale).astype(np.float32)
+    x[1] = x[0]
+    ps, ts = ops.soft_topk_fwd(torch.from_numpy(x).cuda(), k)
+    ps = ps.cpu().numpy()
+    assert np.array_equal(ps[0], ps[1])
+    assert abs(ps[0].sum(dtype=np.float64) - k) <= max(2e-2, 3e-5 * n)
+    order = np.argsort(x[0], kind="stable")
+    assert np.all(np.diff(ps[0][order]) >= -1e-7)
+    ts_ref, ps_ref = olis.find_ts(x[:1], k)
+    well_conditioned = min(k, n - k) >= 2 and scale >= 0.1
+    assert np.abs(ps[0] - ps_ref[0]).max() <= (2e-5 if well_conditioned else 2e-3)

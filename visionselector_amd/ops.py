@@ -315,6 +315,8 @@ def splice(input_ids, inputs_embeds, visual_token_id: int, all_indices, visual_e
     new_am = torch.empty(1, l_out, dtype=torch.int64, device=dev) if am is not None else None
     src = torch.empty(max(l_out, 1), dtype=torch.int32, device=dev)
     stats = torch.empty(3, dtype=torch.int32, device=dev)
+    if l_out == 0:          # every position was a dropped visual token: nothing to write
+        return sel, new_ids, new_emb, new_pos, new_am
     N.check(N.lib().vsel_splice(_stream(), input_ids.data_ptr(), L, int(visual_token_id), all_indices.data_ptr(), k,
                                 int(n_visual), inputs_embeds.data_ptr(), vis.data_ptr(), _code(inputs_embeds), d, _p(pos), rows,
                                 _p(am), sel.data_ptr(), new_ids.data_ptr(), new_emb.data_ptr(), _p(new_pos), _p(new_am),

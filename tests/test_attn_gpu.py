@@ -147,3 +147,24 @@ def test_paged_equals_contiguous_when_pages_are_in_order(ops):
     b = ops.paged_attn(q.cuda(), k.cuda().view(-1, page, 2, 128), v.cuda().view(-1, page, 2, 128), cu,
                        torch.tensor(lens, dtype=torch.int32).cuda(), bt.cuda(), max(lens))
     assert torch.equal(a, b)
+
+
+def test_workgroup_shapes_agree(ops):
+    """4-wave (128-query) and 8-wave (256-query) workgroups produce bit-identical outputs on a ragged batch."""
+    import ctypes
+    from visionselector_amd import _native
+    lib = _native.lib()
+    lens = [700, 33, 256, 257, 1500]
+    q, k, v = make_qkv(sum(lens), 8, 2, 41)
+    cu = torch.tensor(np.concatenate(([0], np.cumsum(lens))), dtype=torch.int32).cuda()
+    outs = []
+    for nw in (4, 8):
+        lib.vsel_debug_attn_waves(ctypes.c_int(nw))
+        try:
+            outs.append(ops.varlen_attn(q.cuda(), k.cuda(), v.cuda(), cu, max(lens)))
+        finally:
+            lib.vsel_debug_attn_waves(ctypes.c_int(0))
+    assert torch.equal(outs[0], outs[1])
+    ref = oattn.varlen_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu.cpu().numpy())
+    err = np.abs(outs[1].float().cpu().numpy() - ref)
+    check(err.max(), err.mean(), np.abs(ref).max())

@@ -25,7 +25,6 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kHeadDim = 128;
-constexpr int kBlockQ = 128;
 constexpr int kTileK = 64;
 constexpr int kKRowBytes = 256;
 constexpr int kVRowBytes = 320;
@@ -49,12 +48,17 @@ struct PagedKV {
   int page_size;
 };
 
-template <bool USE_TR>
-__global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+// NW = waves per workgroup (4 -> 128 queries, two workgroups per CU; 8 -> 256 queries, one workgroup per CU sharing ONE K/V
+// stream among its 8 waves: half the global loads and LDS stores per FLOP, used when the grid is large enough).
+template <bool USE_TR, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                               const uint16_t* __restrict__ v,
                                                               const int32_t* __restrict__ cu, int hq, int hkv,
                                                               float scale_log2e, int causal, uint16_t* __restrict__ out,
                                                               int q_tiles, int n_seq, int slot, PagedKV pg) {
+  constexpr int kBlockQ = 32 * NW;
+  constexpr int kThreads = 64 * NW;
+  constexpr int kChunksPerThread = 1024 / kThreads;
   __shared__ __attribute__((aligned(16))) char smem[kLds];
   __shared__ int s_item;
   char* const k_sm = smem;
@@ -121,12 +125,12 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
   }
 
   // staging: 1024 16-byte chunks per tile per tensor, 4 per thread
-  u32x4 kreg[4], vreg[4];
+  u32x4 kreg[kChunksPerThread], vreg[kChunksPerThread];
   // per-thread element offsets of its 4 chunks inside tile 0 (contiguous keys); a tile adds a wave-uniform stride
-  int64_t off0[4];
+  int64_t off0[kChunksPerThread];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int c = tid + 256 * u;
+  for (int u = 0; u < kChunksPerThread; ++u) {
+    const int c = tid + kThreads * u;
     off0[u] = ((int64_t)(ks + (c >> 4)) * hkv + kvh) * kHeadDim + (c & 15) * 8;
   }
   const int64_t tile_stride = (int64_t)kTileK * hkv * kHeadDim;
@@ -136,15 +140,15 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
       const uint16_t* kp = k + (int64_t)t * tile_stride;
       const uint16_t* vp = v + (int64_t)t * tile_stride;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kChunksPerThread; ++u) {
         kreg[u] = *reinterpret_cast<const u32x4*>(kp + off0[u]);
         vreg[u] = *reinterpret_cast<const u32x4*>(vp + off0[u]);
       }
       return;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = tid + 256 * u;
+    for (int u = 0; u < kChunksPerThread; ++u) {
+      const int c = tid + kThreads * u;
       const int key = c >> 4, part = c & 15;
       const int kpos = min(t * kTileK + key, len - 1);
       int64_t row;
@@ -161,8 +165,8 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = tid + 256 * u;
+    for (int u = 0; u < kChunksPerThread; ++u) {
+      const int c = tid + kThreads * u;
       const int key = c >> 4, part = c & 15;
       *reinterpret_cast<u32x4*>(k_sm + buf * kKBuf + key * kKRowBytes + ((part ^ (key & 15)) << 4)) = kreg[u];
       *reinterpret_cast<u32x4*>(v_sm + buf * kVBuf + key * kVRowBytes + part * 16) = vreg[u];
@@ -298,29 +302,40 @@ __global__ __launch_bounds__(256, 2) void varlen_attn_fwd_kernel(const uint16_t*
 using namespace vsel;
 
 static bool g_attn_use_tr = true;
+static int g_attn_nw = 0;      // 0 = choose by grid size, 4 / 8 = force the workgroup size
 extern "C" void vsel_debug_attn_use_tr(int on) { g_attn_use_tr = on != 0; }
+extern "C" void vsel_debug_attn_waves(int nw) { g_attn_nw = nw; }
 
 static int attn_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
                        int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg) {
-  const int q_tiles = (int)cdiv(max_seqlen_q, kBlockQ);
+  // 8-wave workgroups (256 queries) when there is enough work to fill the chip with them, else 4-wave (128 queries)
+  const int64_t items8 = cdiv(max_seqlen_q, 256) * hq * n_seq;
+  // measured on MI355X (tools/exp_attn_nw.py): 8 waves +12-16 % at L >= 4096, +4 % at 16 x 2368, -20 % at L = 524
+  const bool big = g_attn_nw == 8 || (g_attn_nw == 0 && max_seqlen_q >= 2048 && items8 >= 1024);
+  const int block_q = big ? 256 : 128;
+  const int q_tiles = (int)cdiv(max_seqlen_q, block_q);
   const int64_t n_items = (int64_t)q_tiles * hq * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
+  const int64_t slots = big ? 256 : 512;                           // resident workgroups
   static unsigned next_slot = 0;
   int slot = -1;                                                   // -1: direct mapping, one item per workgroup
-  if (n_items > 512) {                                             // more items than the 2 x 256 resident workgroups
+  if (n_items > slots) {
     slot = (int)(next_slot++ & 63u);
     int* counters = nullptr;
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_attn_work_counter)));
     VSEL_HIP_CHECK(hipMemsetAsync(counters + slot, 0, sizeof(int), st));
   }
-  const dim3 grid((unsigned)std::min<int64_t>(n_items, 512));
+  const dim3 grid((unsigned)std::min<int64_t>(n_items, slots));
   const float sl2 = scale * 1.4426950408889634f;
-  if (g_attn_use_tr)
-    hipLaunchKernelGGL((varlen_attn_fwd_kernel<true>), grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                       (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg);
-  else
-    hipLaunchKernelGGL((varlen_attn_fwd_kernel<false>), grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                       (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg);
+#define VSEL_ATTN_LAUNCH(TR, NWV)                                                                                          \
+  hipLaunchKernelGGL((varlen_attn_fwd_kernel<TR, NWV>), grid, dim3(64 * NWV), 0, st, (const uint16_t*)q, (const uint16_t*)k, \
+                     (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg)
+  if (g_attn_use_tr) {
+    if (big) VSEL_ATTN_LAUNCH(true, 8); else VSEL_ATTN_LAUNCH(true, 4);
+  } else {
+    if (big) VSEL_ATTN_LAUNCH(false, 8); else VSEL_ATTN_LAUNCH(false, 4);
+  }
+#undef VSEL_ATTN_LAUNCH
   VSEL_AFTER_LAUNCH(st, "varlen_attn_fwd_kernel");
   return VSEL_OK;
 }

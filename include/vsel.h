@@ -174,6 +174,28 @@ int vsel_splice(void* stream, const int64_t* input_ids, int64_t seq_len, int64_t
                 void* new_inputs_embeds, int64_t* new_position_ids, int64_t* new_attention_mask,
                 int32_t* src_scratch, int32_t* stats);
 
+/* -------- packed-batch splice ----------------------------------------------
+ * The reference's generation forward is batch 1 (`assert ... "selector only support single batch"`,
+ * EV/token_compression/selector_model.py:270; OV/compression_method/modeling_selector.py:259).  This entry applies the same
+ * index algebra (:246-262, :264-290, :311-320) to S prompts packed back to back -- the layout the var-len prefill of
+ * FT/qwenvl/train/trainer.py:79-113 consumes -- in two launches, and emits cu_seqlens' for vsel_varlen_attn_fwd.
+ * Sequence s owns packed positions [cu_seqlens[s], cu_seqlens[s+1]), visual rows [cu_visual[s], cu_visual[s+1]) (its LIS
+ * segment, as passed to vsel_lis_select) and kept rows all_indices[cu_kept[s] .. cu_kept[s+1]) holding LOCAL ranks inside
+ * that segment, ascending (exactly vsel_lis_select's idx output for ragged segments).  No scan is needed for the output
+ * offsets: cu_seqlens'[s] = cu_seqlens[s] - cu_visual[s] + cu_kept[s].
+ *   in : input_ids int64 [T]; cu_seqlens, cu_visual, cu_kept int32 [S+1] (device); max_visual >= every segment's size;
+ *        inputs_embeds [T, d_llm]; visual_embeds [K, d_llm]; position_ids int64 [pos_rows, T] or NULL (pos_rows = 0)
+ *   out: selected_indices, new_input_ids int64 [T']; new_inputs_embeds [T', d_llm]; new_position_ids [pos_rows, T'];
+ *        cu_seqlens_out int32 [S+1]; src_scratch int32 [T']; stats int32 [4] = {visual tokens found, rows written, kept
+ *        visual rows, sequences whose token counts disagree with cu_visual / cu_kept (0 on success)}.  T' = T - N + K. */
+int vsel_splice_batched(void* stream, const int64_t* input_ids, int64_t total_len, const int32_t* cu_seqlens,
+                        const int32_t* cu_visual, const int32_t* cu_kept, int64_t n_seq, int64_t max_visual,
+                        int64_t total_visual, int64_t total_kept, int64_t visual_token_id, const int64_t* all_indices,
+                        const void* inputs_embeds, const void* visual_embeds, vsel_dtype dtype, int64_t d_llm,
+                        const int64_t* position_ids, int64_t pos_rows, int64_t* selected_indices, int64_t* new_input_ids,
+                        void* new_inputs_embeds, int64_t* new_position_ids, int32_t* cu_seqlens_out, int32_t* src_scratch,
+                        int32_t* stats);
+
 /* -------- var-len causal attention (compressed-sequence prefill) --------------------------------
  * Replaces flash_attn_varlen_func as called by FT/qwenvl/train/trainer.py:101-113 and the FA2 prefill
  * of EV/qwen25vl/modeling_qwen2_5_vl.py:900 / OV/llavaonevision1_5/modeling_llavaonevision1_5.py:686.

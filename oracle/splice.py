@@ -62,3 +62,31 @@ def slice_positions(position_ids: np.ndarray, attention_mask: np.ndarray, select
     and attention_mask[:, sel].  OV :311-314 slices 1-D position_ids / cache_position / attention_mask
     the same way."""
     return position_ids[..., selected], attention_mask[:, selected]
+
+
+def splice_packed(input_ids: np.ndarray, inputs_embeds: np.ndarray, visual_token_id: int, seq_lens, visual_lens, ks,
+                  all_indices: np.ndarray, visual_embeds: np.ndarray, position_ids: np.ndarray | None = None):
+    """S prompts packed back to back, each spliced independently with the batch-1 algebra above (EV :246-262, :318-319)
+    and concatenated: what running the reference's generation forward once per prompt and packing the results for the
+    var-len prefill (FT/qwenvl/train/trainer.py:79-113) gives.  all_indices holds local ranks per prompt.
+    -> (selected [T'] packed positions, ids' [T'], embeds' [T', D], position_ids' [R, T'] | None, cu_seqlens' [S+1])."""
+    input_ids = np.asarray(input_ids)
+    sel_all, ids_all, emb_all, pos_all, cu = [], [], [], [], [0]
+    p0 = j0 = 0
+    for l_s, n_s, k_s in zip(seq_lens, visual_lens, ks):
+        ids = input_ids[None, p0:p0 + l_s]
+        assert int((ids == visual_token_id).sum()) == n_s
+        idx = np.asarray(all_indices[j0:j0 + k_s], np.int64)
+        sel, new_ids = splice_image(ids, visual_token_id, idx)
+        emb = splice_embeds(inputs_embeds[None, p0:p0 + l_s], new_ids, sel, visual_token_id, visual_embeds[j0:j0 + k_s])
+        sel_all.append(sel + p0)
+        ids_all.append(new_ids[0])
+        emb_all.append(emb[0])
+        if position_ids is not None:
+            pos_all.append(position_ids[:, p0:p0 + l_s][:, sel])
+        cu.append(cu[-1] + sel.shape[0])
+        p0 += l_s
+        j0 += k_s
+    pos = np.concatenate(pos_all, axis=1) if position_ids is not None else None
+    return (np.concatenate(sel_all), np.concatenate(ids_all), np.concatenate(emb_all, axis=0), pos,
+            np.asarray(cu, np.int32))

@@ -77,3 +77,100 @@ def test_splice_token_count_mismatch_raises(ops):
         ops.splice(ids, emb, IMAGE_TOKEN, torch.tensor([0]).cuda(), torch.zeros(1, 8).cuda(), 3, check=True)
     with pytest.raises(ValueError, match="single batch"):      # reference assert (EV :270)
         ops.splice(ids.repeat(2, 1), emb.repeat(2, 1, 1), IMAGE_TOKEN, torch.tensor([0]).cuda(), torch.zeros(1, 8).cuda(), 2)
+
+
+def _packed_case(rng, seq_lens, visual_lens, ks, d, dt):
+    ids_l, idx_l = [], []
+    for l_s, n_s, k_s in zip(seq_lens, visual_lens, ks):
+        ids = rng.integers(10, 1000, l_s).astype(np.int64)
+        ids[np.sort(rng.choice(l_s, n_s, replace=False))] = IMAGE_TOKEN
+        ids_l.append(ids)
+        idx_l.append(np.sort(rng.choice(n_s, k_s, replace=False)).astype(np.int64))
+    ids = np.concatenate(ids_l)
+    idx = np.concatenate(idx_l) if sum(ks) else np.zeros(0, np.int64)
+    t = ids.shape[0]
+    emb = torch.from_numpy(rng.standard_normal((t, d), dtype=np.float32)).to(dt)
+    ve = torch.from_numpy(rng.standard_normal((sum(ks), d), dtype=np.float32)).to(dt)
+    pos = torch.from_numpy(rng.integers(0, 9999, (3, t)).astype(np.int64))
+    return ids, idx, emb, ve, pos
+
+
+@pytest.mark.parametrize("seq_lens,visual_lens,ks,dt", [
+    ([700, 2400, 90, 1300], [576, 2304, 0, 1100], [115, 460, 0, 1100], torch.bfloat16),   # no-image prompt, k = N prompt
+    ([40], [30], [6], torch.float32),                                                      # S = 1 equals the batch-1 entry
+    ([4200, 64, 64, 3000, 1025], [4096, 1, 64, 2900, 1024], [819, 1, 0, 580, 204], torch.bfloat16),
+])
+def test_splice_batched_matches_per_prompt_reference(ops, seq_lens, visual_lens, ks, dt):
+    """vsel_splice_batched == the reference's batch-1 index algebra applied per prompt and concatenated (bit-exact), and
+    its cu_seqlens' are the per-prompt output lengths."""
+    rng = np.random.default_rng(sum(seq_lens) + sum(ks))
+    ids, idx, emb, ve, pos = _packed_case(rng, seq_lens, visual_lens, ks, 128, dt)
+    sel, new_ids, new_emb, new_pos, cu = ops.splice_batched(
+        torch.from_numpy(ids).cuda(), emb.cuda(), IMAGE_TOKEN, seq_lens, visual_lens, ks, torch.from_numpy(idx).cuda(),
+        ve.cuda(), position_ids=pos.cuda(), check=True)
+    r_sel, r_ids, r_emb, r_pos, r_cu = osplice.splice_packed(ids, emb.float().numpy(), IMAGE_TOKEN, seq_lens, visual_lens, ks,
+                                                             idx, ve.float().numpy(), pos.numpy())
+    assert np.array_equal(cu.cpu().numpy(), r_cu)
+    assert np.array_equal(sel.cpu().numpy(), r_sel) and np.array_equal(new_ids.cpu().numpy(), r_ids)
+    assert np.array_equal(new_emb.float().cpu().numpy(), r_emb) and np.array_equal(new_pos.cpu().numpy(), r_pos)
+    if len(seq_lens) == 1:
+        s1 = ops.splice(torch.from_numpy(ids)[None].cuda(), emb[None].cuda(), IMAGE_TOKEN, torch.from_numpy(idx).cuda(), ve.cuda(),
+                        visual_lens[0], position_ids=pos[:, None].cuda())
+        assert torch.equal(s1[0], sel) and torch.equal(s1[1][0], new_ids) and torch.equal(s1[2][0], new_emb)
+
+
+def test_splice_batched_reports_mismatch(ops):
+    """A prompt whose visual-token count disagrees with visual_lens raises the reference's ValueError under check=True."""
+    rng = np.random.default_rng(5)
+    ids, idx, emb, ve, pos = _packed_case(rng, [100, 200], [50, 120], [10, 24], 64, torch.bfloat16)
+    ids[np.where(ids[:100] == IMAGE_TOKEN)[0][0]] = 11          # prompt 0 now holds 49 visual tokens
+    with pytest.raises(ValueError, match="do not match"):
+        ops.splice_batched(torch.from_numpy(ids).cuda(), emb.cuda(), IMAGE_TOKEN, [100, 200], [50, 120], [10, 24],
+                           torch.from_numpy(idx).cuda(), ve.cuda(), check=True)
+    with pytest.raises(ValueError):
+        ops.splice_batched(torch.from_numpy(ids).cuda(), emb.cuda(), IMAGE_TOKEN, [100, 200], [50, 220], [10, 24],
+                           torch.from_numpy(idx).cuda(), ve.cuda())
+
+
+def test_select_splice_attend_packed_pipeline(ops):
+    """Config C5 end to end on device: ragged LIS select -> packed splice -> var-len attention over cu_seqlens', against
+    the oracle run prompt by prompt."""
+    from oracle import attention as oattn
+    from oracle import lis as olis
+    rng = np.random.default_rng(77)
+    d, hd = 256, 128
+    visual_lens, texts = [576, 1024, 300], [40, 17, 64]
+    ks = [int(n * 0.2) for n in visual_lens]
+    seq_lens = [n + t for n, t in zip(visual_lens, texts)]
+    h = torch.from_numpy(rng.standard_normal((sum(visual_lens), d), dtype=np.float32))
+    wq, wk = [torch.from_numpy(rng.standard_normal((hd, d), dtype=np.float32) * 0.02) for _ in range(2)]
+    bq, bk = [torch.from_numpy(rng.standard_normal(hd, dtype=np.float32) * 0.02) for _ in range(2)]
+    out, idx, _ = ops.lis_select_varlen(h.cuda(), visual_lens, ks, wq.cuda(), bq.cuda(), wk.cuda(), bk.cuda())
+    ids_l = []
+    for n, t in zip(visual_lens, texts):
+        ids_l.append(np.concatenate([rng.integers(10, 1000, t // 2), np.full(n, IMAGE_TOKEN), rng.integers(10, 1000, t - t // 2)]))
+    ids = np.concatenate(ids_l).astype(np.int64)
+    emb = torch.from_numpy(rng.standard_normal((ids.shape[0], d), dtype=np.float32))
+    sel, new_ids, new_emb, _, cu = ops.splice_batched(torch.from_numpy(ids).cuda(), emb.cuda(), IMAGE_TOKEN, seq_lens, visual_lens,
+                                                      ks, idx, out, check=True)
+    # oracle: per-prompt select + splice
+    o_idx, v0 = [], 0
+    for n, k in zip(visual_lens, ks):
+        s = olis.scorer_collapsed(h[None, v0:v0 + n].numpy(), wq.numpy(), bq.numpy(), wk.numpy(), bk.numpy())[0]
+        o_idx.append(olis.hard_topk_indices(np.asarray(s, np.float32), k))
+        v0 += n
+    o_idx = np.concatenate(o_idx)
+    assert np.array_equal(idx.cpu().numpy(), o_idx)
+    offs = np.repeat(np.cumsum([0] + visual_lens[:-1]), ks)
+    r_sel, r_ids, r_emb, _, r_cu = osplice.splice_packed(ids, emb.numpy(), IMAGE_TOKEN, seq_lens, visual_lens, ks, o_idx,
+                                                         h.numpy()[o_idx + offs])
+    assert np.array_equal(cu.cpu().numpy(), r_cu) and np.array_equal(sel.cpu().numpy(), r_sel)
+    assert np.array_equal(new_emb.cpu().numpy(), r_emb)
+    # attention over the compressed packed batch (2 q heads, 1 kv head, d 128 taken from the embeddings)
+    x = new_emb.to(torch.bfloat16)
+    q = x[:, :256].reshape(-1, 2, 128).contiguous()
+    kk = x[:, 128:256].reshape(-1, 1, 128).contiguous()
+    vv = x[:, :128].reshape(-1, 1, 128).contiguous()
+    o = ops.varlen_attn(q, kk, vv, cu, max(seq_lens))
+    ref = oattn.varlen_attention(q.float().cpu().numpy(), kk.float().cpu().numpy(), vv.float().cpu().numpy(), r_cu)
+    assert np.abs(o.float().cpu().numpy() - ref).max() <= 2e-2          # bf16 output of values ~N(0,1)

@@ -48,6 +48,8 @@ SIGNATURES = {
     "vsel_lis_train_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _SC, _P, _P, _P, _P, _P, _F, _P, _SZ, _P, _P, _P, _P, _P]),
     "vsel_lis_scores_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _SC, _P, _SZ, _P, _P, _P, _P, _P]),
     "vsel_splice": (C.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, C.c_int, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vsel_splice_batched": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, C.c_int, _I64, _P, _I64,
+                                      _P, _P, _P, _P, _P, _P, _P]),
     "vsel_varlen_attn_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, C.c_int, _P]),
     "vsel_paged_attn_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, C.c_int, _P]),
 }

@@ -330,6 +330,67 @@ def splice(input_ids, inputs_embeds, visual_token_id: int, all_indices, visual_e
     return sel, new_ids, new_emb, new_pos, new_am
 
 
+def splice_batched(input_ids, inputs_embeds, visual_token_id: int, seq_lens: Sequence[int], visual_lens: Sequence[int],
+                   ks: Sequence[int], all_indices, visual_embeds, position_ids=None, check: bool = False):
+    """Packed-batch splice.  input_ids [T] int64 = S prompts back to back (seq_lens), prompt s holding visual_lens[s]
+    visual tokens of which ks[s] are kept; all_indices [sum ks] int64 = local ranks per prompt, ascending (the idx output of
+    lis_select_varlen(h, visual_lens, ks, ...)); visual_embeds [sum ks, D] (its `out`); inputs_embeds [T, D];
+    position_ids [R, T] int64 or None ->
+    (selected_indices [T'], input_ids' [T'], inputs_embeds' [T', D], position_ids' [R, T'] | None, cu_seqlens' int32 [S+1]).
+    Each prompt is spliced exactly like the reference's batch-1 forward; no host sync unless check=True (raises ValueError
+    on a token-count mismatch, reference: selector_model.py:210-213)."""
+    dev = _dev(input_ids, inputs_embeds, all_indices, visual_embeds, position_ids)
+    if input_ids.dim() != 1 or inputs_embeds.dim() != 2:
+        raise ValueError("packed splice takes input_ids [T] and inputs_embeds [T, D]")
+    if input_ids.dtype != torch.int64 or all_indices.dtype != torch.int64:
+        raise TypeError("input_ids / all_indices must be int64")
+    s = len(seq_lens)
+    if s == 0 or len(visual_lens) != s or len(ks) != s:
+        raise ValueError("seq_lens, visual_lens and ks must have the same non-zero length")
+    for l_s, n_s, k_s in zip(seq_lens, visual_lens, ks):
+        if not (0 <= k_s <= n_s <= l_s):
+            raise ValueError(f"need 0 <= k <= visual tokens <= length per prompt, got k={k_s}, visual={n_s}, length={l_s}")
+    t = input_ids.numel()
+    if sum(seq_lens) != t or inputs_embeds.shape[0] != t:
+        raise ValueError(f"sum(seq_lens)={sum(seq_lens)} / embeds rows {inputs_embeds.shape[0]} != positions {t}")
+    n_tot, k_tot = sum(visual_lens), sum(ks)
+    if all_indices.numel() != k_tot or visual_embeds.shape[0] != k_tot:
+        raise ValueError("all_indices / visual_embeds must hold sum(ks) rows")
+    d = inputs_embeds.shape[-1]
+    l_out = t - n_tot + k_tot
+
+    def _cu(lens):
+        c = [0]
+        for x in lens:
+            c.append(c[-1] + int(x))
+        return torch.tensor(c, dtype=torch.int32).to(dev, non_blocking=True)
+
+    cu_s, cu_v, cu_k = _cu(seq_lens), _cu(visual_lens), _cu(ks)
+    vis = visual_embeds.to(inputs_embeds.dtype).contiguous()
+    emb = inputs_embeds.contiguous()
+    pos = None
+    rows = 0
+    if position_ids is not None:
+        pos = position_ids.to(torch.int64).contiguous()
+        rows = pos.numel() // t
+    sel = torch.empty(l_out, dtype=torch.int64, device=dev)
+    new_ids = torch.empty(l_out, dtype=torch.int64, device=dev)
+    new_emb = torch.empty(l_out, d, dtype=inputs_embeds.dtype, device=dev)
+    new_pos = torch.empty(rows, l_out, dtype=torch.int64, device=dev) if pos is not None else None
+    cu_out = torch.empty(s + 1, dtype=torch.int32, device=dev)
+    src = torch.empty(max(l_out, 1), dtype=torch.int32, device=dev)
+    stats = torch.empty(4, dtype=torch.int32, device=dev)
+    N.check(N.lib().vsel_splice_batched(_stream(), input_ids.data_ptr(), t, cu_s.data_ptr(), cu_v.data_ptr(), cu_k.data_ptr(),
+                                        s, max(visual_lens), n_tot, k_tot, int(visual_token_id), _p(all_indices), emb.data_ptr(),
+                                        _p(vis), _code(inputs_embeds), d, _p(pos), rows, sel.data_ptr(), new_ids.data_ptr(),
+                                        new_emb.data_ptr(), _p(new_pos), cu_out.data_ptr(), src.data_ptr(), stats.data_ptr()))
+    if check:
+        found, written, kept, bad = stats.tolist()
+        if bad or found != n_tot or written != l_out or kept != k_tot:
+            raise ValueError(f"Image features and image tokens do not match: tokens: {found}, features {n_tot}")
+    return sel, new_ids, new_emb, new_pos, cu_out
+
+
 # ------------------------------------------------------------------------------------------------
 # var-len attention
 # ------------------------------------------------------------------------------------------------

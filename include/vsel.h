@@ -217,6 +217,24 @@ int vsel_paged_attn_fwd(void* stream, const void* q, const void* k_cache, const 
                         int64_t max_pages_per_seq, int64_t page_size, int64_t n_seq, int64_t max_seqlen_q, int64_t hq,
                         int64_t hkv, int64_t d, float scale, int causal, void* out);
 
+/* -------- var-len attention for TRAINING: forward that also saves the log-sum-exp, and the backward -------------
+ * The reference trains the LIS through the frozen LLM with flash_attn_varlen_func (FT/qwenvl/train/trainer.py:101-113,
+ * patched in by replace_qwen2_vl_attention_class :150-160), so dQ / dK / dV of the same op are on the training path.
+ * Math = autograd of the eager formula EV/qwen25vl/modeling_qwen2_5_vl.py:777-797 (see csrc/attn_bwd.hip).
+ *   vsel_varlen_attn_fwd_lse: as vsel_varlen_attn_fwd, plus lse float32 [total, hq] = log sum_j exp(scale * q_i.k_j) over the
+ *     visible keys (natural log).
+ *   vsel_varlen_attn_bwd: dout, out [total, hq, 128] bf16, lse from the forward -> dq [total, hq, 128], dk, dv
+ *     [total, hkv, 128] bf16 (overwritten; GQA groups are summed in fp32 inside the kernel).  q and k share cu_seqlens.
+ *     Deterministic: no float atomics, reruns are bit-identical.  Workspace: vsel_varlen_attn_bwd_workspace_bytes.     */
+int vsel_varlen_attn_fwd_lse(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens,
+                             int64_t n_seq, int64_t max_seqlen, int64_t total, int64_t hq, int64_t hkv, int64_t d,
+                             float scale, int causal, void* out, float* lse);
+size_t vsel_varlen_attn_bwd_workspace_bytes(int64_t total, int64_t hq);
+int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* q, const void* k, const void* v, const void* out,
+                         const float* lse, const int32_t* cu_seqlens, int64_t n_seq, int64_t max_seqlen, int64_t total,
+                         int64_t hq, int64_t hkv, int64_t d, float scale, int causal, void* workspace,
+                         size_t workspace_bytes, void* dq, void* dk, void* dv);
+
 #ifdef __cplusplus
 }
 #endif

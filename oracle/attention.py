@@ -84,3 +84,42 @@ def paged_attention(q: np.ndarray, k_cache: np.ndarray, v_cache: np.ndarray, cu_
             p_ = np.where(den > 0, p_ / np.where(den > 0, den, 1.0), 0.0)
             out[a:b, h, :] = np.where(ok[:, None], p_ @ vv_all[:, h // rep, :], 0.0)
     return out
+
+
+def varlen_attention_backward(q: np.ndarray, k: np.ndarray, v: np.ndarray, cu_seqlens: np.ndarray, dout: np.ndarray,
+                              causal: bool = True, softmax_scale: float | None = None):
+    """Closed-form gradients of varlen_attention w.r.t. q, k, v (fp64): the autograd of the eager formula
+    (/root/reference/qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py:777-797) that the reference obtains from
+    flash_attn_varlen_func's backward when training through the frozen LLM
+    (/root/reference/qwen-vl-finetune/qwenvl/train/trainer.py:101-113).  PARITY UNPINNED against flash_attn (absent);
+    tests/test_oracle_golden.py pins this function against torch autograd of the same eager formula.
+    -> (dq [T,Hq,d], dk [T,Hkv,d], dv [T,Hkv,d]); GQA groups sum into their kv head (repeat_kv's autograd, :693-702)."""
+    q = np.asarray(q, np.float64)
+    k = np.asarray(k, np.float64)
+    v = np.asarray(v, np.float64)
+    dout = np.asarray(dout, np.float64)
+    t, hq, d = q.shape
+    hkv = k.shape[1]
+    rep = hq // hkv
+    scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(d)
+    dq, dk, dv = np.zeros_like(q), np.zeros_like(k), np.zeros_like(v)
+    cu = [int(c) for c in cu_seqlens]
+    for s in range(len(cu) - 1):
+        a, b = cu[s], cu[s + 1]
+        n = b - a
+        if n <= 0:
+            continue
+        for h in range(hq):
+            g = h // rep
+            w = (q[a:b, h, :] @ k[a:b, g, :].T) * scale
+            if causal:
+                w = np.where(np.tril(np.ones((n, n), bool)), w, -np.inf)
+            p = np.exp(w - w.max(axis=1, keepdims=True))
+            p /= p.sum(axis=1, keepdims=True)
+            do = dout[a:b, h, :]
+            dv[a:b, g, :] += p.T @ do
+            dp = do @ v[a:b, g, :].T
+            ds = p * (dp - (dp * p).sum(axis=1, keepdims=True))
+            dq[a:b, h, :] = ds @ k[a:b, g, :] * scale
+            dk[a:b, g, :] += ds.T @ q[a:b, h, :] * scale
+    return dq, dk, dv

@@ -1,0 +1,112 @@
+"""GPU parity of the var-len attention backward (vsel_varlen_attn_bwd) against the closed-form fp64 oracle
+(oracle/attention.py::varlen_attention_backward, itself pinned to torch autograd of the reference's eager formula on CPU).
+Parity with flash_attn's backward (what the reference calls, trainer.py:101-113) is UNPINNED: flash_attn is absent."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention as oattn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from visionselector_amd import ops as _ops
+    return _ops
+
+
+def _case(lens, hq, hkv, seed):
+    rng = np.random.default_rng(seed)
+    total = sum(lens)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s, dtype=np.float32)).bfloat16()  # noqa: E731
+    q, k, v, do = f(total, hq, 128), f(total, hkv, 128), f(total, hkv, 128), f(total, hq, 128)
+    cu = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    return q, k, v, do, cu
+
+
+def _run(ops, lens, hq, hkv, causal, seed):
+    q, k, v, do, cu = _case(lens, hq, hkv, seed)
+    cu_d = torch.from_numpy(cu).cuda()
+    out, lse = ops.varlen_attn_fwd_lse(q.cuda(), k.cuda(), v.cuda(), cu_d, max(lens), causal=causal)
+    dq, dk, dv = ops.varlen_attn_bwd(do.cuda(), q.cuda(), k.cuda(), v.cuda(), out, lse, cu_d, max(lens), causal=causal)
+    return (q, k, v, do, cu), out, lse, (dq, dk, dv)
+
+
+def _rel(got, ref):
+    """max |err| relative to the tensor's max magnitude: outputs are bf16 and P / dS are rounded to bf16 before the
+    second contractions, exactly as in the forward kernel and in flash-attn."""
+    got = got.float().cpu().numpy().astype(np.float64)
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-3)      # floor: a single-key row has dS == 0 exactly
+
+
+@pytest.mark.parametrize("lens,hq,hkv", [([100], 4, 2), ([128], 2, 2), ([129], 4, 1), ([1], 2, 1), ([64, 65, 3, 200], 4, 2),
+                                         ([300, 17], 14, 2), ([257], 8, 8)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_attention_backward_matches_oracle(ops, lens, hq, hkv, causal):
+    (q, k, v, do, cu), out, lse, (dq, dk, dv) = _run(ops, lens, hq, hkv, causal, seed=sum(lens) + hq)
+    a = [x.float().numpy() for x in (q, k, v)]
+    rq, rk, rv = oattn.varlen_attention_backward(*a, cu, do.float().numpy(), causal=causal)
+    # tolerance: 2 bf16 ulps of the tensor's magnitude (2^-7) -- bf16 outputs + bf16-rounded P / dS operands
+    assert _rel(dq, rq) <= 2 ** -6, _rel(dq, rq)
+    assert _rel(dk, rk) <= 2 ** -6, _rel(dk, rk)
+    assert _rel(dv, rv) <= 2 ** -6, _rel(dv, rv)
+
+
+def test_forward_lse_matches_oracle(ops):
+    lens = [70, 200, 5]
+    (q, k, v, do, cu), out, lse, _ = _run(ops, lens, 4, 2, True, seed=9)
+    qf, kf = q.float().numpy().astype(np.float64), k.float().numpy().astype(np.float64)
+    ref = np.zeros((sum(lens), 4))
+    for a, b in zip(cu[:-1], cu[1:]):
+        for h in range(4):
+            w = qf[a:b, h] @ kf[a:b, h // 2].T / np.sqrt(128.0)
+            w = np.where(np.tril(np.ones((b - a, b - a), bool)), w, -np.inf)
+            m = w.max(axis=1)
+            ref[a:b, h] = m + np.log(np.exp(w - m[:, None]).sum(axis=1))
+    assert np.abs(lse.cpu().numpy() - ref).max() <= 1e-4
+    # and the lse-returning forward writes the same output bits as the plain forward
+    out2 = ops.varlen_attn(q.cuda(), k.cuda(), v.cuda(), torch.from_numpy(cu).cuda(), max(lens), causal=True)
+    assert torch.equal(out, out2)
+
+
+def test_backward_is_deterministic_and_batch_invariant(ops):
+    """No float atomics: reruns are bit-identical, and a sequence's gradients do not depend on what it is packed with."""
+    lens = [333, 140, 700]
+    (q, k, v, do, cu), out, lse, g1 = _run(ops, lens, 8, 2, True, seed=4)
+    _, _, _, g2 = _run(ops, lens, 8, 2, True, seed=4)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+    s0, s1 = int(cu[1]), int(cu[2])
+    cu1 = torch.tensor([0, s1 - s0], dtype=torch.int32).cuda()
+    sl = lambda x: x[s0:s1].contiguous().cuda()  # noqa: E731
+    o1, l1 = ops.varlen_attn_fwd_lse(sl(q), sl(k), sl(v), cu1, s1 - s0)
+    h1 = ops.varlen_attn_bwd(sl(do), sl(q), sl(k), sl(v), o1, l1, cu1, s1 - s0)
+    for a, b in zip(g1, h1):
+        assert torch.equal(a[s0:s1], b)
+
+
+def test_backward_linearity_and_full_size(ops):
+    """Full-size (7B geometry, L = 2368) property checks: the backward is linear in dout (up to bf16 rounding), and
+    sum(dout * out) == sum(dq * q) == sum(dk * k) for ... no -- softmax invariances: rows of dS sum to zero, hence
+    sum_d dq.q == sum_d dk.k per (sequence, group) (both equal sum_ij dS_ij S_ij)."""
+    lens = [2368, 524]
+    hq, hkv = 28, 4
+    (q, k, v, do, cu), out, lse, (dq, dk, dv) = _run(ops, lens, hq, hkv, True, seed=21)
+    qd, kd = q.cuda().float(), k.cuda().float()
+    for a, b in zip(cu[:-1], cu[1:]):
+        lhs = (dq[a:b].float() * qd[a:b]).sum().item()
+        rhs = (dk[a:b].float() * kd[a:b]).sum().item()
+        scale = max(abs(lhs), (dq[a:b].float() * qd[a:b]).abs().sum().item() * 2 ** -8)
+        assert abs(lhs - rhs) <= 2 ** -5 * scale + 1e-3, (lhs, rhs)
+    # dV = P^T dO: sum over keys of dv equals sum over queries of dout per group (P rows sum to 1)
+    for g in range(hkv):
+        lhs = dv[:, g].float().sum(0)
+        rhs = do.cuda()[:, g * 7:(g + 1) * 7].float().sum((0, 1))
+        assert (lhs - rhs).abs().max().item() <= 2 ** -6 * rhs.abs().max().item() + 0.5
+    # spot-check one head group of the short sequence against the oracle
+    a, b = int(cu[1]), int(cu[2])
+    sl = lambda x: x[a:b].float().numpy()  # noqa: E731
+    rq, rk, rv = oattn.varlen_attention_backward(sl(q)[:, :7], sl(k)[:, :1], sl(v)[:, :1], np.array([0, b - a]), sl(do)[:, :7])
+    assert _rel(dq[a:b, :7], rq) <= 2 ** -6 and _rel(dk[a:b, :1], rk) <= 2 ** -6 and _rel(dv[a:b, :1], rv) <= 2 ** -6

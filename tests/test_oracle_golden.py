@@ -189,3 +189,43 @@ def test_torch_cpu_restatement(golden_dir, cases, name):
         assert np.array_equal(idx.numpy(), g["idx_" + str(r).replace(".", "p")])
         assert np.abs(scores.numpy() - g["scores"]).max() <= 2e-6 * max(1.0, np.abs(g["scores"]).max())
         assert torch.equal(h_new, t["h"][idx])
+
+
+def _eager_attention_torch(q, k, v, cu, causal):
+    """torch restatement of the eager formula (modeling_qwen2_5_vl.py:777-797) in fp64, differentiable."""
+    import torch
+    t, hq, d = q.shape
+    rep = hq // k.shape[1]
+    outs = []
+    for a, b in zip(cu[:-1], cu[1:]):
+        qq = q[a:b].transpose(0, 1)
+        kk = k[a:b].repeat_interleave(rep, dim=1).transpose(0, 1)
+        vv = v[a:b].repeat_interleave(rep, dim=1).transpose(0, 1)
+        w = qq @ kk.transpose(1, 2) / (d ** 0.5)
+        if causal:
+            n = b - a
+            w = w.masked_fill(~torch.tril(torch.ones(n, n, dtype=torch.bool)), float("-inf"))
+        outs.append((torch.softmax(w, dim=-1) @ vv).transpose(0, 1))
+    return torch.cat(outs, 0)
+
+
+@pytest.mark.parametrize("causal", [True, False])
+def test_attention_oracle_forward_backward_match_torch_autograd(causal):
+    """Pins oracle.attention.varlen_attention / varlen_attention_backward against torch autograd of the same eager formula
+    (flash_attn, which the reference calls, is absent: parity with it is unpinned)."""
+    import torch
+    from oracle import attention as oattn
+    rng = np.random.default_rng(3)
+    cu = [0, 37, 37, 90]
+    q = rng.standard_normal((90, 4, 16))
+    k = rng.standard_normal((90, 2, 16))
+    v = rng.standard_normal((90, 2, 16))
+    do = rng.standard_normal((90, 4, 16))
+    tq, tk, tv = [torch.tensor(x, requires_grad=True) for x in (q, k, v)]
+    out = _eager_attention_torch(tq, tk, tv, cu, causal)
+    out.backward(torch.tensor(do))
+    assert np.allclose(oattn.varlen_attention(q, k, v, np.asarray(cu), causal=causal), out.detach().numpy(), atol=1e-12)
+    dq, dk, dv = oattn.varlen_attention_backward(q, k, v, np.asarray(cu), do, causal=causal)
+    assert np.allclose(dq, tq.grad.numpy(), atol=1e-11)
+    assert np.allclose(dk, tk.grad.numpy(), atol=1e-11)
+    assert np.allclose(dv, tv.grad.numpy(), atol=1e-11)

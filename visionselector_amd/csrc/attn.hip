@@ -55,7 +55,8 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
                                                               const uint16_t* __restrict__ v,
                                                               const int32_t* __restrict__ cu, int hq, int hkv,
                                                               float scale_log2e, int causal, uint16_t* __restrict__ out,
-                                                              int q_tiles, int n_seq, int slot, PagedKV pg) {
+                                                              int q_tiles, int n_seq, int slot, PagedKV pg,
+                                                              float* __restrict__ lse) {
   constexpr int kBlockQ = 32 * NW;
   constexpr int kThreads = 64 * NW;
   constexpr int kChunksPerThread = 1024 / kThreads;
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
       uint16_t* op = out + ((int64_t)(qs + my_q) * hq + head) * kHeadDim + 64 * hh;
 #pragma unroll
       for (int c = 0; c < 8; ++c) *reinterpret_cast<u32x4*>(op + 8 * c) = u32x4{0u, 0u, 0u, 0u};
+      if (lse && hh == 0) lse[(int64_t)(qs + my_q) * hq + head] = -INFINITY;
     }
     continue;
   }
@@ -280,6 +282,9 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;      // a row that sees no key (klen < qlen) outputs zeros
   if (q_valid) {
+    // log-sum-exp of the scaled scores (natural log), saved for the backward pass; -inf for a row without a visible key
+    if (lse && hh == 0)
+      lse[(int64_t)(qs + my_q) * hq + head] = l_tot > 0.f ? (m_run + log2f(l_tot)) * 0.6931471805599453f : -INFINITY;
     uint16_t* op = out + ((int64_t)(qs + my_q) * hq + head) * kHeadDim;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -307,7 +312,8 @@ extern "C" void vsel_debug_attn_use_tr(int on) { g_attn_use_tr = on != 0; }
 extern "C" void vsel_debug_attn_waves(int nw) { g_attn_nw = nw; }
 
 static int attn_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
-                       int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg) {
+                       int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg,
+                       float* lse = nullptr) {
   // 8-wave workgroups (256 queries) when there is enough work to fill the chip with them, else 4-wave (128 queries)
   const int64_t items8 = cdiv(max_seqlen_q, 256) * hq * n_seq;
   // measured on MI355X (tools/exp_attn_nw.py): 8 waves +12-16 % at L >= 4096, +4 % at 16 x 2368, -20 % at L = 524
@@ -329,7 +335,7 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   const float sl2 = scale * 1.4426950408889634f;
 #define VSEL_ATTN_LAUNCH(TR, NWV)                                                                                          \
   hipLaunchKernelGGL((varlen_attn_fwd_kernel<TR, NWV>), grid, dim3(64 * NWV), 0, st, (const uint16_t*)q, (const uint16_t*)k, \
-                     (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg)
+                     (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg, lse)
   if (g_attn_use_tr) {
     if (big) VSEL_ATTN_LAUNCH(true, 8); else VSEL_ATTN_LAUNCH(true, 4);
   } else {
@@ -360,6 +366,18 @@ extern "C" int vsel_varlen_attn_fwd(void* stream, const void* q, const void* k, 
   hipStream_t st = (hipStream_t)stream;
   VSEL_PROF_BEGIN(st);
   return attn_launch(st, q, k, v, cu_seqlens, n_seq, max_seqlen, hq, hkv, scale, causal, out, PagedKV{nullptr, nullptr, nullptr, 0, 1});
+}
+
+extern "C" int vsel_varlen_attn_fwd_lse(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens,
+                                        int64_t n_seq, int64_t max_seqlen, int64_t total, int64_t hq, int64_t hkv, int64_t d,
+                                        float scale, int causal, void* out, float* lse) {
+  int rc = attn_checks(q, k, v, cu_seqlens, out, n_seq, max_seqlen, hq, hkv, d);
+  if (rc) return rc;
+  if (total < 1 || !lse) return fail(VSEL_ERR_INVALID, "total must be >= 1 and lse non-NULL");
+  hipStream_t st = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(st);
+  return attn_launch(st, q, k, v, cu_seqlens, n_seq, max_seqlen, hq, hkv, scale, causal, out,
+                     PagedKV{nullptr, nullptr, nullptr, 0, 1}, lse);
 }
 
 extern "C" int vsel_paged_attn_fwd(void* stream, const void* q, const void* k_cache, const void* v_cache,

@@ -1,0 +1,460 @@
+// Var-len causal GQA attention BACKWARD (gfx950, bf16, head_dim 128): dQ, dK, dV for the training path.
+//
+// The reference trains through flash_attn_varlen_func (qwen-vl-finetune/qwenvl/train/trainer.py:101-113, installed by
+// replace_qwen2_vl_attention_class, :150-160): the LLM is frozen but the LIS gradient flows back through every attention
+// layer, so the backward of the same op is on the training hot path.  Math = autograd of the in-tree eager formula
+// (qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py:777-797):
+//   P = softmax(S), S = scale * Q K^T (+ causal);  dV = P^T dO;  dP = dO V^T;  dS = P o (dP - D), D_i = sum_d dO_id O_id;
+//   dQ = scale * dS K;  dK = scale * dS^T Q;  GQA: dK / dV of a kv head sum over the q heads of its group.
+//
+// Deterministic by construction (no float atomics, reruns are bit-identical): two kernels, each owning its outputs.
+//   attn_bwd_dq_kernel    item = (128-query tile, q head, sequence), loops over 64-key K/V tiles in LDS:
+//                         S^T = K Q^T, dP^T = V dO^T (lane = query, so lse / D are per-lane scalars),
+//                         dQ^T += K^T dS^T (K^T fragments by ds_read_b64_tr_b16 from the same tile).
+//   attn_bwd_dkdv_kernel  item = (128-key block, kv head, sequence), K / V fragments stay in registers, loops over the q heads
+//                         of the group and over 64-query Q / dO tiles in LDS: S = Q K^T, dP = dO V^T (lane = key),
+//                         dV^T += dO^T P, dK^T += Q^T dS (transposed fragments by ds_read_b64_tr_b16).
+// P is recomputed from the forward's log-sum-exp (vsel_varlen_attn_fwd_lse).  One LDS layout serves both the row (b128) and
+// the transposed (b64_tr) reads without bank conflicts: 256-byte rows, 16-byte part p of row r stored at part p ^ swz(r),
+// swz(r) = ((r & 3) << 2) | ((r >> 2) & 3).
+#include "common.h"
+
+#include <algorithm>
+
+namespace vsel {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
+namespace bwd {
+
+constexpr int kD = 128;            // head_dim
+constexpr int kRowB = 256;         // bytes per row of a tile
+constexpr int kTile = 64;          // rows per LDS tile
+constexpr int kTileB = kTile * kRowB;   // 16 KiB
+constexpr float kLog2e = 1.4426950408889634f;
+
+__device__ __forceinline__ bf16x8_t as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8_t, v); }
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int chunk_off(int row, int part) { return row * kRowB + ((part ^ swz(row)) << 4); }
+
+// A operand, row form: lane (j, hh) reads 16 bytes = elements 16*st + 8*hh .. +7 of tile row `row`.
+__device__ __forceinline__ bf16x8_t row_frag(const char* tile, int row, int st, int hh) {
+  return as_bf16x8(*reinterpret_cast<const u32x4*>(tile + chunk_off(row, 2 * st + hh)));
+}
+
+// A operand, transposed form: returns for lane (i = lane & 31, hh) the 8 consecutive rows rbase .. rbase+7 of tile column
+// 32*dt + i (hardware transpose read; 16-lane group p supplies the address of row p >> 2, 4-column chunk p & 3).
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int rbase, int dt, int lane) {
+  typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
+  const int p16 = lane & 15;
+  const int part = 4 * dt + 2 * ((lane >> 4) & 1) + ((p16 & 3) >> 1);
+  const int sub = 8 * (p16 & 1);
+  const int r0 = rbase + (p16 >> 2), r1 = r0 + 4;
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(tile + chunk_off(r0, part) + sub));
+  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(tile + chunk_off(r1, part) + sub));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// D[t, h] = sum_d dO[t,h,d] * O[t,h,d]  (fp32).  16 lanes per (t, h) row, 4 rows per wave.
+__global__ __launch_bounds__(256) void attn_bwd_dot_kernel(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ out,
+                                                           int64_t rows, float* __restrict__ dvec) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  float acc = 0.f;
+  if (row < rows) {
+    const u32x4 a = *reinterpret_cast<const u32x4*>(dout + row * kD + (lane & 15) * 8);
+    const u32x4 b = *reinterpret_cast<const u32x4*>(out + row * kD + (lane & 15) * 8);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc = fmaf(__uint_as_float(aw[i] << 16), __uint_as_float(bw[i] << 16), acc);
+      acc = fmaf(__uint_as_float(aw[i] & 0xffff0000u), __uint_as_float(bw[i] & 0xffff0000u), acc);
+    }
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  acc += __shfl_xor(acc, 8, 64);
+  if (row < rows && (lane & 15) == 0) dvec[row] = acc;
+}
+
+__device__ int g_bwd_counter[64];
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dQ: the forward's loop with two extra contractions.  4 waves x 32 queries.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+    const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dvec,
+    const int32_t* __restrict__ cu, int hq, int hkv, float scale, int causal, uint16_t* __restrict__ dq, int q_tiles, int n_seq,
+    int slot) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * kTileB];       // K[2], V[2]
+  __shared__ int s_item;
+  char* const k_sm = smem;
+  char* const v_sm = smem + 2 * kTileB;
+  const int n_items = q_tiles * hq * n_seq;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  const int key_row = (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1);     // see attn.hip: makes C regs 8m..8m+7 consecutive keys
+  const float sl2 = scale * kLog2e;
+
+  for (int round = 0;; ++round) {
+    int item;
+    if (slot < 0) {
+      if (round > 0) return;
+      item = blockIdx.x;
+    } else {
+      if (tid == 0) s_item = atomicAdd(&g_bwd_counter[slot], 1);
+      __syncthreads();
+      item = s_item;
+      __syncthreads();
+    }
+    if (item >= n_items) return;
+    const int qtile = q_tiles - 1 - item / (hq * n_seq);
+    const int rest = item % (hq * n_seq);
+    const int head = rest % hq, seq = rest / hq;
+    const int qs = cu[seq];
+    const int len = cu[seq + 1] - qs;
+    const int q0 = qtile * 128;
+    if (q0 >= len) continue;
+    const int kvh = head / (hq / hkv);
+    const int my_q = min(q0 + wave * 32 + j, len - 1);
+    const bool q_valid = (q0 + wave * 32 + j) < len;
+    const int wave_qmax = min(q0 + wave * 32 + 31, len - 1);
+
+    u32x4 qf[8], dof[8];
+    {
+      const int64_t ro = ((int64_t)(qs + my_q) * hq + head) * kD + 8 * hh;
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        qf[st] = *reinterpret_cast<const u32x4*>(q + ro + 16 * st);
+        dof[st] = *reinterpret_cast<const u32x4*>(dout + ro + 16 * st);
+      }
+    }
+    const float lse2 = lse[(int64_t)(qs + my_q) * hq + head] * kLog2e;
+    const float dsum = dvec[(int64_t)(qs + my_q) * hq + head];
+    f32x16 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+
+    const int kv_end = causal ? min(len, q0 + 128) : len;
+    const int n_tiles = (kv_end + kTile - 1) / kTile;
+    u32x4 kreg[4], vreg[4];
+    auto load_tile = [&](int t) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = tid + 256 * u;
+        const int kpos = min(t * kTile + (c >> 4), len - 1);
+        const int64_t off = ((int64_t)(qs + kpos) * hkv + kvh) * kD + (c & 15) * 8;
+        kreg[u] = *reinterpret_cast<const u32x4*>(k + off);
+        vreg[u] = *reinterpret_cast<const u32x4*>(v + off);
+      }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = tid + 256 * u;
+        const int o = chunk_off(c >> 4, c & 15);
+        *reinterpret_cast<u32x4*>(k_sm + buf * kTileB + o) = kreg[u];
+        *reinterpret_cast<u32x4*>(v_sm + buf * kTileB + o) = vreg[u];
+      }
+    };
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < n_tiles; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < n_tiles) load_tile(t + 1);
+      const char* kt = k_sm + cur * kTileB;
+      const char* vt = v_sm + cur * kTileB;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int key0 = t * kTile + 32 * kb;
+        const bool active = __builtin_amdgcn_readfirstlane((int)(key0 < len && (!causal || key0 <= wave_qmax))) != 0;
+        if (!active) continue;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        const int kl = 32 * kb + key_row;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, kl, st, hh), as_bf16x8(qf[st]), s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(vt, kl, st, hh), as_bf16x8(dof[st]), dp, 0, 0, 0);
+        }
+        const int kmax = causal ? min(len - 1, my_q) : len - 1;
+        bf16x8_t dsf[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + 16 * (r >> 3) + 8 * hh + (r & 7);
+          const float p = key <= kmax ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2)) : 0.f;
+          dsf[r >> 3][r & 7] = (__bf16)(p * (dp[r] - dsum));
+        }
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(kt, 32 * kb + 16 * mm + 8 * hh, dt, lane), dsf[mm], acc[dt],
+                                                              0, 0, 0);
+      }
+      if (t + 1 < n_tiles) store_tile(cur ^ 1);
+      __syncthreads();
+    }
+
+    if (q_valid) {
+      uint16_t* op = dq + ((int64_t)(qs + my_q) * hq + head) * kD;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int d0 = 32 * dt + 8 * g4 + 4 * hh;
+          uint2 pk;
+          pk.x = f32_to_bf16_bits(acc[dt][4 * g4] * scale) | (f32_to_bf16_bits(acc[dt][4 * g4 + 1] * scale) << 16);
+          pk.y = f32_to_bf16_bits(acc[dt][4 * g4 + 2] * scale) | (f32_to_bf16_bits(acc[dt][4 * g4 + 3] * scale) << 16);
+          *reinterpret_cast<uint2*>(op + d0) = pk;
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dK, dV: 4 waves x 32 keys; K / V fragments in registers, Q / dO tiles of 64 queries streamed through LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+    const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dvec,
+    const int32_t* __restrict__ cu, int hq, int hkv, float scale, int causal, uint16_t* __restrict__ dk,
+    uint16_t* __restrict__ dv, int k_blocks, int n_seq, int slot) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * kTileB];       // Q[2], dO[2]
+  __shared__ __attribute__((aligned(16))) float lse_sm[2][kTile];
+  __shared__ __attribute__((aligned(16))) float d_sm[2][kTile];
+  __shared__ int s_item;
+  char* const q_sm = smem;
+  char* const do_sm = smem + 2 * kTileB;
+  const int n_items = k_blocks * hkv * n_seq;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  const int q_row = (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1);       // A-row permutation: C regs 8m..8m+7 = consecutive queries
+  const float sl2 = scale * kLog2e;
+  const int rep = hq / hkv;
+
+  for (int round = 0;; ++round) {
+    int item;
+    if (slot < 0) {
+      if (round > 0) return;
+      item = blockIdx.x;
+    } else {
+      if (tid == 0) s_item = atomicAdd(&g_bwd_counter[slot], 1);
+      __syncthreads();
+      item = s_item;
+      __syncthreads();
+    }
+    if (item >= n_items) return;
+    const int kblock = item / (hkv * n_seq);          // block 0 first: under the causal mask it is seen by the most queries
+    const int rest = item % (hkv * n_seq);
+    const int kvh = rest % hkv, seq = rest / hkv;
+    const int qs = cu[seq];
+    const int len = cu[seq + 1] - qs;
+    const int k0 = kblock * 128;
+    if (k0 >= len) continue;
+    const int kw0 = k0 + 32 * wave;
+    const int my_k = min(kw0 + j, len - 1);
+    const bool k_valid = (kw0 + j) < len;
+
+    u32x4 kf[8], vf[8];
+    {
+      const int64_t ro = ((int64_t)(qs + my_k) * hkv + kvh) * kD + 8 * hh;
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        kf[st] = *reinterpret_cast<const u32x4*>(k + ro + 16 * st);
+        vf[st] = *reinterpret_cast<const u32x4*>(v + ro + 16 * st);
+      }
+    }
+    f32x16 dka[4], dva[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dka[dt][r] = 0.f; dva[dt][r] = 0.f; }
+
+    const int q_begin = causal ? k0 : 0;                         // k0 is a multiple of 128, hence of the 64-query tile
+    const int tiles_per_head = (len - q_begin + kTile - 1) / kTile;
+    const int n_iter = tiles_per_head * rep;
+
+    u32x4 qreg[4], doreg[4];
+    float sreg = 0.f;                                            // tid < 64: lse*log2e of query tid; 64 <= tid < 128: D
+    auto load_tile = [&](int it) {
+      const int g = it / tiles_per_head, qt = q_begin + (it - g * tiles_per_head) * kTile;
+      const int head = kvh * rep + g;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = tid + 256 * u;
+        const int qpos = min(qt + (c >> 4), len - 1);
+        const int64_t off = ((int64_t)(qs + qpos) * hq + head) * kD + (c & 15) * 8;
+        qreg[u] = *reinterpret_cast<const u32x4*>(q + off);
+        doreg[u] = *reinterpret_cast<const u32x4*>(dout + off);
+      }
+      if (tid < 128) {
+        const int qi = qt + (tid & 63);
+        const int64_t o = (int64_t)(qs + min(qi, len - 1)) * hq + head;
+        // a padded query row gets lse = +inf so that its P (and dS) are exactly zero
+        sreg = tid < 64 ? (qi < len ? lse[o] * kLog2e : INFINITY) : dvec[o];
+      }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = tid + 256 * u;
+        const int o = chunk_off(c >> 4, c & 15);
+        *reinterpret_cast<u32x4*>(q_sm + buf * kTileB + o) = qreg[u];
+        *reinterpret_cast<u32x4*>(do_sm + buf * kTileB + o) = doreg[u];
+      }
+      if (tid < 64) lse_sm[buf][tid] = sreg;
+      else if (tid < 128) d_sm[buf][tid - 64] = sreg;
+    };
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int it = 0; it < n_iter; ++it) {
+      const int cur = it & 1;
+      if (it + 1 < n_iter) load_tile(it + 1);
+      const int qt = q_begin + (it % tiles_per_head) * kTile;
+      const char* qtile = q_sm + cur * kTileB;
+      const char* dotile = do_sm + cur * kTileB;
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const int qb0 = qt + 32 * qb;
+        const bool active = __builtin_amdgcn_readfirstlane((int)(qb0 < len && (!causal || qb0 + 31 >= kw0))) != 0;
+        if (!active) continue;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        const int ql = 32 * qb + q_row;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(qtile, ql, st, hh), as_bf16x8(kf[st]), s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dotile, ql, st, hh), as_bf16x8(vf[st]), dp, 0, 0, 0);
+        }
+        bf16x8_t pf[2], dsf[2];
+        const int my_key = kw0 + j;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int rb = 32 * qb + 16 * m + 8 * hh;             // tile row of register 8m
+          const f32x4 l0 = *reinterpret_cast<const f32x4*>(&lse_sm[cur][rb]);
+          const f32x4 l1 = *reinterpret_cast<const f32x4*>(&lse_sm[cur][rb + 4]);
+          const f32x4 e0 = *reinterpret_cast<const f32x4*>(&d_sm[cur][rb]);
+          const f32x4 e1 = *reinterpret_cast<const f32x4*>(&d_sm[cur][rb + 4]);
+          const float lv[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+          const float dv8[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int r = 8 * m + e;
+            const int query = qt + rb + e;
+            const bool vis = !causal || my_key <= query;
+            const float p = vis ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lv[e])) : 0.f;
+            pf[m][e] = (__bf16)p;
+            dsf[m][e] = (__bf16)(p * (dp[r] - dv8[e]));
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const int rbase = 32 * qb + 16 * m + 8 * hh;
+            dva[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dotile, rbase, dt, lane), pf[m], dva[dt], 0, 0, 0);
+            dka[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(qtile, rbase, dt, lane), dsf[m], dka[dt], 0, 0, 0);
+          }
+      }
+      if (it + 1 < n_iter) store_tile(cur ^ 1);
+      __syncthreads();
+    }
+
+    if (k_valid) {
+      const int64_t ro = ((int64_t)(qs + my_k) * hkv + kvh) * kD;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int d0 = 32 * dt + 8 * g4 + 4 * hh;
+          uint2 pk;
+          pk.x = f32_to_bf16_bits(dka[dt][4 * g4] * scale) | (f32_to_bf16_bits(dka[dt][4 * g4 + 1] * scale) << 16);
+          pk.y = f32_to_bf16_bits(dka[dt][4 * g4 + 2] * scale) | (f32_to_bf16_bits(dka[dt][4 * g4 + 3] * scale) << 16);
+          *reinterpret_cast<uint2*>(dk + ro + d0) = pk;
+          pk.x = f32_to_bf16_bits(dva[dt][4 * g4]) | (f32_to_bf16_bits(dva[dt][4 * g4 + 1]) << 16);
+          pk.y = f32_to_bf16_bits(dva[dt][4 * g4 + 2]) | (f32_to_bf16_bits(dva[dt][4 * g4 + 3]) << 16);
+          *reinterpret_cast<uint2*>(dv + ro + d0) = pk;
+        }
+    }
+  }
+}
+
+}  // namespace bwd
+}  // namespace vsel
+
+using namespace vsel;
+
+extern "C" size_t vsel_varlen_attn_bwd_workspace_bytes(int64_t total, int64_t hq) {
+  if (total < 1 || hq < 1) return 0;
+  return (size_t)total * (size_t)hq * sizeof(float);
+}
+
+extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* q, const void* k, const void* v, const void* out,
+                                    const float* lse, const int32_t* cu_seqlens, int64_t n_seq, int64_t max_seqlen,
+                                    int64_t total, int64_t hq, int64_t hkv, int64_t d, float scale, int causal, void* workspace,
+                                    size_t workspace_bytes, void* dq, void* dk, void* dv) {
+  if (!dout || !q || !k || !v || !out || !lse || !cu_seqlens || !workspace || !dq || !dk || !dv)
+    return fail(VSEL_ERR_INVALID, "NULL pointer");
+  if (d != bwd::kD) return fail(VSEL_ERR_UNSUPPORTED, "head_dim %lld != 128", (long long)d);
+  if (n_seq < 1 || max_seqlen < 1 || total < 1 || hq < 1 || hkv < 1 || hq % hkv != 0 || n_seq > (1 << 24) || hq > 65535)
+    return fail(VSEL_ERR_INVALID, "bad attention shape (n_seq=%lld max_seqlen=%lld hq=%lld hkv=%lld)", (long long)n_seq,
+                (long long)max_seqlen, (long long)hq, (long long)hkv);
+  if (((uintptr_t)dout | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)dq | (uintptr_t)dk |
+       (uintptr_t)dv | (uintptr_t)workspace) & 15)
+    return fail(VSEL_ERR_INVALID, "attention tensors must be 16-byte aligned");
+  if (workspace_bytes < vsel_varlen_attn_bwd_workspace_bytes(total, hq)) return fail(VSEL_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(st);
+  float* dvec = (float*)workspace;
+  const int64_t rows = total * hq;
+  hipLaunchKernelGGL(bwd::attn_bwd_dot_kernel, dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, st, (const uint16_t*)dout,
+                     (const uint16_t*)out, rows, dvec);
+  VSEL_AFTER_LAUNCH(st, "attn_bwd_dot_kernel");
+
+  int* counters = nullptr;
+  VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(bwd::g_bwd_counter)));
+  static unsigned next_slot = 0;
+  auto take_slot = [&](int64_t n_items, int64_t resident, int& slot) -> int {
+    slot = -1;
+    if (n_items > resident) {
+      slot = (int)(next_slot++ & 63u);
+      if (hipMemsetAsync(counters + slot, 0, sizeof(int), st) != hipSuccess) return fail(VSEL_ERR_HIP, "hipMemsetAsync(counter)");
+    }
+    return VSEL_OK;
+  };
+  {
+    const int k_blocks = (int)cdiv(max_seqlen, 128);
+    const int64_t n_items = (int64_t)k_blocks * hkv * n_seq;
+    if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
+    int slot;
+    if (int rc = take_slot(n_items, 256, slot)) return rc;
+    hipLaunchKernelGGL(bwd::attn_bwd_dkdv_kernel, dim3((unsigned)std::min<int64_t>(n_items, 256)), dim3(256), 0, st,
+                       (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse, dvec, cu_seqlens,
+                       (int)hq, (int)hkv, scale, causal, (uint16_t*)dk, (uint16_t*)dv, k_blocks, (int)n_seq, slot);
+    VSEL_AFTER_LAUNCH(st, "attn_bwd_dkdv_kernel");
+  }
+  {
+    const int q_tiles = (int)cdiv(max_seqlen, 128);
+    const int64_t n_items = (int64_t)q_tiles * hq * n_seq;
+    if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
+    int slot;
+    if (int rc = take_slot(n_items, 512, slot)) return rc;
+    hipLaunchKernelGGL(bwd::attn_bwd_dq_kernel, dim3((unsigned)std::min<int64_t>(n_items, 512)), dim3(256), 0, st,
+                       (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse, dvec, cu_seqlens,
+                       (int)hq, (int)hkv, scale, causal, (uint16_t*)dq, q_tiles, (int)n_seq, slot);
+    VSEL_AFTER_LAUNCH(st, "attn_bwd_dq_kernel");
+  }
+  return VSEL_OK;
+}

@@ -413,6 +413,50 @@ def varlen_attn(q, k, v, cu_seqlens: torch.Tensor, max_seqlen: int, causal: bool
     return out
 
 
+def varlen_attn_fwd_lse(q, k, v, cu_seqlens: torch.Tensor, max_seqlen: int, causal: bool = True,
+                        softmax_scale: Optional[float] = None):
+    """varlen_attn that also returns lse fp32 [T, Hq] (log-sum-exp of the scaled visible scores) for varlen_attn_bwd."""
+    dev = _dev(q, k, v, cu_seqlens)
+    if q.dtype != torch.bfloat16 or k.dtype != torch.bfloat16 or v.dtype != torch.bfloat16:
+        raise TypeError("varlen_attn takes bfloat16 q/k/v")
+    if cu_seqlens.dtype != torch.int32:
+        raise TypeError("cu_seqlens must be int32")
+    t, hq, d = q.shape
+    hkv = k.shape[1]
+    scale = float(softmax_scale) if softmax_scale is not None else d ** -0.5
+    out = torch.empty_like(q)
+    lse = torch.empty(t, hq, dtype=torch.float32, device=dev)
+    N.check(N.lib().vsel_varlen_attn_fwd_lse(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), cu_seqlens.data_ptr(),
+                                             cu_seqlens.numel() - 1, int(max_seqlen), t, hq, hkv, d, scale, int(causal),
+                                             out.data_ptr(), lse.data_ptr()))
+    return out, lse
+
+
+def varlen_attn_bwd(dout, q, k, v, out, lse, cu_seqlens: torch.Tensor, max_seqlen: int, causal: bool = True,
+                    softmax_scale: Optional[float] = None):
+    """Backward of varlen_attn: dout/out/q [T,Hq,d], k/v [T,Hkv,d] bf16 contiguous, lse fp32 [T,Hq] -> (dq, dk, dv) bf16."""
+    dev = _dev(dout, q, k, v, out, lse, cu_seqlens)
+    for x in (dout, q, k, v, out):
+        if x.dtype != torch.bfloat16:
+            raise TypeError("varlen_attn_bwd takes bfloat16 tensors")
+        if not x.is_contiguous():
+            raise ValueError("varlen_attn_bwd takes contiguous tensors")
+    if lse.dtype != torch.float32 or cu_seqlens.dtype != torch.int32:
+        raise TypeError("lse must be float32 and cu_seqlens int32")
+    t, hq, d = q.shape
+    hkv = k.shape[1]
+    if dout.shape != q.shape or out.shape != q.shape or v.shape != k.shape or lse.shape != (t, hq):
+        raise ValueError("varlen_attn_bwd: shape mismatch")
+    scale = float(softmax_scale) if softmax_scale is not None else d ** -0.5
+    lib = N.lib()
+    ws = _workspace(lib.vsel_varlen_attn_bwd_workspace_bytes(t, hq), dev)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    N.check(lib.vsel_varlen_attn_bwd(_stream(), dout.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                     lse.data_ptr(), cu_seqlens.data_ptr(), cu_seqlens.numel() - 1, int(max_seqlen), t, hq, hkv,
+                                     d, scale, int(causal), ws.data_ptr(), ws.numel(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()))
+    return dq, dk, dv
+
+
 def paged_attn(q, k_cache, v_cache, cu_seqlens_q: torch.Tensor, seqlens_k: torch.Tensor, block_table: torch.Tensor,
                max_seqlen_q: int, causal: bool = True, softmax_scale: Optional[float] = None) -> torch.Tensor:
     """q [Tq,Hq,d] bf16; k_cache / v_cache [n_pages, page_size, Hkv, d] bf16; cu_seqlens_q int32 [S+1];

@@ -229,7 +229,7 @@ int vsel_paged_attn_fwd(void* stream, const void* q, const void* k_cache, const 
 int vsel_varlen_attn_fwd_lse(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens,
                              int64_t n_seq, int64_t max_seqlen, int64_t total, int64_t hq, int64_t hkv, int64_t d,
                              float scale, int causal, void* out, float* lse);
-size_t vsel_varlen_attn_bwd_workspace_bytes(int64_t total, int64_t hq);
+size_t vsel_varlen_attn_bwd_workspace_bytes(int64_t total, int64_t hq, int64_t hkv, int64_t n_seq, int64_t max_seqlen);
 int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* q, const void* k, const void* v, const void* out,
                          const float* lse, const int32_t* cu_seqlens, int64_t n_seq, int64_t max_seqlen, int64_t total,
                          int64_t hq, int64_t hkv, int64_t d, float scale, int causal, void* workspace,

@@ -199,8 +199,18 @@ def test_attention_interface_registration():
                                              is_causal=True).transpose(1, 2)
     assert out.shape == (2, 200, 8, 128)
     assert float((out.float() - ref).abs().max()) <= 2e-2 and float((out.float() - ref).abs().mean()) <= 1e-3
-    with pytest.raises(RuntimeError, match="forward pass only"):
-        vsel_attention_forward(None, q.requires_grad_(True), k, v, None)
+    # training: gradients flow through the native backward (the reference trains through flash_attn's), vs SDPA autograd
+    qg, kg, vg = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    out_g, _ = vsel_attention_forward(None, qg, kg, vg, None, scaling=128 ** -0.5, is_causal=True)
+    assert torch.equal(out_g, out)
+    go = torch.randn(out.shape, device="cuda", generator=g).bfloat16()
+    out_g.backward(go)
+    qr, kr, vr = [t.float().clone().requires_grad_(True) for t in (q, k, v)]
+    F.scaled_dot_product_attention(qr, kr.repeat_interleave(4, 1), vr.repeat_interleave(4, 1),
+                                   is_causal=True).transpose(1, 2).backward(go.float())
+    for got, want in ((qg.grad, qr.grad), (kg.grad, kr.grad), (vg.grad, vr.grad)):
+        # TOLERANCE 2^-6 of the tensor's max magnitude: bf16 gradients + bf16-rounded P / dS operands
+        assert float((got.float() - want).abs().max()) <= 2 ** -6 * float(want.abs().max())
 
 
 def test_native_lis_trainer_reduces_loss_and_checkpoints(tmp_path):

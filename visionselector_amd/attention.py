@@ -6,8 +6,9 @@
   vsel_attention_forward(...)            transformers-5.x AttentionInterface signature (prefill of the *_Selector models;
                                          replaces Qwen2_5_VLFlashAttention2.forward -> flash_attn of
                                          qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py:827-918)
-Forward only (inference prefill + frozen-LLM activations are out of this round's backward scope): tensors that require
-grad are rejected loudly rather than silently detached.
+Training: when q / k / v require grad (the reference trains the LIS through the frozen LLM, so every attention layer
+back-propagates), the call goes through _VarlenAttnFunction = vsel_varlen_attn_fwd_lse + vsel_varlen_attn_bwd (the role of
+FlashAttnVarlenFunc behind trainer.py:101-113).  There is no eager / CPU fallback.
 """
 from __future__ import annotations
 
@@ -20,10 +21,31 @@ from . import ops
 ATTN_NAME = "vsel_varlen"
 
 
-def _check_no_grad(*ts):
-    if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
-        raise RuntimeError("vsel var-len attention implements the forward pass only; run under torch.no_grad() "
-                           "or keep the LLM's attention on its stock implementation for training")
+class _VarlenAttnFunction(torch.autograd.Function):
+    """q [T,Hq,d], k/v [T,Hkv,d] bf16 contiguous, cu_seqlens int32 [S+1] -> out [T,Hq,d]; saves (q, k, v, out, lse)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, cu_seqlens, max_seqlen, causal, softmax_scale):
+        out, lse = ops.varlen_attn_fwd_lse(q, k, v, cu_seqlens, max_seqlen, causal=causal, softmax_scale=softmax_scale)
+        ctx.save_for_backward(q, k, v, out, lse, cu_seqlens)
+        ctx.meta = (max_seqlen, causal, softmax_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse, cu_seqlens = ctx.saved_tensors
+        max_seqlen, causal, softmax_scale = ctx.meta
+        dq, dk, dv = ops.varlen_attn_bwd(dout.contiguous(), q, k, v, out, lse, cu_seqlens, max_seqlen, causal=causal,
+                                         softmax_scale=softmax_scale)
+        return dq, dk, dv, None, None, None, None
+
+
+def varlen_attention(q, k, v, cu_seqlens, max_seqlen: int, causal: bool = True, softmax_scale: Optional[float] = None):
+    """Differentiable var-len attention: the plain forward kernel under no_grad / for tensors without grad, otherwise the
+    LSE-saving forward with the native backward."""
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        return _VarlenAttnFunction.apply(q, k, v, cu_seqlens, int(max_seqlen), bool(causal), softmax_scale)
+    return ops.varlen_attn(q, k, v, cu_seqlens, max_seqlen, causal=causal, softmax_scale=softmax_scale)
 
 
 def _flash_attention_forward(query_states, key_states, value_states, attention_mask, query_length, is_causal,
@@ -37,13 +59,12 @@ def _flash_attention_forward(query_states, key_states, value_states, attention_m
         raise NotImplementedError("attention dropout is not supported")
     if softcap is not None or sliding_window is not None:
         raise NotImplementedError("softcap / sliding_window are not supported")
-    _check_no_grad(query_states, key_states, value_states)
     q, k, v = (t.squeeze(0).contiguous() for t in (query_states, key_states, value_states))
     cu_seqlens = attention_mask.to(torch.int32).contiguous()                                # :79
     with torch.no_grad():
         max_seqlen = int((cu_seqlens[1:] - cu_seqlens[:-1]).max().item())                  # :81-87 (host sync, as the reference)
     causal = is_causal if not use_top_left_mask else (is_causal and query_length != 1)      # :89-93
-    out = ops.varlen_attn(q, k, v, cu_seqlens, max_seqlen, causal=bool(causal), softmax_scale=softmax_scale)
+    out = varlen_attention(q, k, v, cu_seqlens, max_seqlen, causal=bool(causal), softmax_scale=softmax_scale)
     return out.unsqueeze(0)
 
 
@@ -59,7 +80,6 @@ def vsel_attention_forward(module, query, key, value, attention_mask, dropout: f
     (or the packed cu_seq_lens_q kwarg when the batch is flattened).  Returns (attn_output [B, Lq, Hq, d], None)."""
     if dropout:
         raise NotImplementedError("attention dropout is not supported")
-    _check_no_grad(query, key, value)
     b, hq, lq, d = query.shape
     lk = key.shape[2]
     if lq != lk:
@@ -75,7 +95,7 @@ def vsel_attention_forward(module, query, key, value, attention_mask, dropout: f
         cu = torch.arange(0, (b + 1) * lq, lq, dtype=torch.int32, device=query.device)
         max_len = lq
     causal = True if is_causal is None else bool(is_causal)
-    out = ops.varlen_attn(q, k, v, cu, max_len, causal=causal, softmax_scale=scaling)
+    out = varlen_attention(q, k, v, cu, max_len, causal=causal, softmax_scale=scaling)
     return out.view(b, lq, hq, d), None
 
 

@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace vsel {
 
@@ -223,23 +224,41 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
 // ---------------------------------------------------------------------------------------------------------------------
 // dK, dV: 4 waves x 32 keys; K / V fragments in registers, Q / dO tiles of 64 queries streamed through LDS.
 // ---------------------------------------------------------------------------------------------------------------------
+// SPLIT = false: item = (key block, kv head, sequence), the q heads of the group are looped inside and dK / dV leave as bf16.
+// SPLIT = true (few items: short or few sequences): item = (key block, Q head, sequence), 7x (rep x) more parallelism and an
+// rep x shorter critical path; each item writes its fp32 partial [T, hq, 128] and attn_bwd_group_sum_kernel adds the heads
+// of a group in fixed order -- still no atomics.
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
     const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dvec,
     const int32_t* __restrict__ cu, int hq, int hkv, float scale, int causal, uint16_t* __restrict__ dk,
-    uint16_t* __restrict__ dv, int k_blocks, int n_seq, int slot) {
+    uint16_t* __restrict__ dv, float* __restrict__ dk_part, float* __restrict__ dv_part, int k_blocks, int n_seq, int slot) {
   __shared__ __attribute__((aligned(16))) char smem[4 * kTileB];       // Q[2], dO[2]
   __shared__ __attribute__((aligned(16))) float lse_sm[2][kTile];
   __shared__ __attribute__((aligned(16))) float d_sm[2][kTile];
   __shared__ int s_item;
   char* const q_sm = smem;
   char* const do_sm = smem + 2 * kTileB;
-  const int n_items = k_blocks * hkv * n_seq;
+  const int heads_per_item_dim = SPLIT ? hq : hkv;
+  const int n_items = k_blocks * heads_per_item_dim * n_seq;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hh = lane >> 5;
   const int q_row = (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1);       // A-row permutation: C regs 8m..8m+7 = consecutive queries
   const float sl2 = scale * kLog2e;
   const int rep = hq / hkv;
+  // per-lane LDS byte offsets inside a tile; the buffer, the 32-query sub-block and the 16-row step add immediates
+  int row_addr[8], tr_addr[4][2];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) row_addr[st] = chunk_off(q_row, 2 * st + hh);
+  {
+    const int p16 = lane & 15;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int hi = 0; hi < 2; ++hi)
+        tr_addr[dt][hi] = chunk_off(8 * hh + (p16 >> 2) + 4 * hi, 4 * dt + 2 * ((lane >> 4) & 1) + ((p16 & 3) >> 1)) + 8 * (p16 & 1);
+  }
 
   for (int round = 0;; ++round) {
     int item;
@@ -253,9 +272,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
       __syncthreads();
     }
     if (item >= n_items) return;
-    const int kblock = item / (hkv * n_seq);          // block 0 first: under the causal mask it is seen by the most queries
-    const int rest = item % (hkv * n_seq);
-    const int kvh = rest % hkv, seq = rest / hkv;
+    const int kblock = item / (heads_per_item_dim * n_seq);   // block 0 first: under the causal mask it is seen by the most queries
+    const int rest = item % (heads_per_item_dim * n_seq);
+    const int hsel = rest % heads_per_item_dim, seq = rest / heads_per_item_dim;
+    const int kvh = SPLIT ? hsel / rep : hsel;
     const int qs = cu[seq];
     const int len = cu[seq + 1] - qs;
     const int k0 = kblock * 128;
@@ -281,27 +301,28 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
 
     const int q_begin = causal ? k0 : 0;                         // k0 is a multiple of 128, hence of the 64-query tile
     const int tiles_per_head = (len - q_begin + kTile - 1) / kTile;
-    const int n_iter = tiles_per_head * rep;
+    const int n_iter = SPLIT ? tiles_per_head : tiles_per_head * rep;
 
     u32x4 qreg[4], doreg[4];
     float sreg = 0.f;                                            // tid < 64: lse*log2e of query tid; 64 <= tid < 128: D
-    auto load_tile = [&](int it) {
-      const int g = it / tiles_per_head, qt = q_begin + (it - g * tiles_per_head) * kTile;
-      const int head = kvh * rep + g;
+    int ld_qt = q_begin, ld_head = SPLIT ? hsel : kvh * rep;     // (query tile, head) of the NEXT tile to load
+    auto load_tile = [&]() {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = tid + 256 * u;
-        const int qpos = min(qt + (c >> 4), len - 1);
-        const int64_t off = ((int64_t)(qs + qpos) * hq + head) * kD + (c & 15) * 8;
+        const int qpos = min(ld_qt + (c >> 4), len - 1);
+        const int64_t off = ((int64_t)(qs + qpos) * hq + ld_head) * kD + (c & 15) * 8;
         qreg[u] = *reinterpret_cast<const u32x4*>(q + off);
         doreg[u] = *reinterpret_cast<const u32x4*>(dout + off);
       }
       if (tid < 128) {
-        const int qi = qt + (tid & 63);
-        const int64_t o = (int64_t)(qs + min(qi, len - 1)) * hq + head;
+        const int qi = ld_qt + (tid & 63);
+        const int64_t o = (int64_t)(qs + min(qi, len - 1)) * hq + ld_head;
         // a padded query row gets lse = +inf so that its P (and dS) are exactly zero
         sreg = tid < 64 ? (qi < len ? lse[o] * kLog2e : INFINITY) : dvec[o];
       }
+      ld_qt += kTile;
+      if (ld_qt >= len) { ld_qt = q_begin; ++ld_head; }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
@@ -314,65 +335,111 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
       if (tid < 64) lse_sm[buf][tid] = sreg;
       else if (tid < 128) d_sm[buf][tid - 64] = sreg;
     };
-    load_tile(0);
+    load_tile();
     store_tile(0);
     __syncthreads();
 
-    for (int it = 0; it < n_iter; ++it) {
-      const int cur = it & 1;
-      if (it + 1 < n_iter) load_tile(it + 1);
-      const int qt = q_begin + (it % tiles_per_head) * kTile;
-      const char* qtile = q_sm + cur * kTileB;
-      const char* dotile = do_sm + cur * kTileB;
+    int qt = q_begin;                                            // query tile being processed
+    // one 64-query tile from LDS buffer CUR (compile-time, so that every LDS address is a per-lane base + an immediate)
+    auto tile_body = [&](auto cur_c) {
+      constexpr int CUR = decltype(cur_c)::value;
+      const bool visible = __builtin_amdgcn_readfirstlane((int)(!causal || qt + kTile - 1 >= kw0)) != 0;
+      if (visible) {
+        const bool need_mask = __builtin_amdgcn_readfirstlane((int)(causal && kw0 + 31 > qt)) != 0;
+        const char* qtile = smem + CUR * kTileB;
+        const char* dotile = smem + (2 + CUR) * kTileB;
+        f32x16 s[2], dp[2];
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const int qb0 = qt + 32 * qb;
-        const bool active = __builtin_amdgcn_readfirstlane((int)(qb0 < len && (!causal || qb0 + 31 >= kw0))) != 0;
-        if (!active) continue;
-        f32x16 s, dp;
+        for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-        const int ql = 32 * qb + q_row;
+          for (int r = 0; r < 16; ++r) { s[qb][r] = 0.f; dp[qb][r] = 0.f; }
 #pragma unroll
-        for (int st = 0; st < 8; ++st) {
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(qtile, ql, st, hh), as_bf16x8(kf[st]), s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dotile, ql, st, hh), as_bf16x8(vf[st]), dp, 0, 0, 0);
-        }
-        bf16x8_t pf[2], dsf[2];
-        const int my_key = kw0 + j;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const int rb = 32 * qb + 16 * m + 8 * hh;             // tile row of register 8m
-          const f32x4 l0 = *reinterpret_cast<const f32x4*>(&lse_sm[cur][rb]);
-          const f32x4 l1 = *reinterpret_cast<const f32x4*>(&lse_sm[cur][rb + 4]);
-          const f32x4 e0 = *reinterpret_cast<const f32x4*>(&d_sm[cur][rb]);
-          const f32x4 e1 = *reinterpret_cast<const f32x4*>(&d_sm[cur][rb + 4]);
-          const float lv[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-          const float dv8[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int r = 8 * m + e;
-            const int query = qt + rb + e;
-            const bool vis = !causal || my_key <= query;
-            const float p = vis ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lv[e])) : 0.f;
-            pf[m][e] = (__bf16)p;
-            dsf[m][e] = (__bf16)(p * (dp[r] - dv8[e]));
+          for (int st = 0; st < 8; ++st) {
+            const bf16x8_t aq = as_bf16x8(*reinterpret_cast<const u32x4*>(qtile + row_addr[st] + qb * 32 * kRowB));
+            const bf16x8_t ad = as_bf16x8(*reinterpret_cast<const u32x4*>(dotile + row_addr[st] + qb * 32 * kRowB));
+            s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, as_bf16x8(kf[st]), s[qb], 0, 0, 0);
+            dp[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, as_bf16x8(vf[st]), dp[qb], 0, 0, 0);
           }
         }
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int qb = 0; qb < 2; ++qb) {
+          bf16x8_t pf[2], dsf[2];
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            const int rbase = 32 * qb + 16 * m + 8 * hh;
-            dva[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dotile, rbase, dt, lane), pf[m], dva[dt], 0, 0, 0);
-            dka[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(qtile, rbase, dt, lane), dsf[m], dka[dt], 0, 0, 0);
+          for (int m = 0; m < 2; ++m) {
+            const int rb = 32 * qb + 16 * m;                      // + 8*hh through the per-lane base
+            const f32x4 l0 = *reinterpret_cast<const f32x4*>(&lse_sm[CUR][rb] + 8 * hh);
+            const f32x4 l1 = *reinterpret_cast<const f32x4*>(&lse_sm[CUR][rb + 4] + 8 * hh);
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(&d_sm[CUR][rb] + 8 * hh);
+            const f32x4 e1 = *reinterpret_cast<const f32x4*>(&d_sm[CUR][rb + 4] + 8 * hh);
+            const float lv[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+            const float dv8[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+            if (need_mask) {
+              const int rel = kw0 + j - (qt + rb + 8 * hh);       // key visible iff rel <= e
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int r = 8 * m + e;
+                const float p = rel <= e ? __builtin_amdgcn_exp2f(fmaf(s[qb][r], sl2, -lv[e])) : 0.f;
+                pf[m][e] = (__bf16)p;
+                dsf[m][e] = (__bf16)(p * (dp[qb][r] - dv8[e]));
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int r = 8 * m + e;
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[qb][r], sl2, -lv[e]));
+                pf[m][e] = (__bf16)p;
+                dsf[m][e] = (__bf16)(p * (dp[qb][r] - dv8[e]));
+              }
+            }
           }
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+              typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
+              const int off = (32 * qb + 16 * m) * kRowB;
+              const bf16x4_t d_lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dotile + tr_addr[dt][0] + off));
+              const bf16x4_t d_hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dotile + tr_addr[dt][1] + off));
+              const bf16x4_t q_lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(qtile + tr_addr[dt][0] + off));
+              const bf16x4_t q_hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(qtile + tr_addr[dt][1] + off));
+              dva[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(d_lo, d_hi, 0, 1, 2, 3, 4, 5, 6, 7), pf[m],
+                                                                dva[dt], 0, 0, 0);
+              dka[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(q_lo, q_hi, 0, 1, 2, 3, 4, 5, 6, 7), dsf[m],
+                                                                dka[dt], 0, 0, 0);
+            }
+        }
       }
-      if (it + 1 < n_iter) store_tile(cur ^ 1);
+      qt += kTile;
+      if (qt >= len) qt = q_begin;
+    };
+
+    for (int it = 0; it < n_iter; it += 2) {
+      if (it + 1 < n_iter) load_tile();
+      tile_body(std::integral_constant<int, 0>{});
+      if (it + 1 < n_iter) store_tile(1);
+      __syncthreads();
+      if (it + 1 >= n_iter) break;
+      if (it + 2 < n_iter) load_tile();
+      tile_body(std::integral_constant<int, 1>{});
+      if (it + 2 < n_iter) store_tile(0);
       __syncthreads();
     }
 
-    if (k_valid) {
+    if (SPLIT) {
+      if (k_valid) {
+        const int64_t ro = ((int64_t)(qs + my_k) * hq + hsel) * kD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int d0 = 32 * dt + 8 * g4 + 4 * hh;
+            *reinterpret_cast<f32x4*>(dk_part + ro + d0) =
+                f32x4{dka[dt][4 * g4], dka[dt][4 * g4 + 1], dka[dt][4 * g4 + 2], dka[dt][4 * g4 + 3]};
+            *reinterpret_cast<f32x4*>(dv_part + ro + d0) =
+                f32x4{dva[dt][4 * g4], dva[dt][4 * g4 + 1], dva[dt][4 * g4 + 2], dva[dt][4 * g4 + 3]};
+          }
+      }
+    } else if (k_valid) {
       const int64_t ro = ((int64_t)(qs + my_k) * hkv + kvh) * kD;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
@@ -391,14 +458,57 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
   }
 }
 
+// dK[t, g, :] = scale * sum_{h in group g} dk_part[t, h, :] (heads added in ascending order), dV likewise without the scale.
+// One thread per 4 consecutive d.
+__global__ __launch_bounds__(256) void attn_bwd_group_sum_kernel(const float* __restrict__ dk_part, const float* __restrict__ dv_part,
+                                                                 int64_t total, int hq, int hkv, float scale,
+                                                                 uint16_t* __restrict__ dk, uint16_t* __restrict__ dv) {
+  const int rep = hq / hkv;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // over total * hkv * 32
+  if (idx >= total * hkv * 32) return;
+  const int c = (int)(idx & 31);
+  const int64_t tg = idx >> 5;
+  const int g = (int)(tg % hkv);
+  const int64_t t = tg / hkv;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < rep; ++r) {
+    const int64_t o = ((t * hq + g * rep + r) * kD) + 4 * c;
+    a += *reinterpret_cast<const f32x4*>(dk_part + o);
+    b += *reinterpret_cast<const f32x4*>(dv_part + o);
+  }
+  uint2 pk;
+  pk.x = f32_to_bf16_bits(a.x * scale) | (f32_to_bf16_bits(a.y * scale) << 16);
+  pk.y = f32_to_bf16_bits(a.z * scale) | (f32_to_bf16_bits(a.w * scale) << 16);
+  *reinterpret_cast<uint2*>(dk + tg * kD + 4 * c) = pk;
+  pk.x = f32_to_bf16_bits(b.x) | (f32_to_bf16_bits(b.y) << 16);
+  pk.y = f32_to_bf16_bits(b.z) | (f32_to_bf16_bits(b.w) << 16);
+  *reinterpret_cast<uint2*>(dv + tg * kD + 4 * c) = pk;
+}
+
 }  // namespace bwd
 }  // namespace vsel
 
 using namespace vsel;
 
-extern "C" size_t vsel_varlen_attn_bwd_workspace_bytes(int64_t total, int64_t hq) {
-  if (total < 1 || hq < 1) return 0;
-  return (size_t)total * (size_t)hq * sizeof(float);
+// Items of the in-kernel-group dK/dV pass below which the per-q-head split (fp32 partials + group sum) is used instead:
+// measured (tools/bench_attn_bwd.py): the split wins up to ~300 items (4 x 2368: 635 vs 802 us) and loses at 576 (16 x 1100).
+static constexpr int64_t kSplitBelowItems = 512;
+static int g_bwd_split = -1;       // -1 = choose by item count, 0 / 1 = force (tests)
+extern "C" void vsel_debug_attn_bwd_split(int mode) { g_bwd_split = mode; }
+
+static bool bwd_use_split(int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv) {
+  if (hq == hkv) return false;
+  if (g_bwd_split >= 0) return g_bwd_split != 0;
+  return cdiv(max_seqlen, 128) * hkv * n_seq < kSplitBelowItems;
+}
+
+extern "C" size_t vsel_varlen_attn_bwd_workspace_bytes(int64_t total, int64_t hq, int64_t hkv, int64_t n_seq, int64_t max_seqlen) {
+  if (total < 1 || hq < 1 || hkv < 1 || n_seq < 1 || max_seqlen < 1) return 0;
+  size_t bytes = (size_t)total * (size_t)hq * sizeof(float);                       // D
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bwd_use_split(n_seq, max_seqlen, hq, hkv))
+    bytes += 2 * (size_t)total * (size_t)hq * bwd::kD * sizeof(float);             // dK / dV partials per q head
+  return bytes;
 }
 
 extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* q, const void* k, const void* v, const void* out,
@@ -414,7 +524,8 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
   if (((uintptr_t)dout | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)dq | (uintptr_t)dk |
        (uintptr_t)dv | (uintptr_t)workspace) & 15)
     return fail(VSEL_ERR_INVALID, "attention tensors must be 16-byte aligned");
-  if (workspace_bytes < vsel_varlen_attn_bwd_workspace_bytes(total, hq)) return fail(VSEL_ERR_WORKSPACE, "workspace too small");
+  if (workspace_bytes < vsel_varlen_attn_bwd_workspace_bytes(total, hq, hkv, n_seq, max_seqlen))
+    return fail(VSEL_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
   VSEL_PROF_BEGIN(st);
   float* dvec = (float*)workspace;
@@ -435,15 +546,31 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
     return VSEL_OK;
   };
   {
+    const bool split = bwd_use_split(n_seq, max_seqlen, hq, hkv);
     const int k_blocks = (int)cdiv(max_seqlen, 128);
-    const int64_t n_items = (int64_t)k_blocks * hkv * n_seq;
+    const int64_t n_items = (int64_t)k_blocks * (split ? hq : hkv) * n_seq;
     if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
     int slot;
     if (int rc = take_slot(n_items, 256, slot)) return rc;
-    hipLaunchKernelGGL(bwd::attn_bwd_dkdv_kernel, dim3((unsigned)std::min<int64_t>(n_items, 256)), dim3(256), 0, st,
-                       (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse, dvec, cu_seqlens,
-                       (int)hq, (int)hkv, scale, causal, (uint16_t*)dk, (uint16_t*)dv, k_blocks, (int)n_seq, slot);
+    const size_t d_bytes = ((size_t)rows * sizeof(float) + 255) & ~(size_t)255;
+    float* dk_part = split ? (float*)((char*)workspace + d_bytes) : nullptr;
+    float* dv_part = split ? dk_part + (size_t)rows * bwd::kD : nullptr;
+    const dim3 grid((unsigned)std::min<int64_t>(n_items, 256));
+    if (split)
+      hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<true>), grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k,
+                         (const uint16_t*)v, (const uint16_t*)dout, lse, dvec, cu_seqlens, (int)hq, (int)hkv, scale, causal,
+                         (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, k_blocks, (int)n_seq, slot);
+    else
+      hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<false>), grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k,
+                         (const uint16_t*)v, (const uint16_t*)dout, lse, dvec, cu_seqlens, (int)hq, (int)hkv, scale, causal,
+                         (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, k_blocks, (int)n_seq, slot);
     VSEL_AFTER_LAUNCH(st, "attn_bwd_dkdv_kernel");
+    if (split) {
+      // rows past a sequence's end never exist in the packed layout, so every (t, h) partial row was written
+      hipLaunchKernelGGL(bwd::attn_bwd_group_sum_kernel, dim3((unsigned)cdiv(total * hkv * 32, 256)), dim3(256), 0, st, dk_part,
+                         dv_part, total, (int)hq, (int)hkv, scale, (uint16_t*)dk, (uint16_t*)dv);
+      VSEL_AFTER_LAUNCH(st, "attn_bwd_group_sum_kernel");
+    }
   }
   {
     const int q_tiles = (int)cdiv(max_seqlen, 128);

@@ -449,7 +449,7 @@ def varlen_attn_bwd(dout, q, k, v, out, lse, cu_seqlens: torch.Tensor, max_seqle
         raise ValueError("varlen_attn_bwd: shape mismatch")
     scale = float(softmax_scale) if softmax_scale is not None else d ** -0.5
     lib = N.lib()
-    ws = _workspace(lib.vsel_varlen_attn_bwd_workspace_bytes(t, hq), dev)
+    ws = _workspace(lib.vsel_varlen_attn_bwd_workspace_bytes(t, hq, hkv, cu_seqlens.numel() - 1, int(max_seqlen)), dev)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     N.check(lib.vsel_varlen_attn_bwd(_stream(), dout.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                      lse.data_ptr(), cu_seqlens.data_ptr(), cu_seqlens.numel() - 1, int(max_seqlen), t, hq, hkv,

@@ -58,8 +58,10 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int rbase, int dt,
 }
 
 // D[t, h] = sum_d dO[t,h,d] * O[t,h,d]  (fp32).  16 lanes per (t, h) row, 4 rows per wave.
+// Also rescales the forward's log-sum-exp to the exp2 domain once (lse2 = lse * log2(e)) for both backward kernels.
 __global__ __launch_bounds__(256) void attn_bwd_dot_kernel(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ out,
-                                                           int64_t rows, float* __restrict__ dvec) {
+                                                           const float* __restrict__ lse, int64_t rows,
+                                                           float* __restrict__ dvec, float* __restrict__ lse2) {
   const int lane = threadIdx.x & 63;
   const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
   float acc = 0.f;
@@ -77,7 +79,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dot_kernel(const uint16_t* __res
   acc += __shfl_xor(acc, 2, 64);
   acc += __shfl_xor(acc, 4, 64);
   acc += __shfl_xor(acc, 8, 64);
-  if (row < rows && (lane & 15) == 0) dvec[row] = acc;
+  if (row < rows && (lane & 15) == 0) {
+    dvec[row] = acc;
+    lse2[row] = lse[row] * kLog2e;
+  }
 }
 
 __device__ int g_bwd_counter[64];
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
         dof[st] = *reinterpret_cast<const u32x4*>(dout + ro + 16 * st);
       }
     }
-    const float lse2 = lse[(int64_t)(qs + my_q) * hq + head] * kLog2e;
+    const float lse2 = lse[(int64_t)(qs + my_q) * hq + head];          // already in the exp2 domain (attn_bwd_dot_kernel)
     const float dsum = dvec[(int64_t)(qs + my_q) * hq + head];
     f32x16 acc[4];
 #pragma unroll
@@ -303,40 +308,32 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
     const int tiles_per_head = (len - q_begin + kTile - 1) / kTile;
     const int n_iter = SPLIT ? tiles_per_head : tiles_per_head * rep;
 
-    u32x4 qreg[4], doreg[4];
-    float sreg = 0.f;                                            // tid < 64: lse*log2e of query tid; 64 <= tid < 128: D
+    // Q / dO tiles go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write pass).  The LDS
+    // image of such a load is lane-linear (wave-uniform base + 16 * lane), so the swizzle is applied to the SOURCE address:
+    // LDS position (row, part') receives global part part' ^ swz(row).  A wave-instruction covers 4 rows; wave w issues
+    // instructions w, w+4, w+8, w+12, for which swz(row) = ((lane >> 4) << 2) | w is a per-lane constant.
     int ld_qt = q_begin, ld_head = SPLIT ? hsel : kvh * rep;     // (query tile, head) of the NEXT tile to load
-    auto load_tile = [&]() {
+    const int ld_part = ((lane & 15) ^ (((lane >> 4) << 2) | wave)) * 8;
+    auto load_tile = [&](int buf) {
+      typedef const __attribute__((address_space(1))) void* gptr_t;
+      typedef __attribute__((address_space(3))) void* lptr_t;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int c = tid + 256 * u;
-        const int qpos = min(ld_qt + (c >> 4), len - 1);
-        const int64_t off = ((int64_t)(qs + qpos) * hq + ld_head) * kD + (c & 15) * 8;
-        qreg[u] = *reinterpret_cast<const u32x4*>(q + off);
-        doreg[u] = *reinterpret_cast<const u32x4*>(dout + off);
+        const int i = wave + 4 * u;
+        const int qpos = min(ld_qt + 4 * i + (lane >> 4), len - 1);
+        const int64_t off = ((int64_t)(qs + qpos) * hq + ld_head) * kD + ld_part;
+        __builtin_amdgcn_global_load_lds((gptr_t)(q + off), (lptr_t)(q_sm + buf * kTileB + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(dout + off), (lptr_t)(do_sm + buf * kTileB + i * 1024), 16, 0, 0);
       }
-      if (tid < 128) {
-        const int qi = ld_qt + (tid & 63);
-        const int64_t o = (int64_t)(qs + min(qi, len - 1)) * hq + ld_head;
-        // a padded query row gets lse = +inf so that its P (and dS) are exactly zero
-        sreg = tid < 64 ? (qi < len ? lse[o] * kLog2e : INFINITY) : dvec[o];
+      if (wave < 2) {
+        const int64_t o = (int64_t)(qs + min(ld_qt + lane, len - 1)) * hq + ld_head;
+        if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(lse + o), (lptr_t)(&lse_sm[buf][0]), 4, 0, 0);
+        else __builtin_amdgcn_global_load_lds((gptr_t)(dvec + o), (lptr_t)(&d_sm[buf][0]), 4, 0, 0);
       }
       ld_qt += kTile;
       if (ld_qt >= len) { ld_qt = q_begin; ++ld_head; }
     };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = tid + 256 * u;
-        const int o = chunk_off(c >> 4, c & 15);
-        *reinterpret_cast<u32x4*>(q_sm + buf * kTileB + o) = qreg[u];
-        *reinterpret_cast<u32x4*>(do_sm + buf * kTileB + o) = doreg[u];
-      }
-      if (tid < 64) lse_sm[buf][tid] = sreg;
-      else if (tid < 128) d_sm[buf][tid - 64] = sreg;
-    };
-    load_tile();
-    store_tile(0);
+    load_tile(0);
     __syncthreads();
 
     int qt = q_begin;                                            // query tile being processed
@@ -345,7 +342,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
       constexpr int CUR = decltype(cur_c)::value;
       const bool visible = __builtin_amdgcn_readfirstlane((int)(!causal || qt + kTile - 1 >= kw0)) != 0;
       if (visible) {
-        const bool need_mask = __builtin_amdgcn_readfirstlane((int)(causal && kw0 + 31 > qt)) != 0;
+        // the masked variant also zeroes the padded query rows of a head's last tile (their Q / dO rows replay row len-1)
+        const bool need_mask = __builtin_amdgcn_readfirstlane((int)((causal && kw0 + 31 > qt) || qt + kTile > len)) != 0;
         const char* qtile = smem + CUR * kTileB;
         const char* dotile = smem + (2 + CUR) * kTileB;
         f32x16 s[2], dp[2];
@@ -374,11 +372,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
             const float lv[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
             const float dv8[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
             if (need_mask) {
-              const int rel = kw0 + j - (qt + rb + 8 * hh);       // key visible iff rel <= e
+              const int rel = causal ? kw0 + j - (qt + rb + 8 * hh) : -(1 << 30);    // key visible iff rel <= e
+              const int qlim = len - (qt + rb + 8 * hh);                              // query row real iff e < qlim
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
                 const int r = 8 * m + e;
-                const float p = rel <= e ? __builtin_amdgcn_exp2f(fmaf(s[qb][r], sl2, -lv[e])) : 0.f;
+                const float p = (rel <= e && e < qlim) ? __builtin_amdgcn_exp2f(fmaf(s[qb][r], sl2, -lv[e])) : 0.f;
                 pf[m][e] = (__bf16)p;
                 dsf[m][e] = (__bf16)(p * (dp[qb][r] - dv8[e]));
               }
@@ -414,14 +413,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
     };
 
     for (int it = 0; it < n_iter; it += 2) {
-      if (it + 1 < n_iter) load_tile();
+      if (it + 1 < n_iter) load_tile(1);
       tile_body(std::integral_constant<int, 0>{});
-      if (it + 1 < n_iter) store_tile(1);
-      __syncthreads();
+      __syncthreads();                       // also drains this wave's global_load_lds queue (vmcnt(0)) before the release
       if (it + 1 >= n_iter) break;
-      if (it + 2 < n_iter) load_tile();
+      if (it + 2 < n_iter) load_tile(0);
       tile_body(std::integral_constant<int, 1>{});
-      if (it + 2 < n_iter) store_tile(0);
       __syncthreads();
     }
 
@@ -504,8 +501,7 @@ static bool bwd_use_split(int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t
 
 extern "C" size_t vsel_varlen_attn_bwd_workspace_bytes(int64_t total, int64_t hq, int64_t hkv, int64_t n_seq, int64_t max_seqlen) {
   if (total < 1 || hq < 1 || hkv < 1 || n_seq < 1 || max_seqlen < 1) return 0;
-  size_t bytes = (size_t)total * (size_t)hq * sizeof(float);                       // D
-  bytes = (bytes + 255) & ~(size_t)255;
+  size_t bytes = (((size_t)total * (size_t)hq * sizeof(float) + 255) & ~(size_t)255) * 2;   // D, lse * log2(e)
   if (bwd_use_split(n_seq, max_seqlen, hq, hkv))
     bytes += 2 * (size_t)total * (size_t)hq * bwd::kD * sizeof(float);             // dK / dV partials per q head
   return bytes;
@@ -528,10 +524,12 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
     return fail(VSEL_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
   VSEL_PROF_BEGIN(st);
-  float* dvec = (float*)workspace;
   const int64_t rows = total * hq;
+  const size_t d_bytes = ((size_t)rows * sizeof(float) + 255) & ~(size_t)255;
+  float* dvec = (float*)workspace;
+  float* lse2 = (float*)((char*)workspace + d_bytes);
   hipLaunchKernelGGL(bwd::attn_bwd_dot_kernel, dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, st, (const uint16_t*)dout,
-                     (const uint16_t*)out, rows, dvec);
+                     (const uint16_t*)out, lse, rows, dvec, lse2);
   VSEL_AFTER_LAUNCH(st, "attn_bwd_dot_kernel");
 
   int* counters = nullptr;
@@ -552,17 +550,16 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
     if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
     int slot;
     if (int rc = take_slot(n_items, 256, slot)) return rc;
-    const size_t d_bytes = ((size_t)rows * sizeof(float) + 255) & ~(size_t)255;
-    float* dk_part = split ? (float*)((char*)workspace + d_bytes) : nullptr;
+    float* dk_part = split ? (float*)((char*)workspace + 2 * d_bytes) : nullptr;
     float* dv_part = split ? dk_part + (size_t)rows * bwd::kD : nullptr;
     const dim3 grid((unsigned)std::min<int64_t>(n_items, 256));
     if (split)
       hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<true>), grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                         (const uint16_t*)v, (const uint16_t*)dout, lse, dvec, cu_seqlens, (int)hq, (int)hkv, scale, causal,
+                         (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu_seqlens, (int)hq, (int)hkv, scale, causal,
                          (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, k_blocks, (int)n_seq, slot);
     else
       hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<false>), grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                         (const uint16_t*)v, (const uint16_t*)dout, lse, dvec, cu_seqlens, (int)hq, (int)hkv, scale, causal,
+                         (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu_seqlens, (int)hq, (int)hkv, scale, causal,
                          (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, k_blocks, (int)n_seq, slot);
     VSEL_AFTER_LAUNCH(st, "attn_bwd_dkdv_kernel");
     if (split) {
@@ -579,7 +576,7 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
     int slot;
     if (int rc = take_slot(n_items, 512, slot)) return rc;
     hipLaunchKernelGGL(bwd::attn_bwd_dq_kernel, dim3((unsigned)std::min<int64_t>(n_items, 512)), dim3(256), 0, st,
-                       (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse, dvec, cu_seqlens,
+                       (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu_seqlens,
                        (int)hq, (int)hkv, scale, causal, (uint16_t*)dq, q_tiles, (int)n_seq, slot);
     VSEL_AFTER_LAUNCH(st, "attn_bwd_dq_kernel");
   }

@@ -104,6 +104,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
   const int j = lane & 31, hh = lane >> 5;
   const int key_row = (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1);     // see attn.hip: makes C regs 8m..8m+7 consecutive keys
   const float sl2 = scale * kLog2e;
+  // per-lane LDS byte offsets inside a tile; the buffer, the 32-key block and the 16-row step add immediates
+  int row_addr[8], tr_addr[4][2];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) row_addr[st] = chunk_off(key_row, 2 * st + hh);
+  {
+    const int p16 = lane & 15;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int hi = 0; hi < 2; ++hi)
+        tr_addr[dt][hi] = chunk_off(8 * hh + (p16 >> 2) + 4 * hi, 4 * dt + 2 * ((lane >> 4) & 1) + ((p16 & 3) >> 1)) + 8 * (p16 & 1);
+  }
 
   for (int round = 0;; ++round) {
     int item;
@@ -148,35 +160,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
 
     const int kv_end = causal ? min(len, q0 + 128) : len;
     const int n_tiles = (kv_end + kTile - 1) / kTile;
-    u32x4 kreg[4], vreg[4];
-    auto load_tile = [&](int t) {
+    // K / V tiles go global -> LDS directly (global_load_lds_dwordx4), swizzle applied to the source address (see the
+    // dK / dV kernel below); the mask is evaluated only on tiles that touch the causal diagonal or the end of the keys.
+    const int ld_part = ((lane & 15) ^ (((lane >> 4) << 2) | wave)) * 8;
+    auto load_tile = [&](int t, int buf) {
+      typedef const __attribute__((address_space(1))) void* gptr_t;
+      typedef __attribute__((address_space(3))) void* lptr_t;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int c = tid + 256 * u;
-        const int kpos = min(t * kTile + (c >> 4), len - 1);
-        const int64_t off = ((int64_t)(qs + kpos) * hkv + kvh) * kD + (c & 15) * 8;
-        kreg[u] = *reinterpret_cast<const u32x4*>(k + off);
-        vreg[u] = *reinterpret_cast<const u32x4*>(v + off);
+        const int i = wave + 4 * u;
+        const int kpos = min(t * kTile + 4 * i + (lane >> 4), len - 1);
+        const int64_t off = ((int64_t)(qs + kpos) * hkv + kvh) * kD + ld_part;
+        __builtin_amdgcn_global_load_lds((gptr_t)(k + off), (lptr_t)(k_sm + buf * kTileB + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(v + off), (lptr_t)(v_sm + buf * kTileB + i * 1024), 16, 0, 0);
       }
     };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = tid + 256 * u;
-        const int o = chunk_off(c >> 4, c & 15);
-        *reinterpret_cast<u32x4*>(k_sm + buf * kTileB + o) = kreg[u];
-        *reinterpret_cast<u32x4*>(v_sm + buf * kTileB + o) = vreg[u];
-      }
-    };
-    load_tile(0);
-    store_tile(0);
+    load_tile(0, 0);
     __syncthreads();
 
-    for (int t = 0; t < n_tiles; ++t) {
-      const int cur = t & 1;
-      if (t + 1 < n_tiles) load_tile(t + 1);
-      const char* kt = k_sm + cur * kTileB;
-      const char* vt = v_sm + cur * kTileB;
+    const int kmax = causal ? min(len - 1, my_q) : len - 1;      // last visible key of this lane's query
+    auto tile_body = [&](auto cur_c, int t) {
+      constexpr int CUR = decltype(cur_c)::value;
+      const char* kt = smem + CUR * kTileB;
+      const char* vt = smem + (2 + CUR) * kTileB;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const int key0 = t * kTile + 32 * kb;
@@ -185,28 +191,50 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-        const int kl = 32 * kb + key_row;
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, kl, st, hh), as_bf16x8(qf[st]), s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(vt, kl, st, hh), as_bf16x8(dof[st]), dp, 0, 0, 0);
+          const bf16x8_t ak = as_bf16x8(*reinterpret_cast<const u32x4*>(kt + row_addr[st] + kb * 32 * kRowB));
+          const bf16x8_t av = as_bf16x8(*reinterpret_cast<const u32x4*>(vt + row_addr[st] + kb * 32 * kRowB));
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, as_bf16x8(qf[st]), s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, as_bf16x8(dof[st]), dp, 0, 0, 0);
         }
-        const int kmax = causal ? min(len - 1, my_q) : len - 1;
+        const bool need_mask = __builtin_amdgcn_readfirstlane(
+            (int)(key0 + 32 > len || (causal && key0 + 31 > q0 + wave * 32))) != 0;
         bf16x8_t dsf[2];
+        if (need_mask) {
+          const int rel = kmax - (key0 + 8 * hh);                 // register r's key visible iff 16*(r>>3) + (r&7) <= rel
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = key0 + 16 * (r >> 3) + 8 * hh + (r & 7);
-          const float p = key <= kmax ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2)) : 0.f;
-          dsf[r >> 3][r & 7] = (__bf16)(p * (dp[r] - dsum));
+          for (int r = 0; r < 16; ++r) {
+            const float p = (16 * (r >> 3) + (r & 7)) <= rel ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2)) : 0.f;
+            dsf[r >> 3][r & 7] = (__bf16)(p * (dp[r] - dsum));
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2));
+            dsf[r >> 3][r & 7] = (__bf16)(p * (dp[r] - dsum));
+          }
         }
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt)
-            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(kt, 32 * kb + 16 * mm + 8 * hh, dt, lane), dsf[mm], acc[dt],
-                                                              0, 0, 0);
+          for (int dt = 0; dt < 4; ++dt) {
+            typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
+            const int off = (32 * kb + 16 * mm) * kRowB;
+            const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(kt + tr_addr[dt][0] + off));
+            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(kt + tr_addr[dt][1] + off));
+            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), dsf[mm],
+                                                              acc[dt], 0, 0, 0);
+          }
       }
-      if (t + 1 < n_tiles) store_tile(cur ^ 1);
+    };
+    for (int t = 0; t < n_tiles; t += 2) {
+      if (t + 1 < n_tiles) load_tile(t + 1, 1);
+      tile_body(std::integral_constant<int, 0>{}, t);
+      __syncthreads();                       // also drains this wave's global_load_lds queue before the release
+      if (t + 1 >= n_tiles) break;
+      if (t + 2 < n_tiles) load_tile(t + 2, 0);
+      tile_body(std::integral_constant<int, 1>{}, t + 1);
       __syncthreads();
     }
 

@@ -12,12 +12,15 @@
 //                 one query's scores -> row max / sum need a single cross-half exchange (lane ^ 32)
 //   O^T += V^T P^T (A = V^T fragment via ds_read_b64_tr_b16 from the row-major V tile, B = P^T packed to bf16 in
 //                 registers; the K rows are permuted (bits 2<->3) so each lane's P registers are 8 consecutive keys)
-//   K/V tiles of 64 keys are double-buffered in LDS, global loads for tile t+1 are issued before the math of tile t
-//   (register staged), K is XOR-swizzled (conflict-free ds_read_b128), V rows are padded to 320 B (conflict-free
-//   transpose reads).  Online softmax in exp2 domain, fp32.
+//   K/V tiles of 64 keys are double-buffered in LDS and arrive by global_load_lds_dwordx4 (global -> LDS, no staging
+//   registers, no ds_write pass) issued for tile t+1 before the math of tile t.  Both tiles use 256-byte rows with the
+//   16-byte part p of row r stored at p ^ swz(r), swz(r) = ((r & 3) << 2) | ((r >> 2) & 3): conflict-free for the K row
+//   reads (ds_read_b128) and for the V transpose reads (ds_read_b64_tr_b16); the direct loads write LDS lane-linearly,
+//   so the swizzle is applied to their SOURCE address.  Online softmax in exp2 domain, fp32.
 #include "common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace vsel {
 
@@ -26,11 +29,12 @@ typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kHeadDim = 128;
 constexpr int kTileK = 64;
-constexpr int kKRowBytes = 256;
-constexpr int kVRowBytes = 320;
-constexpr int kKBuf = kTileK * kKRowBytes;   // 16 KiB
-constexpr int kVBuf = kTileK * kVRowBytes;   // 20 KiB
-constexpr int kLds = 2 * kKBuf + 2 * kVBuf;  // 72 KiB
+constexpr int kRowBytes = 256;
+constexpr int kBuf = kTileK * kRowBytes;     // 16 KiB per tile
+constexpr int kLds = 4 * kBuf;               // K[2], V[2]: 64 KiB
+
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int chunk_off(int row, int part) { return row * kRowBytes + ((part ^ swz(row)) << 4); }
 
 __device__ __forceinline__ bf16x8_t to_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 
@@ -59,17 +63,32 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
                                                               float* __restrict__ lse) {
   constexpr int kBlockQ = 32 * NW;
   constexpr int kThreads = 64 * NW;
-  constexpr int kChunksPerThread = 1024 / kThreads;
+  constexpr int kLoadsPerWave = 16 / NW;           // 1-KiB wave-instructions per tile per tensor
   __shared__ __attribute__((aligned(16))) char smem[kLds];
   __shared__ int s_item;
   char* const k_sm = smem;
-  char* const v_sm = smem + 2 * kKBuf;
+  char* const v_sm = smem + 2 * kBuf;
   const int n_items = q_tiles * hq * n_seq;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hh = lane >> 5;
   // A-row i of the K operand holds key pi(i) (bits 2 and 3 swapped) so that C registers 8m..8m+7 of lane half hh are
   // the 8 consecutive keys 16m + 8hh .. +7 of the 32-key block.
   const int key_row = (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1);
+  // per-lane LDS byte offsets inside a tile; the buffer, the 32-key block and the 16-key step add immediates
+  int row_addr[8], tr_addr[4][2];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) row_addr[st] = chunk_off(key_row, 2 * st + hh);
+  {
+    const int p16 = lane & 15;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int hi = 0; hi < 2; ++hi)
+        tr_addr[dt][hi] = chunk_off(8 * hh + (p16 >> 2) + 4 * hi, 4 * dt + 2 * ((lane >> 4) & 1) + ((p16 & 3) >> 1)) + 8 * (p16 & 1);
+  }
+  // direct-to-LDS loads: wave w issues wave-instructions w, w + NW, ...; instruction i covers tile rows 4i .. 4i+3, lane l
+  // lands at (row 4i + (l >> 4), position l & 15) and therefore fetches global part (l & 15) ^ swz(row)
+  const int ld_part = ((lane & 15) ^ (((lane >> 4) << 2) | (wave & 3))) * 8;
 
   for (int round = 0;; ++round) {
   int item;
@@ -126,75 +145,52 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
     continue;
   }
 
-  // staging: 1024 16-byte chunks per tile per tensor, 4 per thread
-  u32x4 kreg[kChunksPerThread], vreg[kChunksPerThread];
-  // per-thread element offsets of its 4 chunks inside tile 0 (contiguous keys); a tile adds a wave-uniform stride
-  int64_t off0[kChunksPerThread];
-#pragma unroll
-  for (int u = 0; u < kChunksPerThread; ++u) {
-    const int c = tid + kThreads * u;
-    off0[u] = ((int64_t)(ks + (c >> 4)) * hkv + kvh) * kHeadDim + (c & 15) * 8;
-  }
-  const int64_t tile_stride = (int64_t)kTileK * hkv * kHeadDim;
-  auto load_tile = [&](int t) {
+  const int64_t kv_base = ((int64_t)ks * hkv + kvh) * kHeadDim + ld_part;        // contiguous keys: row r adds r * hkv * 128
+  auto load_tile = [&](int t, int buf) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
     const bool tail = __builtin_amdgcn_readfirstlane((int)(t * kTileK + kTileK > len)) != 0;
-    if (!pg.block_table && !tail) {
-      const uint16_t* kp = k + (int64_t)t * tile_stride;
-      const uint16_t* vp = v + (int64_t)t * tile_stride;
 #pragma unroll
-      for (int u = 0; u < kChunksPerThread; ++u) {
-        kreg[u] = *reinterpret_cast<const u32x4*>(kp + off0[u]);
-        vreg[u] = *reinterpret_cast<const u32x4*>(vp + off0[u]);
-      }
-      return;
-    }
-#pragma unroll
-    for (int u = 0; u < kChunksPerThread; ++u) {
-      const int c = tid + kThreads * u;
-      const int key = c >> 4, part = c & 15;
-      const int kpos = min(t * kTileK + key, len - 1);
-      int64_t row;
-      if (pg.block_table) {
-        const int page = kpos / pg.page_size;
-        row = (int64_t)pg.block_table[(int64_t)seq * pg.max_pages + page] * pg.page_size + (kpos - page * pg.page_size);
+    for (int u = 0; u < kLoadsPerWave; ++u) {
+      const int i = wave + NW * u;
+      const int key = 4 * i + (lane >> 4);
+      int64_t off;
+      if (!pg.block_table && !tail) {
+        off = kv_base + (int64_t)(t * kTileK + key) * hkv * kHeadDim;
       } else {
-        row = ks + kpos;
+        const int kpos = min(t * kTileK + key, len - 1);
+        int64_t row;
+        if (pg.block_table) {
+          const int page = kpos / pg.page_size;
+          row = (int64_t)pg.block_table[(int64_t)seq * pg.max_pages + page] * pg.page_size + (kpos - page * pg.page_size);
+        } else {
+          row = ks + kpos;
+        }
+        off = (row * hkv + kvh) * kHeadDim + ld_part;
       }
-      const int64_t off = (row * hkv + kvh) * kHeadDim + part * 8;
-      kreg[u] = *reinterpret_cast<const u32x4*>(k + off);
-      vreg[u] = *reinterpret_cast<const u32x4*>(v + off);
+      __builtin_amdgcn_global_load_lds((gptr_t)(k + off), (lptr_t)(k_sm + buf * kBuf + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(v + off), (lptr_t)(v_sm + buf * kBuf + i * 1024), 16, 0, 0);
     }
   };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int u = 0; u < kChunksPerThread; ++u) {
-      const int c = tid + kThreads * u;
-      const int key = c >> 4, part = c & 15;
-      *reinterpret_cast<u32x4*>(k_sm + buf * kKBuf + key * kKRowBytes + ((part ^ (key & 15)) << 4)) = kreg[u];
-      *reinterpret_cast<u32x4*>(v_sm + buf * kVBuf + key * kVRowBytes + part * 16) = vreg[u];
-    }
-  };
-  load_tile(0);
-  store_tile(0);
+  load_tile(0, 0);
   __syncthreads();
 
-  for (int t = 0; t < n_tiles; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < n_tiles) load_tile(t + 1);
+  // one 64-key tile from LDS buffer CUR (compile-time, so that every LDS address is a per-lane base + an immediate)
+  auto tile_body = [&](auto cur_c, int t) {
+    constexpr int CUR = decltype(cur_c)::value;
     const bool wave_active = !causal || (t * kTileK <= wave_qmax + shift);
     if (wave_active) {
+      const char* kt = smem + CUR * kBuf;
+      const char* vt = smem + (2 + CUR) * kBuf;
       // ---- S^T = K Q^T ----------------------------------------------------------------------------------------
       f32x16 s[2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-        const int kl = 32 * kb + key_row;
-        const char* krow = k_sm + cur * kKBuf + kl * kKRowBytes;
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
-          const int part = 2 * st + hh;
-          const u32x4 a = *reinterpret_cast<const u32x4*>(krow + ((part ^ (kl & 15)) << 4));
+          const u32x4 a = *reinterpret_cast<const u32x4*>(kt + row_addr[st] + kb * 32 * kRowBytes);
           s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(a), to_bf16x8(qf[st]), s[kb], 0, 0, 0);
         }
       }
@@ -245,36 +241,39 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
         }
       l_run += psum;
       // ---- O^T += V^T P^T -------------------------------------------------------------------------------------
-      const char* vbase = v_sm + cur * kVBuf;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm) {
-          const int kbase = 32 * kb + 16 * mm + 8 * hh;
+          const int off = (32 * kb + 16 * mm) * kRowBytes;
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
             bf16x8_t vf;
             if constexpr (USE_TR) {
               // 16-lane group: lane p supplies the address of row (p >> 2), 4-column chunk (p & 3) of a [4 keys x 16 d]
               // block and receives column p (4 keys) -- hardware transpose read
-              const int p16 = lane & 15;
-              const int d0 = 32 * dt + 16 * ((lane >> 4) & 1);
-              const char* a0 = vbase + (kbase + (p16 >> 2)) * kVRowBytes + (d0 + 4 * (p16 & 3)) * 2;
               typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
-              const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0));
-              const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0 + 4 * kVRowBytes));
+              const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(vt + tr_addr[dt][0] + off));
+              const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(vt + tr_addr[dt][1] + off));
               vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             } else {
               const int dcol = 32 * dt + j;
 #pragma unroll
               for (int e = 0; e < 8; ++e)
-                vf[e] = *reinterpret_cast<const __bf16*>(vbase + (kbase + e) * kVRowBytes + dcol * 2);
+                vf[e] = *reinterpret_cast<const __bf16*>(vt + chunk_off(32 * kb + 16 * mm + 8 * hh + e, dcol >> 3) + (dcol & 7) * 2);
             }
             o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][mm], o[dt], 0, 0, 0);
           }
         }
     }
-    if (t + 1 < n_tiles) store_tile(cur ^ 1);
+  };
+  for (int t = 0; t < n_tiles; t += 2) {
+    if (t + 1 < n_tiles) load_tile(t + 1, 1);
+    tile_body(std::integral_constant<int, 0>{}, t);
+    __syncthreads();                         // also drains this wave's global_load_lds queue (vmcnt(0)) before the release
+    if (t + 1 >= n_tiles) break;
+    if (t + 2 < n_tiles) load_tile(t + 2, 0);
+    tile_body(std::integral_constant<int, 1>{}, t + 1);
     __syncthreads();
   }
 

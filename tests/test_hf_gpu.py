@@ -324,3 +324,55 @@ def test_unreorder_fusion_is_transparent(selector_model):
     finally:
         hf_generic._select_block_permuted = orig
     assert calls, "permuted path not taken"
+
+
+def test_training_through_native_attention_matches_sdpa():
+    """The reference trains the LIS through the frozen LLM whose attention is flash_attn_varlen_func (trainer.py:101-113).
+    Here: the LLM's attention is vsel_varlen (native forward + backward); the scorer gradients must match the same model
+    with torch SDPA attention.  bf16 model, head_dim 128."""
+    from transformers import Qwen2_5_VLConfig
+    from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as hf
+    from visionselector_amd.attention import ATTN_NAME, replace_qwen2_vl_attention_class
+    from visionselector_amd.hf_qwen25vl import install_selector
+    replace_qwen2_vl_attention_class()
+    cfg = Qwen2_5_VLConfig(
+        text_config=dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                         num_key_value_heads=1, vocab_size=64, max_position_embeddings=4096,
+                         rope_parameters=dict(rope_type="default", mrope_section=[16, 24, 24], rope_theta=10000.0)),
+        vision_config=dict(depth=2, hidden_size=64, num_heads=4, intermediate_size=128, out_hidden_size=256, patch_size=14,
+                           spatial_merge_size=2, temporal_patch_size=2, window_size=112, fullatt_block_indexes=[1],
+                           in_channels=3),
+        image_token_id=IMG, video_token_id=VID, vision_start_token_id=VSTART, vision_end_token_id=VEND)
+    torch.manual_seed(0)
+    model = hf.Qwen2_5_VLForConditionalGeneration(cfg).cuda().bfloat16().train()
+    install_selector(model, budget=0.25, regularization_weight=0.7)
+    visual = model.model.visual
+    randomize_scorer(visual.importance_scorer, seed=2)
+    for n, p in model.named_parameters():
+        p.requires_grad = "importance_scorer" in n
+    inp, n_vis = make_inputs(grid=(1, 32, 32), seed=5)
+    inp["pixel_values"] = inp["pixel_values"].bfloat16()
+    labels = inp["input_ids"].clone()
+    labels[inp["input_ids"] == IMG] = -100
+
+    def run(impl):
+        model.model.language_model.config._attn_implementation = impl      # LLM only; the vision tower (head_dim 16) stays SDPA
+        model.model.visual.config._attn_implementation = "sdpa"
+        for p in visual.importance_scorer.parameters():
+            p.grad = None
+        out = model(**inp, labels=labels)
+        out.loss.backward()
+        return float(out.loss.detach()), {n: p.grad.float().clone() for n, p in visual.importance_scorer.named_parameters()}
+
+    loss_ref, g_ref = run("sdpa")
+    from visionselector_amd import _native as N
+    N.profile_start()
+    loss_got, g_got = run(ATTN_NAME)
+    prof = N.profile_stop()
+    assert prof["varlen_attn_fwd_kernel"][1] == 2 and prof["attn_bwd_dq_kernel"][1] == 2, prof       # 2 layers, native path ran
+    assert abs(loss_got - loss_ref) <= 2e-2 * max(1.0, abs(loss_ref))
+    for n in g_ref:
+        scale = float(g_ref[n].abs().max())
+        # TOLERANCE 6 % of the tensor's max: two bf16 attention implementations (different summation order and rounding of
+        # P) back-propagated through 2 bf16 transformer layers
+        assert float((g_got[n] - g_ref[n]).abs().max()) <= 6e-2 * scale + 1e-6, (n, float((g_got[n] - g_ref[n]).abs().max()), scale)

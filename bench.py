@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-attn", action="store_true")
     ap.add_argument("--no-llm", action="store_true", help="skip the whole-LLM prefill leg (7B random-init weights)")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (config C3: fwd + bwd + grad all-reduce)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -177,6 +178,14 @@ def main():
                   "idx_equal_own_scores": bool(np.array_equal(olis.hard_topk_indices(s0, k), idx[0].cpu().numpy())),
                   "gather_exact": bool(torch.equal(out[0], h[0][idx[0]]))}
 
+    # ---- training step (config C3), every rank: LIS fwd + bwd into one flat fp32 bucket + all-reduce over RCCL --------
+    train = None
+    if not args.no_train:
+        try:
+            train = bench_train_step(ops, dist, world, rank)
+        except Exception as e:  # optional leg: never lose the headline line over it
+            train = {"error": str(e)[:300]}
+
     if rank != 0:
         if dist:
             dist.barrier()              # rank 0 is still producing the report (attention leg); leave together
@@ -218,6 +227,8 @@ def main():
         "roofline": roofline, "roofline_path": path, "kernels": kern, "parity": parity,
     }
 
+    if train is not None:
+        res["train_step"] = train
     # ---- prefill attention at the compressed vs the full length (second half of the metric) ----------
     if not args.no_attn:
         try:
@@ -236,6 +247,71 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_train_step(ops, dist, world, rank, iters=20):
+    """BASELINE config 3: one data-parallel training step of the LIS block per rank -- forward (scores, soft top-k, mask
+    apply, constraint mask, BCE), backward (closed-form fp32 gradients written straight into ONE flat bucket) and the mean
+    all-reduce of the 12 848 640 gradients over RCCL (nothing to exchange at world 1).  Curriculum weight per step as
+    train_qwen_selector.py:60-92.  Max over ranks; tokens/s is the whole-job aggregate."""
+    from visionselector_amd.selector import curriculum_weight
+    d, hd = D, HD
+    gen = torch.Generator(device="cuda").manual_seed(4321 + rank)
+    wq = (0.02 * torch.randn(hd, d, device="cuda", generator=gen)).bfloat16()
+    wk = (0.02 * torch.randn(hd, d, device="cuda", generator=gen)).bfloat16()
+    bq = (0.02 * torch.randn(hd, device="cuda", generator=gen)).bfloat16()
+    bk = (0.02 * torch.randn(hd, device="cuda", generator=gen)).bfloat16()
+    bucket = torch.zeros(2 * (hd * d + hd), dtype=torch.float32, device="cuda")
+    views, off = [], 0
+    for shape in ((hd, d), (hd,), (hd, d), (hd,)):
+        cnt = shape[0] * (shape[1] if len(shape) > 1 else 1)
+        views.append(bucket[off:off + cnt].view(*shape))
+        off += cnt
+    out = {"grad_elems": bucket.numel(), "grad_bytes_fp32": bucket.numel() * 4, "world": world}
+    for name, n in (("packed_16x64_tokens", 1024), ("one_image_2304_tokens", 2304)):
+        k = int(n * 0.2)
+        h = torch.randn(n, d, device="cuda", generator=gen).bfloat16()
+        dhn = (torch.randn(n, d, device="cuda", generator=gen) / d ** 0.5).bfloat16()
+
+        def compute(step_no):
+            w = curriculum_weight(step_no, 1000, 0.1, 2.0)
+            h_new, ps, y, scores, ts, bce = ops.lis_train_fwd(h, wq, bq, wk, bk, k)
+            ops.lis_train_bwd(dhn, h, wq, bq, wk, bk, ps, y, scores, ts, None, w, need_dh=False, out=views)
+
+        def exchange():
+            if dist:
+                dist.all_reduce(bucket)
+                bucket.div_(world)
+
+        for i in range(3):
+            compute(i)
+            exchange()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        for i in range(iters):
+            compute(i)
+            exchange()
+        ev[1].record()
+        for i in range(iters):
+            compute(i)
+        ev[2].record()
+        for i in range(iters):
+            exchange()
+        ev[3].record()
+        torch.cuda.synchronize()
+        t = torch.tensor([ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])],
+                         dtype=torch.float64, device="cuda") / iters * 1e3
+        if dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        step_us, comp_us, exch_us = [float(x) for x in t.tolist()]
+        out[name] = {"n_tokens_per_rank": n, "k": k, "step_us": step_us, "fwd_bwd_us": comp_us, "grad_allreduce_us": exch_us,
+                     "tokens_per_s": world * n / (step_us * 1e-6),
+                     "allreduce_busbw_GBps": (2 * (world - 1) / world * bucket.numel() * 4 / (exch_us * 1e-6) / 1e9) if dist else None}
+    return out
 
 
 def bench_attention(ops, k, text=64, hq=28, hkv=4, dh=128, layers=28, iters=20):

@@ -151,3 +151,49 @@ def test_lis_grad_sync_gloo_world2(tmp_path):
     for i, got in enumerate(r0["grads"]):
         exp = (per_rank[0][i] + per_rank[1][i]) / world
         assert torch.allclose(got, exp, atol=1e-7)
+
+
+def _ddp_view_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from visionselector_amd.ddp import LisGradSync
+        torch.manual_seed(3)
+        lin = torch.nn.Linear(8, 4)                        # stands in for the scorer (its forward needs the GPU library)
+        sync = LisGradSync(lin.parameters(), bucket_view=True)
+        views = sync.views()
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(lin.parameters(), views))
+        x = torch.full((2, 8), float(rank + 1))
+        for _ in range(2):                                 # two micro-batches accumulate IN PLACE into the bucket views
+            lin(x).sum().backward()
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(lin.parameters(), views))
+        sync.sync()                                        # one all-reduce on the bucket, no copies
+        g1 = [p.grad.clone() for p in lin.parameters()]
+        lin.zero_grad(set_to_none=True)                    # a caller that drops the views: sync() re-attaches them
+        lin(x).sum().backward()
+        sync.sync()
+        g2 = [p.grad.clone() for p in lin.parameters()]
+        sync.zero_grads()
+        assert all(float(p.grad.abs().max()) == 0.0 for p in lin.parameters())
+        torch.save({"g1": g1, "g2": g2}, os.path.join(out_dir, f"v{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_lis_grad_sync_bucket_view_gloo_world2(tmp_path):
+    """bucket_view: p.grad are views of the flat bucket; the data-parallel mean is one all-reduce with no pack / unpack."""
+    world = 2
+    mp.spawn(_ddp_view_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "v0.pt"), torch.load(tmp_path / "v1.pt")
+    for key in ("g1", "g2"):
+        for a, b in zip(r0[key], r1[key]):
+            assert torch.equal(a, b)
+    # d(sum(Wx + b))/dW = sum over the batch of x; rank r feeds x = r + 1, two rows, two micro-batches
+    exp_w1 = torch.full((4, 8), (2 * 2 * 1.0 + 2 * 2 * 2.0) / 2)
+    exp_b1 = torch.full((4,), (2 * 2 + 2 * 2) / 2.0)
+    assert torch.allclose(r0["g1"][0], exp_w1) and torch.allclose(r0["g1"][1], exp_b1)
+    assert torch.allclose(r0["g2"][0], exp_w1 / 2) and torch.allclose(r0["g2"][1], exp_b1 / 2)
+    with pytest.raises(TypeError):
+        from visionselector_amd.ddp import LisGradSync
+        LisGradSync(torch.nn.Linear(2, 2).bfloat16().parameters(), bucket_view=True)

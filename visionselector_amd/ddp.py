@@ -18,13 +18,54 @@ import torch.distributed as dist
 class LisGradSync:
     """Average the scorer's gradients over the data-parallel group with one bucketed all-reduce."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None,
+                 bucket_view: bool = False):
+        """bucket_view=True (fp32 parameters): every p.grad is a VIEW into the flat bucket (DDP's gradient_as_bucket_view),
+        autograd accumulates into it in place and sync() is one all-reduce with no pack / unpack copies.  Clear gradients
+        with zero_grads() (or optimizer.zero_grad(set_to_none=False)), not by setting them to None."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters to synchronise")
         self.group = group
         self.numel = sum(p.numel() for p in self.params)
         self._bucket: Optional[torch.Tensor] = None
+        self.bucket_view = bool(bucket_view)
+        if self.bucket_view:
+            if any(p.dtype != torch.float32 for p in self.params):
+                raise TypeError("bucket_view needs float32 parameters (the bucket is fp32)")
+            self.attach_views()
+
+    def attach_views(self) -> None:
+        """(Re)point every p.grad at its slice of the flat fp32 bucket, keeping what it held."""
+        bucket = self._flat(self.params[0].device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            view = bucket[off:off + n].view_as(p)
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+            p.grad = view
+            off += n
+
+    def views(self) -> List[torch.Tensor]:
+        """The bucket slices in parameter order (for kernels that write gradients directly, e.g. ops.lis_train_bwd(out=...))."""
+        bucket = self._flat(self.params[0].device)
+        out, off = [], 0
+        for p in self.params:
+            out.append(bucket[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return out
+
+    def zero_grads(self) -> None:
+        if self.bucket_view:
+            self._flat(self.params[0].device).zero_()
+            if any(p.grad is None or p.grad.data_ptr() != v.data_ptr() for p, v in zip(self.params, self.views())):
+                self.attach_views()
+        else:
+            for p in self.params:
+                p.grad = None
 
     def _flat(self, device) -> torch.Tensor:
         if self._bucket is None or self._bucket.device != device:
@@ -38,6 +79,12 @@ class LisGradSync:
         if world == 1:
             return
         bucket = self._flat(self.params[0].device)
+        if self.bucket_view:
+            if any(p.grad is None or p.grad.data_ptr() != v.data_ptr() for p, v in zip(self.params, self.views())):
+                self.attach_views()                    # someone replaced a .grad (e.g. zero_grad(set_to_none=True))
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+            bucket.div_(world)
+            return
         off = 0
         for p in self.params:
             n = p.numel()

@@ -248,15 +248,23 @@ def lis_train_fwd(h, wq, bq, wk, bk, k: int):
     return h_new, ps, y, scores, ts, bce
 
 
-def lis_train_bwd(d_hnew, h, wq, bq, wk, bk, ps, y, scores, ts, d_ps_ext=None, dl_dbce: float = 0.0, need_dh: bool = False):
-    """-> (dwq, dbq, dwk, dbk fp32, dh or None)."""
+def lis_train_bwd(d_hnew, h, wq, bq, wk, bk, ps, y, scores, ts, d_ps_ext=None, dl_dbce: float = 0.0, need_dh: bool = False,
+                  out=None):
+    """-> (dwq, dbq, dwk, dbk fp32, dh or None).  out = (dwq, dbq, dwk, dbk): contiguous fp32 buffers to OVERWRITE (e.g. the
+    slices of a flat all-reduce bucket, ddp.LisGradSync.views()) instead of fresh tensors."""
     dev = _dev(d_hnew, h, wq, bq, wk, bk, ps, y, scores, ts, d_ps_ext)
     n, d = h.shape
     sc = _scorer(wq, bq, wk, bk)
     lib = N.lib()
     ws = _workspace(lib.vsel_lis_train_workspace_bytes(n, d, sc.hd), dev)
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
-    dwq, dbq, dwk, dbk = f(sc.hd, d), f(sc.hd), f(sc.hd, d), f(sc.hd)
+    if out is not None:
+        dwq, dbq, dwk, dbk = out
+        for t, shape in ((dwq, (sc.hd, d)), (dbq, (sc.hd,)), (dwk, (sc.hd, d)), (dbk, (sc.hd,))):
+            if t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous() or t.device != dev:
+                raise ValueError("lis_train_bwd(out=...): need contiguous float32 [Hd,D], [Hd], [Hd,D], [Hd] on the same device")
+    else:
+        dwq, dbq, dwk, dbk = f(sc.hd, d), f(sc.hd), f(sc.hd, d), f(sc.hd)
     dh = torch.empty_like(h) if need_dh else None
     N.check(lib.vsel_lis_train_bwd(_stream(), d_hnew.data_ptr(), h.data_ptr(), _code(h), n, C.byref(sc), ps.data_ptr(),
                                    y.data_ptr(), scores.data_ptr(), ts.data_ptr(), _p(d_ps_ext), float(dl_dbce),

@@ -78,7 +78,8 @@ class LisTrainer:
         warm = max(1, int(warmup_ratio * max_steps))
         self.sched = torch.optim.lr_scheduler.LambdaLR(
             self.opt, lambda s: (s + 1) / warm if s < warm else 0.5 * (1 + math.cos(math.pi * (s - warm) / max(1, max_steps - warm))))
-        self.sync = LisGradSync(self.params, group)
+        # fp32 scorer: gradients live in ONE flat bucket (views), so the data-parallel mean is a single all-reduce, no copies
+        self.sync = LisGradSync(self.params, group, bucket_view=all(p.dtype == torch.float32 for p in self.params))
         self.sync.broadcast_parameters(0)
         self.global_step = 0
         self.log = log
@@ -90,7 +91,7 @@ class LisTrainer:
         self.model.regularization_weight = w                                   # train_qwen_selector.py:82-83
         if self.rank == 0 and self.global_step > 0:
             self.log(f"\\n[Step {self.global_step}] Set regularization_weight to: {w:.4f}")   # :86-89
-        self.opt.zero_grad(set_to_none=True)
+        self.sync.zero_grads()
         batches = list(batches)
         total = 0.0
         for b in batches:

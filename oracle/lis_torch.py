@@ -48,3 +48,18 @@ def select_forward(h, wq, bq, wk, bk, budgets: float, with_soft_scores: bool = F
     if with_soft_scores:
         find_ts(scores.unsqueeze(0), k)                                   # :190 (visualisation only)
     return h_new, idx, scores
+
+
+@torch.no_grad()
+def select_forward_collapsed(h, wq, bq, wk, bk, budgets: float):
+    """The same selection with the scorer in its algebraically collapsed form (mean_j q_i.k_j = q_i.kbar,
+    oracle/lis.py::scorer_collapsed) -- NOT what the reference executes; reported beside the reference formulation in
+    bench.py's cpu_baseline so the GPU/CPU ratio is not credited with the algebra."""
+    hidden_dim = wq.shape[0]
+    total = h.shape[0]
+    kbar = F.linear(h.mean(dim=0), wk, bk)
+    w = kbar @ wq
+    scores = (h @ w + torch.dot(bq, kbar)) / (hidden_dim ** 0.5)
+    k = max(1, int(total * budgets))
+    idx = scores.topk(k).indices.sort().values
+    return h[idx, :], idx, total

@@ -174,6 +174,24 @@ int vsel_splice(void* stream, const int64_t* input_ids, int64_t seq_len, int64_t
                 void* new_inputs_embeds, int64_t* new_position_ids, int64_t* new_attention_mask,
                 int32_t* src_scratch, int32_t* stats);
 
+/* -------- producer-side fusion: single-sweep LIS ---------------------------------
+ * The tokens come out of the patch merger  ln_q -> Linear -> GELU -> Linear  (Qwen2_5_VLPatchMerger,
+ * EV/qwen25vl/modeling_qwen2_5_vl.py:148-161; RicePatchMerger, OV/llavaonevision1_5/modeling_llavaonevision1_5.py:255-268)
+ * and the scorer needs their row mean first (selector_scorer.py:47-53 collapsed: DESIGN.md section 3).  The last Linear is
+ * linear, so  sum_rows(H) = sum_rows(G) W2^T + N b2  with G the GELU output:
+ *   vsel_gelu_colsum  replaces the merger's GELU launch: y = GELU(x) (erf form, fp32 math, as nn.GELU()) and
+ *     col_sums [n_seg, cols] fp32 = per-segment column sums of y as rounded to `dtype` -- no extra HBM traffic;
+ *   vsel_lis_select_presummed  = vsel_lis_select (row maps NULL) / vsel_lis_select_permuted (row maps given) with the
+ *     column sums of the tokens supplied by the caller (col_sums [n_seg, D] fp32), skipping the first sweep over H.
+ * The caller forms sum_rows(H) from sum_rows(G) with one skinny fp32 GEMM (a library call).                          */
+size_t vsel_gelu_colsum_workspace_bytes(const vsel_segments* seg, int64_t cols);
+int vsel_gelu_colsum(void* stream, const void* x, vsel_dtype dtype, const vsel_segments* seg, int64_t cols, void* y,
+                     float* col_sums, void* workspace, size_t workspace_bytes);
+int vsel_lis_select_presummed(void* stream, const void* h, vsel_dtype hdtype, const vsel_segments* seg,
+                              const vsel_scorer* scorer, const float* col_sums, void* workspace, size_t workspace_bytes,
+                              const int64_t* logical_to_physical, const int64_t* physical_to_logical, void* out,
+                              int64_t* idx, float* scores);
+
 /* -------- packed-batch splice ----------------------------------------------
  * The reference's generation forward is batch 1 (`assert ... "selector only support single batch"`,
  * EV/token_compression/selector_model.py:270; OV/compression_method/modeling_selector.py:259).  This entry applies the same

@@ -376,3 +376,30 @@ def test_training_through_native_attention_matches_sdpa():
         # TOLERANCE 6 % of the tensor's max: two bf16 attention implementations (different summation order and rounding of
         # P) back-propagated through 2 bf16 transformer layers
         assert float((g_got[n] - g_ref[n]).abs().max()) <= 6e-2 * scale + 1e-6, (n, float((g_got[n] - g_ref[n]).abs().max()), scale)
+
+
+def test_merger_colsum_fusion_is_transparent(selector_model):
+    """Single-sweep LIS (section 8f N2): the merger's GELU is replaced by vsel_gelu_colsum during the tower forward and the LIS
+    block takes sum_rows(H) = sum_rows(G) W2^T + N b2 instead of sweeping H.  Same kept tokens and logits as the two-sweep
+    path; the native profile shows the fused kernel and no column-sum sweep."""
+    from visionselector_amd import _native as N
+    m = selector_model
+    m.visual.budgets = 0.25
+    inp, n_vis = make_inputs(grid=(1, 32, 32), seed=11)
+    outs = []
+    for fuse in (True, False):
+        m.visual.fuse_merger_colsum = fuse
+        m.model.rope_deltas = None
+        N.profile_start()
+        with torch.no_grad():
+            o = m(**inp)
+        prof = N.profile_stop()
+        outs.append((o.logits.clone(), m.visual.last_selected_indices.clone(), m.visual.last_combined_scores.clone(), prof))
+    m.visual.fuse_merger_colsum = False
+    assert "gelu_colsum_kernel" in outs[0][3] and "colsum_partial_kernel" not in outs[0][3], outs[0][3].keys()
+    assert "gelu_colsum_kernel" not in outs[1][3] and "colsum_partial_kernel" in outs[1][3]
+    assert torch.equal(outs[0][1], outs[1][1])
+    # TOLERANCE: the mean of H comes from fp32 sums of G through an fp32 GEMM instead of fp32 sums of the rounded H rows
+    assert float((outs[0][2] - outs[1][2]).abs().max()) <= 1e-4
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-4 * max(1.0, float(outs[1][0].abs().max()))
+    assert isinstance(m.visual.merger.mlp[1], torch.nn.GELU)            # the stock module is back in place

@@ -102,3 +102,53 @@ def test_soft_topk_invariants(ops, data):
     ts_ref, ps_ref = olis.find_ts(x[:1], k)
     well_conditioned = min(k, n - k) >= 2 and scale >= 0.1
     assert np.abs(ps[0] - ps_ref[0]).max() <= (2e-5 if well_conditioned else 2e-3)
+
+
+# ---------------------------------------------------------------------------------------------------
+# producer-side fusion: GELU + column sums, single-sweep LIS
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,cols,n_seg", [(300, 5120, 1), (1024, 512, 4), (7, 64, 1), (129 * 3, 1280, 3)])
+def test_gelu_colsum_matches_torch(rows, cols, n_seg, dt):
+    """y is bit-identical to nn.GELU() (erf form) on the same device and the sums are those of the ROUNDED y."""
+    from visionselector_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(rows + cols)
+    x = (2.5 * torch.randn(rows, cols, device="cuda", generator=g)).to(dt)
+    y, sums = ops.gelu_colsum(x, n_seg)
+    ref = torch.nn.functional.gelu(x)
+    assert torch.equal(y, ref)
+    want = ref.double().view(n_seg, rows // n_seg, cols).sum(1)
+    # TOLERANCE: fp32 accumulation of <= 1024 values of magnitude <= ~10: 1e-5 relative to the column's absolute sum
+    scale = ref.double().abs().view(n_seg, rows // n_seg, cols).sum(1)
+    assert float(((sums.double() - want).abs() / (scale + 1e-6)).max()) <= 1e-5
+    # deterministic
+    y2, sums2 = ops.gelu_colsum(x, n_seg)
+    assert torch.equal(sums, sums2)
+
+
+def test_presummed_select_equals_two_sweep_select():
+    """vsel_lis_select_presummed with the true column sums selects the same rows as the two-sweep path (scores agree to
+    fp32 rounding of the mean), with and without the row permutation."""
+    from visionselector_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(77)
+    b, n, d, hd, k = 3, 2304, 3584, 1792, 460
+    h = torch.randn(b, n, d, device="cuda", generator=g).bfloat16()
+    wq, wk = [(0.02 * torch.randn(hd, d, device="cuda", generator=g)).bfloat16() for _ in range(2)]
+    bq, bk = [(0.02 * torch.randn(hd, device="cuda", generator=g)).bfloat16() for _ in range(2)]
+    out0, idx0, sc0 = ops.lis_select(h, wq, bq, wk, bk, k)
+    sums = h.double().sum(1).float().contiguous()
+    out1, idx1, sc1 = ops.lis_select_presummed(h, sums, wq, bq, wk, bk, k)
+    assert torch.equal(idx0, idx1) and torch.equal(out0, out1)
+    assert float((sc0 - sc1).abs().max()) <= 1e-6 * max(1.0, float(sc0.abs().max()))
+    # permuted form, one segment
+    perm = torch.randperm(n, device="cuda", generator=g)
+    h_phys = torch.empty_like(h[0])
+    h_phys[perm] = h[0]                      # logical row i lives at physical row perm[i]
+    p2l = torch.empty_like(perm)
+    p2l[perm] = torch.arange(n, device="cuda")
+    out2, idx2, sc2 = ops.lis_select_presummed(h_phys, sums[0].contiguous(), wq, bq, wk, bk, k, logical_to_physical=perm,
+                                               physical_to_logical=p2l)
+    assert torch.equal(idx2, idx0[0]) and torch.equal(out2, out0[0])
+    assert float((sc2 - sc0[0]).abs().max()) <= 1e-6 * max(1.0, float(sc0.abs().max()))
+    with pytest.raises(ValueError):
+        ops.lis_select_presummed(h, sums[:, :8].contiguous(), wq, bq, wk, bk, k)

@@ -591,11 +591,16 @@ inline int run_colsum(hipStream_t st, const T* h, const vsel_segments* seg, int 
 }
 
 // stage 2: partials -> xbar -> kbar -> (w, c)   (small, latency-bound kernels)
+// col_sums (optional): [S, D] fp32 column sums of the tokens supplied by the producer (vsel_lis_select_presummed); they take
+// the place of the sweep-1 partials as a single "chunk", everything downstream is unchanged.
 template <typename TW>
-inline int run_proj(hipStream_t st, const vsel_segments* seg, const vsel_scorer* sc, char* ws, const LisPlan& p) {
+inline int run_proj(hipStream_t st, const vsel_segments* seg, const vsel_scorer* sc, char* ws, const LisPlan& p_in,
+                    const float* col_sums = nullptr) {
   const SegView sv = make_view(seg);
   const int d = (int)sc->d, hd = (int)sc->hd, S = (int)seg->n_seg;
-  float* partial = (float*)(ws + p.off_partial);
+  LisPlan p = p_in;
+  if (col_sums) p.row_splits = 1;
+  const float* partial = col_sums ? col_sums : (const float*)(ws + p.off_partial);
   float* xbar = (float*)(ws + p.off_xbar);
   float* part1 = (float*)(ws + p.off_part1);
   float* kbar = (float*)(ws + p.off_kbar);

@@ -40,6 +40,33 @@ class _LazyRows(torch.Tensor):
         return super().__torch_function__(func, types, args, kwargs or {})
 
 
+class _GeluColsum(torch.nn.Module):
+    """Stands in for the merger's nn.GELU() during an inference tower forward: same output, plus the column sums of that
+    output in the same pass (vsel_gelu_colsum).  With them and the linearity of the merger's last Linear the LIS block knows
+    sum_rows(H) without sweeping H."""
+
+    def __init__(self):
+        super().__init__()
+        self.col_sums = None
+
+    def forward(self, x):
+        if x.dim() != 2 or not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float32) or x.shape[1] % 8:
+            return torch.nn.functional.gelu(x)                 # not the merger layout: leave the numerics to torch
+        y, self.col_sums = ops.gelu_colsum(x.contiguous(), 1)
+        return y
+
+
+def _merger_gelu_slot(merger):
+    """(container, key) of the exact-GELU module between the merger's two Linears, or None when the merger does not have
+    the ln -> Linear -> GELU -> Linear shape (then the two-sweep path runs)."""
+    mlp = getattr(merger, "mlp", None)
+    if isinstance(mlp, torch.nn.Sequential) and len(mlp) == 3 and isinstance(mlp[0], torch.nn.Linear) \
+            and isinstance(mlp[2], torch.nn.Linear) and isinstance(mlp[1], torch.nn.GELU) \
+            and getattr(mlp[1], "approximate", "none") == "none":
+        return mlp, 1
+    return None
+
+
 def _merged_tokens(out) -> torch.Tensor:
     """Accept either a plain tensor (transformers 4.5x towers) or a ModelOutput with pooler_output (5.x)."""
     if isinstance(out, torch.Tensor):
@@ -65,17 +92,35 @@ def make_vision_tower_forward_selector(base_forward: Callable, mode: str):
     def forward_eval(self, hidden_states: torch.Tensor, grid_thw: torch.Tensor, **kwargs):
         merger = getattr(self, "merger", None)
         handle = None
+        fused_gelu, slot = None, None
         if merger is not None and not torch.is_grad_enabled() and getattr(self, "fuse_unreorder", True):
             handle = merger.register_forward_hook(lambda mod, inp, out: _LazyRows(out) if out.dim() == 2 else out)
+            # opt-in (visual.fuse_merger_colsum = True): measured on MI355X it does not pay -- the erf-bound fused GELU is
+            # 1.6-3x slower than torch's and the 73 MB fp32 GEMV costs more than the 16.5 MB sweep it replaces at one image
+            # (tools/exp_merger_fusion.py)
+            slot = _merger_gelu_slot(merger) if getattr(self, "fuse_merger_colsum", False) else None
+            if slot is not None:
+                fused_gelu = _GeluColsum()
+                original_gelu = slot[0][slot[1]]
+                slot[0][slot[1]] = fused_gelu
         try:
             merged = _merged_tokens(base_forward(self, hidden_states, grid_thw, **kwargs))
         finally:
             if handle is not None:
                 handle.remove()
+            if slot is not None:
+                slot[0][slot[1]] = original_gelu
         perm = getattr(merged, "_perm", None) if isinstance(merged, _LazyRows) else None
         merged = merged.as_subclass(torch.Tensor).detach()
+        col_sums = None
+        if fused_gelu is not None and fused_gelu.col_sums is not None and perm is not None:
+            # sum_rows(H) = sum_rows(G) W2^T + N b2 (one skinny fp32 GEMM; the merger's last Linear is linear)
+            last = slot[0][2]
+            col_sums = torch.addmm(last.bias.float() * merged.shape[0] if last.bias is not None
+                                   else torch.zeros(last.out_features, device=merged.device),
+                                   fused_gelu.col_sums, last.weight.float().t()).contiguous()
         if perm is not None:
-            out, idx, total, combined = _select_block_permuted(merged, perm, self.importance_scorer, self.budgets)
+            out, idx, total, combined = _select_block_permuted(merged, perm, self.importance_scorer, self.budgets, col_sums)
         else:
             out, idx, total, combined = lis_select_block(merged, self.importance_scorer, self.budgets)
         self.last_combined_scores = combined
@@ -86,15 +131,21 @@ def make_vision_tower_forward_selector(base_forward: Callable, mode: str):
 
 
 @torch.no_grad()
-def _select_block_permuted(merged_physical: torch.Tensor, reverse_indices: torch.Tensor, scorer, budgets: float):
-    """lis_select_block on merged_physical[reverse_indices] without materialising it (vsel_lis_select_permuted)."""
+def _select_block_permuted(merged_physical: torch.Tensor, reverse_indices: torch.Tensor, scorer, budgets: float,
+                           col_sums: torch.Tensor | None = None):
+    """lis_select_block on merged_physical[reverse_indices] without materialising it (vsel_lis_select_permuted; with the
+    producer's column sums: vsel_lis_select_presummed, one sweep over the tokens instead of two)."""
     total = merged_physical.shape[0]
     k = max(1, int(total * budgets))
     l2p = reverse_indices.to(merged_physical.device).contiguous()     # transformers builds window_index on the host
     p2l = torch.empty_like(l2p)
     p2l[l2p] = torch.arange(total, device=l2p.device, dtype=l2p.dtype)          # = window_index
-    out, idx, scores = ops.lis_select_permuted(merged_physical.contiguous(), l2p, p2l,
-                                               *[p.detach().contiguous() for p in scorer.params()], k)
+    params = [p.detach().contiguous() for p in scorer.params()]
+    if col_sums is not None:
+        out, idx, scores = ops.lis_select_presummed(merged_physical.contiguous(), col_sums, *params, k,
+                                                    logical_to_physical=l2p, physical_to_logical=p2l)
+    else:
+        out, idx, scores = ops.lis_select_permuted(merged_physical.contiguous(), l2p, p2l, *params, k)
     combined = None
     if 0 < k < total:
         combined = ops.soft_topk_fwd(scores[None], k)[0][0].to(merged_physical.dtype)

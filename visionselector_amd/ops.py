@@ -154,6 +154,53 @@ def lis_select_permuted(h_physical, logical_to_physical, physical_to_logical, wq
     return out, idx, scores
 
 
+def gelu_colsum(x: torch.Tensor, n_seg: int = 1):
+    """y = GELU(x) (erf form, as nn.GELU()) and the per-segment column sums of y, in one pass.  x [R, C] (n_seg equal
+    segments of R / n_seg rows) -> (y [R, C] same dtype, col_sums fp32 [n_seg, C])."""
+    dev = _dev(x)
+    if x.dim() != 2 or not x.is_contiguous():
+        raise ValueError("gelu_colsum takes a contiguous [rows, cols] tensor")
+    r, c = x.shape
+    if n_seg < 1 or r % n_seg:
+        raise ValueError(f"rows {r} do not split into {n_seg} equal segments")
+    seg = _uniform_segments(n_seg, r // n_seg, 1)
+    lib = N.lib()
+    ws = _workspace(lib.vsel_gelu_colsum_workspace_bytes(C.byref(seg), c), dev)
+    y = torch.empty_like(x)
+    sums = torch.empty(n_seg, c, dtype=torch.float32, device=dev)
+    N.check(lib.vsel_gelu_colsum(_stream(), x.data_ptr(), _code(x), C.byref(seg), c, y.data_ptr(), sums.data_ptr(),
+                                 ws.data_ptr(), ws.numel()))
+    return y, sums
+
+
+def lis_select_presummed(h, col_sums, wq, bq, wk, bk, k: int, logical_to_physical=None, physical_to_logical=None):
+    """lis_select / lis_select_permuted with the column sums of the tokens supplied by their producer (fp32 [B, D] or [D]):
+    the first HBM sweep over h is skipped.  h [N,D] or [B,N,D]."""
+    dev = _dev(h, col_sums, wq, bq, wk, bk, logical_to_physical, physical_to_logical)
+    b, n, d = _as_bnd(h)
+    if col_sums.dtype != torch.float32 or col_sums.numel() != b * d or not col_sums.is_contiguous():
+        raise ValueError("col_sums must be contiguous float32 with one row of D sums per segment")
+    if (logical_to_physical is None) != (physical_to_logical is None):
+        raise ValueError("give both permutation maps or neither")
+    if logical_to_physical is not None:
+        if logical_to_physical.dtype != torch.int64 or physical_to_logical.dtype != torch.int64:
+            raise TypeError("permutation maps must be int64")
+        if logical_to_physical.numel() != b * n or physical_to_logical.numel() != b * n:
+            raise ValueError("permutation maps must have one entry per token row")
+    sc = _scorer(wq, bq, wk, bk)
+    seg = _uniform_segments(b, n, int(k))
+    lib = N.lib()
+    ws = _workspace(lib.vsel_lis_workspace_bytes(C.byref(seg), d, sc.hd), dev)
+    lead = h.shape[:-2]
+    out = torch.empty(*lead, k, d, dtype=h.dtype, device=dev)
+    idx = torch.empty(*lead, k, dtype=torch.int64, device=dev)
+    scores = torch.empty(*lead, n, dtype=torch.float32, device=dev)
+    N.check(lib.vsel_lis_select_presummed(_stream(), h.data_ptr(), _code(h), C.byref(seg), C.byref(sc), col_sums.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), _p(logical_to_physical), _p(physical_to_logical),
+                                          out.data_ptr(), idx.data_ptr(), scores.data_ptr()))
+    return out, idx, scores
+
+
 def lis_select_varlen(h, seg_lens: Sequence[int], ks: Sequence[int], wq, bq, wk, bk):
     """Ragged form: h [T,D] holds len(seg_lens) segments back to back; segment s keeps ks[s] rows.
     -> (out [sum ks, D], idx int64 [sum ks] local to the segment, scores fp32 [T])."""

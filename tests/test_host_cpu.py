@@ -44,6 +44,10 @@ def test_dropin_import_paths():
         from token_compression.selector_model import (Qwen2_5_VisionTransformerPretrainedModel_Selector,  # noqa: F401
                                                       Qwen2_5_VLForConditionalGeneration_Selector)
         from compression_method.monkeypatch import replace_llavaov15
+        from compression_method.selector_model import (llavaov15_generation_forward_selector,  # noqa: F401
+                                                       llavaov15_vision_tower_forward_selector,
+                                                       llavaov15_vlmodel_forward_selector)
+        from compression_method.modeling_selector import make_llavaov15_selector_classes  # noqa: F401
     finally:
         sys.path.pop(0)
     sentinel = object()

@@ -6,3 +6,9 @@ from visionselector_amd.hf_qwen25vl import (  # noqa: F401
     qwen25vl_vision_tower_forward_selector,
 )
 from visionselector_amd.hf_generic import make_vision_tower_forward_selector  # noqa: F401
+from visionselector_amd.hf_llavaov15 import (  # noqa: F401
+    install_selector_llavaov15,
+    llavaov15_generation_forward_selector,
+    llavaov15_vision_tower_forward_selector,
+    llavaov15_vlmodel_forward_selector,
+)

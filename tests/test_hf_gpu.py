@@ -568,3 +568,59 @@ def test_llavaov15_inference_classes_splice_like_the_reference():
                                 return_dict=True).last_hidden_state
     assert n_vis == 64 and out.last_hidden_state.shape == (1, 16 + 11, 128)
     assert float((out.last_hidden_state - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_llavaov15_class_factory_builds_the_three_selector_classes():
+    """make_llavaov15_selector_classes on PreTrainedModel-shaped toy bases (config-constructed, _from_config, post_init):
+    names, scorer attachment (in_features from the tower config), forwards and the (output, visual_token_num) contract."""
+    from visionselector_amd.hf_llavaov15 import make_llavaov15_selector_classes
+
+    class Base(torch.nn.Module):
+        @classmethod
+        def _from_config(cls, config):
+            return cls(config)
+
+        def post_init(self):
+            pass
+
+    class Rice(Base, _ToyRice):
+        def __init__(self, config):
+            _ToyRice.__init__(self)
+            self.config = config
+
+    class VL(Base):
+        def __init__(self, config):
+            torch.nn.Module.__init__(self)
+            self.config = config
+            self.visual = Rice(config.vision_config)
+            inner = _ToyOVModel(self.visual)
+            self.language_model = inner.language_model
+            self.get_input_embeddings = inner.get_input_embeddings
+
+        def get_image_features(self, pixel_values, image_grid_thw=None):
+            return self.visual(pixel_values.type(self.visual.dtype), grid_thw=image_grid_thw)
+
+    class CG(Base):
+        def __init__(self, config):
+            torch.nn.Module.__init__(self)
+            self.config = config
+
+    ns = lambda **k: type("C", (), k)()  # noqa: E731
+    cfg = ns(vision_config=ns(out_hidden_size=128), text_config=ns(hidden_size=128, vocab_size=64), image_token_id=60,
+             video_token_id=61, output_attentions=False, output_hidden_states=False, use_return_dict=True, vocab_size=64)
+    RiceSel, VLSel, CGSel = make_llavaov15_selector_classes(Rice, VL, CG)
+    assert (RiceSel.__name__, VLSel.__name__, CGSel.__name__) == (
+        "RiceTransformerPretrainedModel_Selector", "LLaVAOneVision1_5_Model_Selector",
+        "LLaVAOneVision1_5_ForConditionalGeneration_Selector")
+    torch.manual_seed(2)
+    m = CGSel(cfg).cuda().float().eval()
+    assert isinstance(m.model, VLSel) and isinstance(m.model.visual, RiceSel)
+    sc = m.model.visual.importance_scorer
+    assert (sc.in_features, sc.hidden_dim) == (128, 64) and m.model.visual.budgets == 1.0
+    randomize_scorer(sc, seed=3)
+    m.model.visual.budgets = 0.5
+    inp = _ov_inputs(seed=6)
+    with torch.no_grad():
+        out, n_vis = m.model(**inp)
+    assert n_vis == 64 and out.last_hidden_state.shape == (1, 32 + 11, 128)
+    assert m.lm_head.weight.shape == (64, 128)

@@ -201,3 +201,20 @@ def test_lis_grad_sync_bucket_view_gloo_world2(tmp_path):
     with pytest.raises(TypeError):
         from visionselector_amd.ddp import LisGradSync
         LisGradSync(torch.nn.Linear(2, 2).bfloat16().parameters(), bucket_view=True)
+
+
+def test_eval_time_log_reader(tmp_path):
+    """The EVAL_TIME lines our *_Selector.forward / timed_generate print are averaged like qwen-evaluation/extract_time.py."""
+    from visionselector_amd.evaltime import parse_log, summarize_log
+    log = tmp_path / "log_eval.log"
+    log.write_text("\n".join([
+        "using selector",
+        "Input visual token number is: 2304", "Generation prefill time is: 15.5", "Generation latency time is: 120.25",
+        "after generation memory: 17179869184",
+        "noise Input visual token number is: 576", "Generation prefill time is: 4.5", "Generation latency time is: 80.75",
+        "after generation memory: 8589934592", "Generation prefill time is: 0.0",            # zero values are dropped
+    ]))
+    s = summarize_log(str(log))
+    assert s["samples"] == 2 and s["avg_prefill_ms"] == 10.0 and s["avg_latency_ms"] == 100.5
+    assert s["avg_visual_tokens"] == 1440.0 and s["avg_max_memory_GB"] == 12.0
+    assert parse_log(["nothing here"]) == {"memory_bytes": [], "latency_ms": [], "prefill_ms": [], "visual_tokens": []}

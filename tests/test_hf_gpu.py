@@ -624,3 +624,42 @@ def test_llavaov15_class_factory_builds_the_three_selector_classes():
         out, n_vis = m.model(**inp)
     assert n_vis == 64 and out.last_hidden_state.shape == (1, 32 + 11, 128)
     assert m.lm_head.weight.shape == (64, 128)
+
+
+def test_native_attention_prefill_then_decode_matches_sdpa():
+    """attn_implementation = vsel_varlen for a whole generate()-style run: prefill (var-len kernel), then decode steps and a
+    3-token chunk against the cache (paged kernel, one page per batch row), vs the same bf16 model on SDPA."""
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    from visionselector_amd.attention import ATTN_NAME, replace_qwen2_vl_attention_class
+    replace_qwen2_vl_attention_class()
+    torch.manual_seed(0)
+    cfg = Qwen2Config(hidden_size=512, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, vocab_size=128, max_position_embeddings=2048, head_dim=128)
+    model = Qwen2ForCausalLM(cfg).cuda().bfloat16().eval()
+    ids = torch.randint(0, 128, (2, 37), device="cuda")
+    steps = [torch.randint(0, 128, (2, 1), device="cuda"), torch.randint(0, 128, (2, 1), device="cuda"),
+             torch.randint(0, 128, (2, 3), device="cuda")]
+
+    def run(impl):
+        model.config._attn_implementation = impl
+        outs = []
+        with torch.no_grad():
+            o = model(input_ids=ids, use_cache=True)
+            outs.append(o.logits.float())
+            past = o.past_key_values
+            for nxt in steps:
+                o = model(input_ids=nxt, past_key_values=past, use_cache=True)
+                outs.append(o.logits.float())
+                past = o.past_key_values
+        return outs
+
+    ref = run("sdpa")
+    from visionselector_amd import _native as N
+    N.profile_start()
+    got = run(ATTN_NAME)
+    prof = N.profile_stop()
+    assert prof["varlen_attn_fwd_kernel"][1] == 2 * 4, prof            # 2 layers x (prefill + 3 cache steps), all native
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape
+        # TOLERANCE 3e-2 of the logits' max magnitude: two bf16 attention implementations through 2 bf16 layers
+        assert float((a - b).abs().max()) <= 3e-2 * max(1.0, float(b.abs().max()))

@@ -77,13 +77,14 @@ def vsel_attention_forward(module, query, key, value, attention_mask, dropout: f
     """transformers AttentionInterface function.  query [B, Hq, Lq, d], key/value [B, Hkv, Lk, d].
 
     Prefill (Lq == Lk): every batch row is one causal sequence -> one var-len call with cu_seqlens = [0, L, 2L, ...]
-    (or the packed cu_seq_lens_q kwarg when the batch is flattened).  Returns (attn_output [B, Lq, Hq, d], None)."""
+    (or the packed cu_seq_lens_q kwarg when the batch is flattened).  Decode / chunked prefill (Lq < Lk): the same kernel
+    against the cache as one page per batch row (_decode_attention).  Returns (attn_output [B, Lq, Hq, d], None)."""
     if dropout:
         raise NotImplementedError("attention dropout is not supported")
     b, hq, lq, d = query.shape
     lk = key.shape[2]
     if lq != lk:
-        raise NotImplementedError("vsel var-len attention covers the prefill (Lq == Lk); use the stock kernel for decode")
+        return _decode_attention(query, key, value, scaling, is_causal), None
     q = query.transpose(1, 2).reshape(b * lq, hq, d).contiguous()
     k = key.transpose(1, 2).reshape(b * lk, key.shape[1], d).contiguous()
     v = value.transpose(1, 2).reshape(b * lk, value.shape[1], d).contiguous()
@@ -97,6 +98,28 @@ def vsel_attention_forward(module, query, key, value, attention_mask, dropout: f
     causal = True if is_causal is None else bool(is_causal)
     out = varlen_attention(q, k, v, cu, max_len, causal=causal, softmax_scale=scaling)
     return out.view(b, lq, hq, d), None
+
+
+def _decode_attention(query, key, value, scaling, is_causal):
+    """Lq < Lk (decode / chunked prefill against the cache): every batch row is one sequence whose keys are ONE page of
+    Lk rows -> vsel_paged_attn_fwd with page_size = Lk and block_table[b] = [b]; bottom-right aligned causal mask (query i
+    sees keys <= i + Lk - Lq), which is what the HF cache layout means.  Inference only."""
+    b, hq, lq, d = query.shape
+    hkv, lk = key.shape[1], key.shape[2]
+    if lq > lk:
+        raise ValueError(f"more queries ({lq}) than keys ({lk})")
+    if torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad):
+        raise RuntimeError("vsel attention against a longer key sequence (decode) has no backward; training uses Lq == Lk")
+    q = query.transpose(1, 2).reshape(b * lq, hq, d).contiguous()
+    k_pages = key.transpose(1, 2).contiguous()                    # [B pages, Lk, Hkv, d]
+    v_pages = value.transpose(1, 2).contiguous()
+    dev = query.device
+    cu_q = torch.arange(0, (b + 1) * lq, lq, dtype=torch.int32, device=dev)
+    seqlens_k = torch.full((b,), lk, dtype=torch.int32, device=dev)
+    block_table = torch.arange(b, dtype=torch.int32, device=dev).view(b, 1)
+    causal = True if is_causal is None else bool(is_causal)
+    out = ops.paged_attn(q, k_pages, v_pages, cu_q, seqlens_k, block_table, lq, causal=causal, softmax_scale=scaling)
+    return out.view(b, lq, hq, d)
 
 
 def replace_qwen2_vl_attention_class():

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   // one 64-key tile from LDS buffer CUR (compile-time, so that every LDS address is a per-lane base + an immediate)
   auto tile_body = [&](auto cur_c, int t) {
     constexpr int CUR = decltype(cur_c)::value;
-    const bool wave_active = !causal || (t * kTileK <= wave_qmax + shift);
+    // a wave whose 32 query slots are all padding (short q-tiles: decode, ragged tails) only helps with the loads
+    const bool wave_active = (q0 + wave * 32 < qlen) && (!causal || (t * kTileK <= wave_qmax + shift));
     if (wave_active) {
       const char* kt = smem + CUR * kBuf;
       const char* vt = smem + (2 + CUR) * kBuf;

@@ -218,7 +218,7 @@ int vsel_splice_batched(void* stream, const int64_t* input_ids, int64_t total_le
  * Replaces flash_attn_varlen_func as called by FT/qwenvl/train/trainer.py:101-113 and the FA2 prefill
  * of EV/qwen25vl/modeling_qwen2_5_vl.py:900 / OV/llavaonevision1_5/modeling_llavaonevision1_5.py:686.
  *   q [T, Hq, d], k/v [T, Hkv, d] bf16, already rotated; cu_seqlens DEVICE int32 [n_seq + 1]
- *   (the tensor the reference passes as `attention_mask`); out [T, Hq, d] bf16.  d must be 128.
+ *   (the tensor the reference passes as `attention_mask`); out [T, Hq, d] bf16.  d in {128 (the LLMs), 80, 64 (vision towers)}.
  * Math: softmax(q k^T * scale + causal) v with fp32 softmax (EV/qwen25vl/modeling_qwen2_5_vl.py:777-797). */
 int vsel_varlen_attn_fwd(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens,
                          int64_t n_seq, int64_t max_seqlen, int64_t total, int64_t hq, int64_t hkv, int64_t d,
@@ -234,6 +234,13 @@ int vsel_paged_attn_fwd(void* stream, const void* q, const void* k_cache, const 
                         const int32_t* cu_seqlens_q, const int32_t* seqlens_k, const int32_t* block_table,
                         int64_t max_pages_per_seq, int64_t page_size, int64_t n_seq, int64_t max_seqlen_q, int64_t hq,
                         int64_t hkv, int64_t d, float scale, int causal, void* out);
+
+/* Same kernel with separate query / key packings (flash_attn_varlen_func's general form: cu_seqlens_q != cu_seqlens_k):
+ * sequence s owns query rows [cu_seqlens_q[s], cu_seqlens_q[s+1]) of q and key rows [cu_seqlens_k[s], +seqlens_k[s]) of
+ * k / v (contiguous, [total_k, hkv, d]); causal masking is bottom-right aligned (flash-attn >= 2.1).  Forward only.     */
+int vsel_varlen_attn_fwd_kv(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens_q,
+                            const int32_t* cu_seqlens_k, const int32_t* seqlens_k, int64_t n_seq, int64_t max_seqlen_q,
+                            int64_t hq, int64_t hkv, int64_t d, float scale, int causal, void* out);
 
 /* -------- var-len attention for TRAINING: forward that also saves the log-sum-exp, and the backward -------------
  * The reference trains the LIS through the frozen LLM with flash_attn_varlen_func (FT/qwenvl/train/trainer.py:101-113,

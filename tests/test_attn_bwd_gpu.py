@@ -130,3 +130,44 @@ def test_split_and_grouped_dkdv_agree(ops):
     assert torch.equal(g0[0], g1[0])                                   # dQ does not depend on the mode
     for a, b in zip(g0[1:], g1[1:]):
         assert float((a.float() - b.float()).abs().max()) <= 2 ** -7 * float(a.float().abs().max())
+
+
+def test_flash_attn_compat_functions(ops):
+    """flash_attn_varlen_func / flash_attn_func with the flash-attn call shapes: same packing (differentiable), different
+    query / key packings (forward only, bottom-right causal) and the batched dense form."""
+    from visionselector_amd.flash_attn_compat import flash_attn_func, flash_attn_varlen_func
+    q, k, v, do, cu = _case([150, 64, 9], 4, 2, seed=31)
+    cu_d = torch.from_numpy(cu).cuda()
+    qd, kd, vd = [t.cuda().requires_grad_(True) for t in (q, k, v)]
+    out = flash_attn_varlen_func(qd, kd, vd, cu_d, cu_d, 150, 150, causal=True)
+    out.backward(do.cuda())
+    a = [x.float().numpy() for x in (q, k, v)]
+    ref = oattn.varlen_attention(*a, cu, causal=True)
+    rq, rk, rv = oattn.varlen_attention_backward(*a, cu, do.float().numpy(), causal=True)
+    assert np.abs(out.detach().float().cpu().numpy() - ref).max() <= 8e-3 * max(1.0, np.abs(ref).max())
+    assert _rel(qd.grad, rq) <= 2 ** -6 and _rel(kd.grad, rk) <= 2 ** -6 and _rel(vd.grad, rv) <= 2 ** -6
+    # different packings: 3 sequences with (q, k) lengths (5, 70), (1, 33), (40, 40)
+    rng = np.random.default_rng(5)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s, dtype=np.float32)).bfloat16()  # noqa: E731
+    q2, k2, v2 = f(46, 4, 128), f(143, 2, 128), f(143, 2, 128)
+    cq = torch.tensor([0, 5, 6, 46], dtype=torch.int32).cuda()
+    ck = torch.tensor([0, 70, 103, 143], dtype=torch.int32).cuda()
+    o2 = flash_attn_varlen_func(q2.cuda(), k2.cuda(), v2.cuda(), cq, ck, 40, 70, causal=True)
+    # oracle through the paged form: one page per sequence
+    pages = np.zeros((3, 70, 2, 128), np.float32)
+    vpages = np.zeros((3, 70, 2, 128), np.float32)
+    for s, (a0, b0) in enumerate([(0, 70), (70, 103), (103, 143)]):
+        pages[s, : b0 - a0] = k2[a0:b0].float().numpy()
+        vpages[s, : b0 - a0] = v2[a0:b0].float().numpy()
+    ref2 = oattn.paged_attention(q2.float().numpy(), pages, vpages, cq.cpu().numpy(), np.array([70, 33, 40]),
+                                 np.array([[0], [1], [2]]), causal=True)
+    assert np.abs(o2.float().cpu().numpy() - ref2).max() <= 8e-3 * max(1.0, np.abs(ref2).max())
+    with pytest.raises(RuntimeError, match="no backward"):
+        flash_attn_varlen_func(q2.cuda().requires_grad_(True), k2.cuda(), v2.cuda(), cq, ck, 40, 70, causal=True)
+    # dense batched form
+    qb, kb, vb = f(2, 100, 4, 128), f(2, 100, 2, 128), f(2, 100, 2, 128)
+    ob = flash_attn_func(qb.cuda(), kb.cuda(), vb.cuda(), causal=True)
+    refb = oattn.varlen_attention(qb.reshape(200, 4, 128).float().numpy(), kb.reshape(200, 2, 128).float().numpy(),
+                                  vb.reshape(200, 2, 128).float().numpy(), np.array([0, 100, 200]), causal=True)
+    assert ob.shape == (2, 100, 4, 128)
+    assert np.abs(ob.reshape(200, 4, 128).float().cpu().numpy() - refb).max() <= 8e-3 * max(1.0, np.abs(refb).max())

@@ -18,19 +18,19 @@ def ops():
     return _ops
 
 
-def make_qkv(total, hq, hkv, seed, spike=False):
+def make_qkv(total, hq, hkv, seed, spike=False, d=128):
     rng = np.random.default_rng(seed)
     f = lambda *s: torch.from_numpy(rng.standard_normal(s, dtype=np.float32)).bfloat16()  # noqa: E731
-    q, k, v = f(total, hq, 128), f(total, hkv, 128), f(total, hkv, 128)
+    q, k, v = f(total, hq, d), f(total, hkv, d), f(total, hkv, d)
     if spike:      # force large running-max jumps late in the sequence (online-softmax rescale path)
         k[total // 2] *= 6
         k[total - 3] *= 9
     return q, k, v
 
 
-def run_case(ops, lens, hq, hkv, causal, seed, spike=False):
+def run_case(ops, lens, hq, hkv, causal, seed, spike=False, d=128):
     total = sum(lens)
-    q, k, v = make_qkv(total, hq, hkv, seed, spike)
+    q, k, v = make_qkv(total, hq, hkv, seed, spike, d)
     cu = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
     out = ops.varlen_attn(q.cuda(), k.cuda(), v.cuda(), torch.from_numpy(cu).cuda(), max(lens), causal=causal)
     ref = oattn.varlen_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu, causal=causal)
@@ -168,3 +168,18 @@ def test_workgroup_shapes_agree(ops):
     ref = oattn.varlen_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu.cpu().numpy())
     err = np.abs(outs[1].float().cpu().numpy() - ref)
     check(err.max(), err.mean(), np.abs(ref).max())
+
+
+@pytest.mark.parametrize("d", [80, 64])
+@pytest.mark.parametrize("lens,hq,hkv,causal", [([64] * 9, 16, 16, False), ([576], 16, 16, False), ([100, 64, 3, 333], 4, 2, True),
+                                                 ([64, 64, 16, 48], 2, 2, False)])
+def test_attention_vision_tower_head_dims(ops, d, lens, hq, hkv, causal):
+    """head_dim 80 (Qwen2.5-VL ViT) and 64 (Rice ViT): packed non-causal windows of 64 tokens, full attention, ragged tails."""
+    check(*run_case(ops, lens, hq, hkv, causal, seed=d + len(lens), d=d))
+
+
+def test_attention_rejects_unsupported_head_dim(ops):
+    from visionselector_amd._native import VselError
+    q = torch.zeros(8, 2, 96, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(VselError, match="head_dim"):
+        ops.varlen_attn(q, q, q, torch.tensor([0, 8], dtype=torch.int32, device="cuda"), 8)

@@ -663,3 +663,33 @@ def test_native_attention_prefill_then_decode_matches_sdpa():
         assert a.shape == b.shape
         # TOLERANCE 3e-2 of the logits' max magnitude: two bf16 attention implementations through 2 bf16 layers
         assert float((a - b).abs().max()) <= 3e-2 * max(1.0, float(b.abs().max()))
+
+
+def test_vision_tower_through_packed_native_attention_matches_sdpa():
+    """Qwen2.5-VL vision tower (window + full attention layers, head_dim 64 here, 80 in the 7B) with the packed var-len
+    kernel (ATTN_NAME_PACKED: one launch per layer over cu_seqlens) vs transformers' per-window SDPA loop."""
+    from transformers import Qwen2_5_VLConfig
+    from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as hf
+    from visionselector_amd import _native as N
+    from visionselector_amd.attention import ATTN_NAME_PACKED, replace_qwen2_vl_attention_class
+    replace_qwen2_vl_attention_class()
+    vc = Qwen2_5_VLConfig(vision_config=dict(depth=4, hidden_size=256, num_heads=4, intermediate_size=512, out_hidden_size=128,
+                                             patch_size=14, spatial_merge_size=2, temporal_patch_size=2, window_size=112,
+                                             fullatt_block_indexes=[1, 3], in_channels=3)).vision_config
+    torch.manual_seed(0)
+    tower = hf.Qwen2_5_VisionTransformerPretrainedModel(vc).cuda().bfloat16().eval()
+    g = torch.Generator().manual_seed(2)
+    pix = torch.randn(2 * 24 * 24 + 16 * 16, 3 * 2 * 14 * 14, generator=g).bfloat16().cuda()
+    grid = torch.tensor([[2, 24, 24], [1, 16, 16]]).cuda()                    # a 2-frame video-like grid and a small image
+    outs = {}
+    for impl in ("sdpa", ATTN_NAME_PACKED):
+        tower.config._attn_implementation = impl
+        N.profile_start()
+        with torch.no_grad():
+            outs[impl] = tower(pix, grid).pooler_output.float()
+        prof = N.profile_stop()
+        if impl == ATTN_NAME_PACKED:
+            assert prof["varlen_attn_fwd_kernel"][1] == 4, prof                # ONE launch per layer
+    ref, got = outs["sdpa"], outs[ATTN_NAME_PACKED]
+    # TOLERANCE 3e-2 of the output's max: two bf16 attention implementations through 4 bf16 ViT blocks + merger
+    assert float((got - ref).abs().max()) <= 3e-2 * float(ref.abs().max())

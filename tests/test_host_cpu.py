@@ -218,3 +218,40 @@ def test_eval_time_log_reader(tmp_path):
     assert s["samples"] == 2 and s["avg_prefill_ms"] == 10.0 and s["avg_latency_ms"] == 100.5
     assert s["avg_visual_tokens"] == 1440.0 and s["avg_max_memory_GB"] == 12.0
     assert parse_log(["nothing here"]) == {"memory_bytes": [], "latency_ms": [], "prefill_ms": [], "visual_tokens": []}
+
+
+def test_flash_attn_shim_helpers_cpu():
+    """dropin/flash_attn: module paths the reference imports resolve, and the padding / rotary helpers (pure index and
+    elementwise torch ops) behave like flash-attn 2.7's."""
+    sys.path.insert(0, os.path.join(ROOT, "visionselector_amd", "dropin"))
+    try:
+        for m in [k for k in sys.modules if k == "flash_attn" or k.startswith("flash_attn.")]:
+            del sys.modules[m]
+        from flash_attn import flash_attn_func, flash_attn_varlen_func  # noqa: F401
+        from flash_attn.bert_padding import index_first_axis, pad_input, unpad_input
+        from flash_attn.flash_attn_interface import flash_attn_varlen_func as f2
+        from flash_attn.layers.rotary import apply_rotary_emb
+        assert f2 is flash_attn_varlen_func
+    finally:
+        sys.path.pop(0)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 5, 4, generator=g)
+    mask = torch.tensor([[1, 1, 1, 0, 0], [1, 1, 1, 1, 1], [1, 0, 0, 0, 0]])
+    tok, idx, cu, mx, lens = unpad_input(x, mask)
+    assert tok.shape == (9, 4) and cu.tolist() == [0, 3, 8, 9] and cu.dtype == torch.int32 and mx == 5 and lens.tolist() == [3, 5, 1]
+    assert torch.equal(tok, x.reshape(15, 4)[idx]) and torch.equal(index_first_axis(x.reshape(15, 4), idx), tok)
+    back = pad_input(tok, idx, 3, 5)
+    assert torch.equal(back, x * mask[..., None])
+    # rotary: matches the textbook rotation on the first rotary_dim features, both layouts
+    xs = torch.randn(2, 6, 3, 16, generator=g)
+    ang = torch.randn(6, 4, generator=g)
+    cos, sin = ang.cos(), ang.sin()
+    out = apply_rotary_emb(xs, cos, sin)
+    x1, x2 = xs[..., :4], xs[..., 4:8]
+    c, s = cos[None, :, None, :], sin[None, :, None, :]
+    assert torch.allclose(out[..., :4], x1 * c - x2 * s, atol=1e-6) and torch.allclose(out[..., 4:8], x1 * s + x2 * c, atol=1e-6)
+    assert torch.equal(out[..., 8:], xs[..., 8:])
+    outi = apply_rotary_emb(xs, cos, sin, interleaved=True)
+    assert torch.allclose(outi[..., 0:8:2], xs[..., 0:8:2] * c - xs[..., 1:8:2] * s, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        flash_attn_varlen_func(xs, xs, xs, cu, cu, 5, 5, dropout_p=0.1)

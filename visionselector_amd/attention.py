@@ -19,6 +19,12 @@ import torch
 from . import ops
 
 ATTN_NAME = "vsel_varlen"
+# Same function under a name that contains "flash": transformers hands var-len metadata (cu_seq_lens_q / max_length_q) to an
+# attention interface only when `is_flash_attention_requested(config)` -- e.g. the Qwen2.5-VL vision tower otherwise splits
+# the packed windows and calls the interface once per window (144 calls per layer at 1344 x 1344).  Use this name for
+# vision towers (head_dim 80 / 64, non-causal windows), where the reference itself calls flash_attn_varlen_func
+# (qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py, Qwen2_5_VLVisionFlashAttention2).
+ATTN_NAME_PACKED = "vsel_flash_varlen"
 
 
 class _VarlenAttnFunction(torch.autograd.Function):
@@ -131,6 +137,7 @@ def replace_qwen2_vl_attention_class():
     import transformers
     from transformers import AttentionInterface
     AttentionInterface.register(ATTN_NAME, vsel_attention_forward)
+    AttentionInterface.register(ATTN_NAME_PACKED, vsel_attention_forward)
     for mod_name, cls_name in (("qwen2_vl", "Qwen2VLModel"), ("qwen2_5_vl", "Qwen2_5_VLModel")):
         mod = getattr(getattr(transformers.models, mod_name, None), f"modeling_{mod_name}", None)
         if mod is None:

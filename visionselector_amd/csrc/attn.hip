@@ -1,4 +1,5 @@
-// Var-len causal GQA attention forward for the compressed-sequence prefill (gfx950, bf16, head_dim 128).
+// Var-len (causal or full) GQA attention forward (gfx950, bf16): head_dim 128 for the compressed-sequence prefill of the LLMs,
+// head_dim 80 / 64 for the var-len window attention of the vision towers (Qwen2.5-VL ViT: 1280 / 16, Rice ViT: 1024 / 16).
 //
 // Replaces flash_attn_varlen_func / the FA2 prefill the reference reaches through
 //   qwen-vl-finetune/qwenvl/train/trainer.py:101-113          (cu_seqlens passed as `attention_mask`)
@@ -27,7 +28,7 @@ namespace vsel {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int kHeadDim = 128;
+constexpr int kMaxHeadDim = 128;   // LDS rows are 256 bytes for every supported head_dim (multiples of 16 up to 128)
 constexpr int kTileK = 64;
 constexpr int kRowBytes = 256;
 constexpr int kBuf = kTileK * kRowBytes;     // 16 KiB per tile
@@ -54,7 +55,9 @@ struct PagedKV {
 
 // NW = waves per workgroup (4 -> 128 queries, two workgroups per CU; 8 -> 256 queries, one workgroup per CU sharing ONE K/V
 // stream among its 8 waves: half the global loads and LDS stores per FLOP, used when the grid is large enough).
-template <bool USE_TR, int NW>
+// D = head_dim (64, 80, 128): D / 16 k-steps for S, ceil(D / 32) d-tiles for O (columns past D are computed on whatever the
+// unused LDS parts hold and never stored).
+template <bool USE_TR, int NW, int D>
 __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                               const uint16_t* __restrict__ v,
                                                               const int32_t* __restrict__ cu, int hq, int hkv,
@@ -64,6 +67,10 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   constexpr int kBlockQ = 32 * NW;
   constexpr int kThreads = 64 * NW;
   constexpr int kLoadsPerWave = 16 / NW;           // 1-KiB wave-instructions per tile per tensor
+  constexpr int kHeadDim = D;
+  constexpr int kSteps = D / 16;                   // k-steps of S^T = K Q^T
+  constexpr int kDTiles = (D + 31) / 32;           // 32-wide d-tiles of O^T
+  constexpr int kParts = D / 8;                    // 16-byte parts per row that hold data
   __shared__ __attribute__((aligned(16))) char smem[kLds];
   __shared__ int s_item;
   char* const k_sm = smem;
@@ -75,20 +82,23 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   // the 8 consecutive keys 16m + 8hh .. +7 of the 32-key block.
   const int key_row = (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1);
   // per-lane LDS byte offsets inside a tile; the buffer, the 32-key block and the 16-key step add immediates
-  int row_addr[8], tr_addr[4][2];
+  int row_addr[kSteps], tr_addr[kDTiles][2];
 #pragma unroll
-  for (int st = 0; st < 8; ++st) row_addr[st] = chunk_off(key_row, 2 * st + hh);
+  for (int st = 0; st < kSteps; ++st) row_addr[st] = chunk_off(key_row, 2 * st + hh);
   {
     const int p16 = lane & 15;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < kDTiles; ++dt)
 #pragma unroll
       for (int hi = 0; hi < 2; ++hi)
         tr_addr[dt][hi] = chunk_off(8 * hh + (p16 >> 2) + 4 * hi, 4 * dt + 2 * ((lane >> 4) & 1) + ((p16 & 3) >> 1)) + 8 * (p16 & 1);
   }
   // direct-to-LDS loads: wave w issues wave-instructions w, w + NW, ...; instruction i covers tile rows 4i .. 4i+3, lane l
   // lands at (row 4i + (l >> 4), position l & 15) and therefore fetches global part (l & 15) ^ swz(row)
-  const int ld_part = ((lane & 15) ^ (((lane >> 4) << 2) | (wave & 3))) * 8;
+  // (a source part past the row's data, head_dim < 128, is redirected to part 0: its LDS position is never read for S and only
+  // feeds output columns >= D)
+  const int ld_src = (lane & 15) ^ (((lane >> 4) << 2) | (wave & 3));
+  const int ld_part = (ld_src < kParts ? ld_src : 0) * 8;
 
   for (int round = 0;; ++round) {
   int item;
@@ -120,15 +130,15 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   const int wave_qmax = min(q0 + wave * 32 + 31, qlen - 1);
 
   // Q^T fragments (B operand of S^T = K Q^T): lane (j, hh) holds q[my_q][16*step + 8*hh .. +7]
-  u32x4 qf[8];
+  u32x4 qf[kSteps];
   {
     const uint16_t* qp = q + ((int64_t)(qs + my_q) * hq + head) * kHeadDim + 8 * hh;
 #pragma unroll
-    for (int st = 0; st < 8; ++st) qf[st] = *reinterpret_cast<const u32x4*>(qp + 16 * st);
+    for (int st = 0; st < kSteps; ++st) qf[st] = *reinterpret_cast<const u32x4*>(qp + 16 * st);
   }
-  f32x16 o[4];
+  f32x16 o[kDTiles];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
+  for (int dt = 0; dt < kDTiles; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
@@ -137,15 +147,16 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   const int n_tiles = (kv_end + kTileK - 1) / kTileK;
   if (n_tiles <= 0) {     // no visible key for this whole q-tile (key sequence shorter than the query offset): zeros
     if (q_valid) {
-      uint16_t* op = out + ((int64_t)(qs + my_q) * hq + head) * kHeadDim + 64 * hh;
+      uint16_t* op = out + ((int64_t)(qs + my_q) * hq + head) * kHeadDim;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) *reinterpret_cast<u32x4*>(op + 8 * c) = u32x4{0u, 0u, 0u, 0u};
+      for (int c = 0; c < kParts; ++c)
+        if ((c & 1) == hh) *reinterpret_cast<u32x4*>(op + 8 * c) = u32x4{0u, 0u, 0u, 0u};
       if (lse && hh == 0) lse[(int64_t)(qs + my_q) * hq + head] = -INFINITY;
     }
     continue;
   }
 
-  const int64_t kv_base = ((int64_t)ks * hkv + kvh) * kHeadDim + ld_part;        // contiguous keys: row r adds r * hkv * 128
+  const int64_t kv_base = ((int64_t)ks * hkv + kvh) * kHeadDim + ld_part;        // contiguous keys: row r adds r * hkv * D
   auto load_tile = [&](int t, int buf) {
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
-        for (int st = 0; st < 8; ++st) {
+        for (int st = 0; st < kSteps; ++st) {
           const u32x4 a = *reinterpret_cast<const u32x4*>(kt + row_addr[st] + kb * 32 * kRowBytes);
           s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(a), to_bf16x8(qf[st]), s[kb], 0, 0, 0);
         }
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
         m_run = m_new;
         l_run *= alpha;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < kDTiles; ++dt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
       }
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
         for (int mm = 0; mm < 2; ++mm) {
           const int off = (32 * kb + 16 * mm) * kRowBytes;
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
+          for (int dt = 0; dt < kDTiles; ++dt) {
             bf16x8_t vf;
             if constexpr (USE_TR) {
               // 16-lane group: lane p supplies the address of row (p >> 2), 4-column chunk (p & 3) of a [4 keys x 16 d]
@@ -287,10 +298,11 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
       lse[(int64_t)(qs + my_q) * hq + head] = l_tot > 0.f ? (m_run + log2f(l_tot)) * 0.6931471805599453f : -INFINITY;
     uint16_t* op = out + ((int64_t)(qs + my_q) * hq + head) * kHeadDim;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < kDTiles; ++dt)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int d0 = 32 * dt + 8 * g4 + 4 * hh;
+        if (d0 >= kHeadDim) continue;                 // head_dim 80: the last d-tile is half padding
         const uint32_t w0 = f32_to_bf16_bits(o[dt][4 * g4] * inv) | (f32_to_bf16_bits(o[dt][4 * g4 + 1] * inv) << 16);
         const uint32_t w1 = f32_to_bf16_bits(o[dt][4 * g4 + 2] * inv) | (f32_to_bf16_bits(o[dt][4 * g4 + 3] * inv) << 16);
         uint2 pk;
@@ -312,8 +324,8 @@ extern "C" void vsel_debug_attn_use_tr(int on) { g_attn_use_tr = on != 0; }
 extern "C" void vsel_debug_attn_waves(int nw) { g_attn_nw = nw; }
 
 static int attn_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
-                       int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg,
-                       float* lse = nullptr) {
+                       int64_t max_seqlen_q, int64_t hq, int64_t hkv, int64_t d, float scale, int causal, void* out,
+                       const PagedKV& pg, float* lse = nullptr) {
   // 8-wave workgroups (256 queries) when there is enough work to fill the chip with them, else 4-wave (128 queries)
   const int64_t items8 = cdiv(max_seqlen_q, 256) * hq * n_seq;
   // measured on MI355X (tools/exp_attn_nw.py): 8 waves +12-16 % at L >= 4096, +4 % at 16 x 2368, -20 % at L = 524
@@ -333,13 +345,19 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   }
   const dim3 grid((unsigned)std::min<int64_t>(n_items, slots));
   const float sl2 = scale * 1.4426950408889634f;
-#define VSEL_ATTN_LAUNCH(TR, NWV)                                                                                          \
-  hipLaunchKernelGGL((varlen_attn_fwd_kernel<TR, NWV>), grid, dim3(64 * NWV), 0, st, (const uint16_t*)q, (const uint16_t*)k, \
+#define VSEL_ATTN_LAUNCH(TR, NWV, DV)                                                                                          \
+  hipLaunchKernelGGL((varlen_attn_fwd_kernel<TR, NWV, DV>), grid, dim3(64 * NWV), 0, st, (const uint16_t*)q, (const uint16_t*)k, \
                      (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg, lse)
-  if (g_attn_use_tr) {
-    if (big) VSEL_ATTN_LAUNCH(true, 8); else VSEL_ATTN_LAUNCH(true, 4);
-  } else {
-    if (big) VSEL_ATTN_LAUNCH(false, 8); else VSEL_ATTN_LAUNCH(false, 4);
+  if (d == 128) {
+    if (g_attn_use_tr) {
+      if (big) VSEL_ATTN_LAUNCH(true, 8, 128); else VSEL_ATTN_LAUNCH(true, 4, 128);
+    } else {
+      if (big) VSEL_ATTN_LAUNCH(false, 8, 128); else VSEL_ATTN_LAUNCH(false, 4, 128);
+    }
+  } else if (d == 80) {          // Qwen2.5-VL vision tower
+    if (big) VSEL_ATTN_LAUNCH(true, 8, 80); else VSEL_ATTN_LAUNCH(true, 4, 80);
+  } else {                       // d == 64: Rice ViT (LLaVA-OV-1.5)
+    if (big) VSEL_ATTN_LAUNCH(true, 8, 64); else VSEL_ATTN_LAUNCH(true, 4, 64);
   }
 #undef VSEL_ATTN_LAUNCH
   VSEL_AFTER_LAUNCH(st, "varlen_attn_fwd_kernel");
@@ -349,7 +367,7 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
 static int attn_checks(const void* q, const void* k, const void* v, const int32_t* cu, const void* out, int64_t n_seq,
                        int64_t max_seqlen, int64_t hq, int64_t hkv, int64_t d) {
   if (!q || !k || !v || !cu || !out) return fail(VSEL_ERR_INVALID, "NULL pointer");
-  if (d != kHeadDim) return fail(VSEL_ERR_UNSUPPORTED, "head_dim %lld != 128", (long long)d);
+  if (d != 128 && d != 80 && d != 64) return fail(VSEL_ERR_UNSUPPORTED, "head_dim %lld not in {64, 80, 128}", (long long)d);
   if (n_seq < 1 || max_seqlen < 1 || hq < 1 || hkv < 1 || hq % hkv != 0 || n_seq > (1 << 24) || hq > 65535)
     return fail(VSEL_ERR_INVALID, "bad attention shape (n_seq=%lld max_seqlen=%lld hq=%lld hkv=%lld)", (long long)n_seq,
                 (long long)max_seqlen, (long long)hq, (long long)hkv);
@@ -365,7 +383,7 @@ extern "C" int vsel_varlen_attn_fwd(void* stream, const void* q, const void* k, 
   if (total < 1) return fail(VSEL_ERR_INVALID, "total must be >= 1");
   hipStream_t st = (hipStream_t)stream;
   VSEL_PROF_BEGIN(st);
-  return attn_launch(st, q, k, v, cu_seqlens, n_seq, max_seqlen, hq, hkv, scale, causal, out, PagedKV{nullptr, nullptr, nullptr, 0, 1});
+  return attn_launch(st, q, k, v, cu_seqlens, n_seq, max_seqlen, hq, hkv, d, scale, causal, out, PagedKV{nullptr, nullptr, nullptr, 0, 1});
 }
 
 extern "C" int vsel_varlen_attn_fwd_lse(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens,
@@ -376,8 +394,21 @@ extern "C" int vsel_varlen_attn_fwd_lse(void* stream, const void* q, const void*
   if (total < 1 || !lse) return fail(VSEL_ERR_INVALID, "total must be >= 1 and lse non-NULL");
   hipStream_t st = (hipStream_t)stream;
   VSEL_PROF_BEGIN(st);
-  return attn_launch(st, q, k, v, cu_seqlens, n_seq, max_seqlen, hq, hkv, scale, causal, out,
+  return attn_launch(st, q, k, v, cu_seqlens, n_seq, max_seqlen, hq, hkv, d, scale, causal, out,
                      PagedKV{nullptr, nullptr, nullptr, 0, 1}, lse);
+}
+
+extern "C" int vsel_varlen_attn_fwd_kv(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens_q,
+                                       const int32_t* cu_seqlens_k, const int32_t* seqlens_k, int64_t n_seq,
+                                       int64_t max_seqlen_q, int64_t hq, int64_t hkv, int64_t d, float scale, int causal,
+                                       void* out) {
+  int rc = attn_checks(q, k, v, cu_seqlens_q, out, n_seq, max_seqlen_q, hq, hkv, d);
+  if (rc) return rc;
+  if (!cu_seqlens_k || !seqlens_k) return fail(VSEL_ERR_INVALID, "cu_seqlens_k / seqlens_k is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(st);
+  return attn_launch(st, q, k, v, cu_seqlens_q, n_seq, max_seqlen_q, hq, hkv, d, scale, causal, out,
+                     PagedKV{seqlens_k, nullptr, cu_seqlens_k, 0, 1});
 }
 
 extern "C" int vsel_paged_attn_fwd(void* stream, const void* q, const void* k_cache, const void* v_cache,
@@ -392,6 +423,6 @@ extern "C" int vsel_paged_attn_fwd(void* stream, const void* q, const void* k_ca
                 (long long)max_pages_per_seq);
   hipStream_t st = (hipStream_t)stream;
   VSEL_PROF_BEGIN(st);
-  return attn_launch(st, q, k_cache, v_cache, cu_seqlens_q, n_seq, max_seqlen_q, hq, hkv, scale, causal, out,
+  return attn_launch(st, q, k_cache, v_cache, cu_seqlens_q, n_seq, max_seqlen_q, hq, hkv, d, scale, causal, out,
                      PagedKV{seqlens_k, block_table, nullptr, (int)max_pages_per_seq, (int)page_size});
 }

@@ -512,6 +512,26 @@ def varlen_attn_bwd(dout, q, k, v, out, lse, cu_seqlens: torch.Tensor, max_seqle
     return dq, dk, dv
 
 
+def varlen_attn_kv(q, k, v, cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor, max_seqlen_q: int, causal: bool = True,
+                   softmax_scale: Optional[float] = None) -> torch.Tensor:
+    """Separate query / key packings: q [Tq,Hq,d], k/v [Tk,Hkv,d] bf16, cu_seqlens_q / cu_seqlens_k int32 [S+1] ->
+    out [Tq,Hq,d].  Bottom-right aligned causal mask (query i of a sequence sees keys <= i + klen - qlen)."""
+    dev = _dev(q, k, v, cu_seqlens_q, cu_seqlens_k)
+    if q.dtype != torch.bfloat16 or k.dtype != torch.bfloat16 or v.dtype != torch.bfloat16:
+        raise TypeError("varlen_attn_kv takes bfloat16 q/k/v")
+    if cu_seqlens_q.dtype != torch.int32 or cu_seqlens_k.dtype != torch.int32 or cu_seqlens_q.numel() != cu_seqlens_k.numel():
+        raise TypeError("cu_seqlens_q / cu_seqlens_k must be int32 of the same length")
+    tq, hq, d = q.shape
+    hkv = k.shape[1]
+    scale = float(softmax_scale) if softmax_scale is not None else d ** -0.5
+    seqlens_k = (cu_seqlens_k[1:] - cu_seqlens_k[:-1]).contiguous()
+    out = torch.empty_like(q)
+    N.check(N.lib().vsel_varlen_attn_fwd_kv(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), cu_seqlens_q.data_ptr(),
+                                            cu_seqlens_k.data_ptr(), seqlens_k.data_ptr(), cu_seqlens_q.numel() - 1,
+                                            int(max_seqlen_q), hq, hkv, d, scale, int(causal), out.data_ptr()))
+    return out
+
+
 def paged_attn(q, k_cache, v_cache, cu_seqlens_q: torch.Tensor, seqlens_k: torch.Tensor, block_table: torch.Tensor,
                max_seqlen_q: int, causal: bool = True, softmax_scale: Optional[float] = None) -> torch.Tensor:
     """q [Tq,Hq,d] bf16; k_cache / v_cache [n_pages, page_size, Hkv, d] bf16; cu_seqlens_q int32 [S+1];

@@ -626,8 +626,10 @@ def test_llavaov15_class_factory_builds_the_three_selector_classes():
     assert m.lm_head.weight.shape == (64, 128)
 
 
-def test_native_attention_prefill_then_decode_matches_sdpa():
-    """attn_implementation = vsel_varlen for a whole generate()-style run: prefill (var-len kernel), then decode steps and a
+@pytest.mark.parametrize("impl_name", ["vsel_varlen", "vsel_flash_varlen"])
+def test_native_attention_prefill_then_decode_matches_sdpa(impl_name):
+    """attn_implementation = vsel_varlen / vsel_flash_varlen (the name transformers treats as a flash flavour: no 4-D mask,
+    var-len metadata passed through) for a whole generate()-style run: prefill (var-len kernel), then decode steps and a
     3-token chunk against the cache (paged kernel, one page per batch row), vs the same bf16 model on SDPA."""
     from transformers import Qwen2Config, Qwen2ForCausalLM
     from visionselector_amd.attention import ATTN_NAME, replace_qwen2_vl_attention_class
@@ -656,7 +658,7 @@ def test_native_attention_prefill_then_decode_matches_sdpa():
     ref = run("sdpa")
     from visionselector_amd import _native as N
     N.profile_start()
-    got = run(ATTN_NAME)
+    got = run(impl_name)
     prof = N.profile_stop()
     assert prof["varlen_attn_fwd_kernel"][1] == 2 * 4, prof            # 2 layers x (prefill + 3 cache steps), all native
     for a, b in zip(got, ref):

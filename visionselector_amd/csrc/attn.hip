@@ -18,24 +18,19 @@
 //   16-byte part p of row r stored at p ^ swz(r), swz(r) = ((r & 3) << 2) | ((r >> 2) & 3): conflict-free for the K row
 //   reads (ds_read_b128) and for the V transpose reads (ds_read_b64_tr_b16); the direct loads write LDS lane-linearly,
 //   so the swizzle is applied to their SOURCE address.  Online softmax in exp2 domain, fp32.
-#include "common.h"
+#include "attn_common.h"
 
 #include <algorithm>
 #include <type_traits>
 
 namespace vsel {
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+using namespace attn;      // tile layout + fragment addressing shared with the backward (attn_common.h)
 
 constexpr int kMaxHeadDim = 128;   // LDS rows are 256 bytes for every supported head_dim (multiples of 16 up to 128)
 constexpr int kTileK = 64;
-constexpr int kRowBytes = 256;
-constexpr int kBuf = kTileK * kRowBytes;     // 16 KiB per tile
+constexpr int kBuf = kTileBytes;             // 16 KiB per tile
 constexpr int kLds = 4 * kBuf;               // K[2], V[2]: 64 KiB
-
-__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-__device__ __forceinline__ int chunk_off(int row, int part) { return row * kRowBytes + ((part ^ swz(row)) << 4); }
 
 __device__ __forceinline__ bf16x8_t to_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 
@@ -80,24 +75,16 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   const int j = lane & 31, hh = lane >> 5;
   // A-row i of the K operand holds key pi(i) (bits 2 and 3 swapped) so that C registers 8m..8m+7 of lane half hh are
   // the 8 consecutive keys 16m + 8hh .. +7 of the 32-key block.
-  const int key_row = (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1);
-  // per-lane LDS byte offsets inside a tile; the buffer, the 32-key block and the 16-key step add immediates
+  // per-lane LDS byte offsets inside a tile; the buffer, the 32-key block and the 16-key step add immediates.  K rows are
+  // read permuted (perm_row) so that one lane's P registers are 8 consecutive keys.
   int row_addr[kSteps], tr_addr[kDTiles][2];
-#pragma unroll
-  for (int st = 0; st < kSteps; ++st) row_addr[st] = chunk_off(key_row, 2 * st + hh);
-  {
-    const int p16 = lane & 15;
-#pragma unroll
-    for (int dt = 0; dt < kDTiles; ++dt)
-#pragma unroll
-      for (int hi = 0; hi < 2; ++hi)
-        tr_addr[dt][hi] = chunk_off(8 * hh + (p16 >> 2) + 4 * hi, 4 * dt + 2 * ((lane >> 4) & 1) + ((p16 & 3) >> 1)) + 8 * (p16 & 1);
-  }
+  make_row_addr<kSteps>(row_addr, j, hh);
+  make_tr_addr<kDTiles>(tr_addr, lane);
   // direct-to-LDS loads: wave w issues wave-instructions w, w + NW, ...; instruction i covers tile rows 4i .. 4i+3, lane l
   // lands at (row 4i + (l >> 4), position l & 15) and therefore fetches global part (l & 15) ^ swz(row)
   // (a source part past the row's data, head_dim < 128, is redirected to part 0: its LDS position is never read for S and only
   // feeds output columns >= D)
-  const int ld_src = (lane & 15) ^ (((lane >> 4) << 2) | (wave & 3));
+  const int ld_src = slice_src_part(lane, wave);
   const int ld_part = (ld_src < kParts ? ld_src : 0) * 8;
 
   for (int round = 0;; ++round) {

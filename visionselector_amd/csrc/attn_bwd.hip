@@ -17,45 +17,22 @@
 // P is recomputed from the forward's log-sum-exp (vsel_varlen_attn_fwd_lse).  One LDS layout serves both the row (b128) and
 // the transposed (b64_tr) reads without bank conflicts: 256-byte rows, 16-byte part p of row r stored at part p ^ swz(r),
 // swz(r) = ((r & 3) << 2) | ((r >> 2) & 3).
-#include "common.h"
+#include "attn_common.h"
 
 #include <algorithm>
 #include <type_traits>
 
 namespace vsel {
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-
 namespace bwd {
 
+using namespace attn;      // tile layout + fragment addressing shared with the forward (attn_common.h)
+
 constexpr int kD = 128;            // head_dim
-constexpr int kRowB = 256;         // bytes per row of a tile
-constexpr int kTile = 64;          // rows per LDS tile
-constexpr int kTileB = kTile * kRowB;   // 16 KiB
+constexpr int kRowB = kRowBytes;
+constexpr int kTile = kTileRows;   // rows per LDS tile
+constexpr int kTileB = kTileBytes;
 constexpr float kLog2e = 1.4426950408889634f;
-
-__device__ __forceinline__ bf16x8_t as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8_t, v); }
-__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-__device__ __forceinline__ int chunk_off(int row, int part) { return row * kRowB + ((part ^ swz(row)) << 4); }
-
-// A operand, row form: lane (j, hh) reads 16 bytes = elements 16*st + 8*hh .. +7 of tile row `row`.
-__device__ __forceinline__ bf16x8_t row_frag(const char* tile, int row, int st, int hh) {
-  return as_bf16x8(*reinterpret_cast<const u32x4*>(tile + chunk_off(row, 2 * st + hh)));
-}
-
-// A operand, transposed form: returns for lane (i = lane & 31, hh) the 8 consecutive rows rbase .. rbase+7 of tile column
-// 32*dt + i (hardware transpose read; 16-lane group p supplies the address of row p >> 2, 4-column chunk p & 3).
-__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int rbase, int dt, int lane) {
-  typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
-  const int p16 = lane & 15;
-  const int part = 4 * dt + 2 * ((lane >> 4) & 1) + ((p16 & 3) >> 1);
-  const int sub = 8 * (p16 & 1);
-  const int r0 = rbase + (p16 >> 2), r1 = r0 + 4;
-  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(tile + chunk_off(r0, part) + sub));
-  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(tile + chunk_off(r1, part) + sub));
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
 
 // D[t, h] = sum_d dO[t,h,d] * O[t,h,d]  (fp32).  16 lanes per (t, h) row, 4 rows per wave.
 // Also rescales the forward's log-sum-exp to the exp2 domain once (lse2 = lse * log2(e)) for both backward kernels.
@@ -102,20 +79,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
   const int n_items = q_tiles * hq * n_seq;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hh = lane >> 5;
-  const int key_row = (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1);     // see attn.hip: makes C regs 8m..8m+7 consecutive keys
   const float sl2 = scale * kLog2e;
   // per-lane LDS byte offsets inside a tile; the buffer, the 32-key block and the 16-row step add immediates
   int row_addr[8], tr_addr[4][2];
-#pragma unroll
-  for (int st = 0; st < 8; ++st) row_addr[st] = chunk_off(key_row, 2 * st + hh);
-  {
-    const int p16 = lane & 15;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int hi = 0; hi < 2; ++hi)
-        tr_addr[dt][hi] = chunk_off(8 * hh + (p16 >> 2) + 4 * hi, 4 * dt + 2 * ((lane >> 4) & 1) + ((p16 & 3) >> 1)) + 8 * (p16 & 1);
-  }
+  make_row_addr<8>(row_addr, j, hh);
+  make_tr_addr<4>(tr_addr, lane);
 
   for (int round = 0;; ++round) {
     int item;
@@ -162,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     const int n_tiles = (kv_end + kTile - 1) / kTile;
     // K / V tiles go global -> LDS directly (global_load_lds_dwordx4), swizzle applied to the source address (see the
     // dK / dV kernel below); the mask is evaluated only on tiles that touch the causal diagonal or the end of the keys.
-    const int ld_part = ((lane & 15) ^ (((lane >> 4) << 2) | wave)) * 8;
+    const int ld_part = slice_src_part(lane, wave) * 8;
     auto load_tile = [&](int t, int buf) {
       typedef const __attribute__((address_space(1))) void* gptr_t;
       typedef __attribute__((address_space(3))) void* lptr_t;
@@ -277,21 +245,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
   const int n_items = k_blocks * heads_per_item_dim * n_seq;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hh = lane >> 5;
-  const int q_row = (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1);       // A-row permutation: C regs 8m..8m+7 = consecutive queries
   const float sl2 = scale * kLog2e;
   const int rep = hq / hkv;
   // per-lane LDS byte offsets inside a tile; the buffer, the 32-query sub-block and the 16-row step add immediates
   int row_addr[8], tr_addr[4][2];
-#pragma unroll
-  for (int st = 0; st < 8; ++st) row_addr[st] = chunk_off(q_row, 2 * st + hh);
-  {
-    const int p16 = lane & 15;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int hi = 0; hi < 2; ++hi)
-        tr_addr[dt][hi] = chunk_off(8 * hh + (p16 >> 2) + 4 * hi, 4 * dt + 2 * ((lane >> 4) & 1) + ((p16 & 3) >> 1)) + 8 * (p16 & 1);
-  }
+  make_row_addr<8>(row_addr, j, hh);
+  make_tr_addr<4>(tr_addr, lane);
 
   for (int round = 0;; ++round) {
     int item;
@@ -341,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
     // LDS position (row, part') receives global part part' ^ swz(row).  A wave-instruction covers 4 rows; wave w issues
     // instructions w, w+4, w+8, w+12, for which swz(row) = ((lane >> 4) << 2) | w is a per-lane constant.
     int ld_qt = q_begin, ld_head = SPLIT ? hsel : kvh * rep;     // (query tile, head) of the NEXT tile to load
-    const int ld_part = ((lane & 15) ^ (((lane >> 4) << 2) | wave)) * 8;
+    const int ld_part = slice_src_part(lane, wave) * 8;
     auto load_tile = [&](int buf) {
       typedef const __attribute__((address_space(1))) void* gptr_t;
       typedef __attribute__((address_space(3))) void* lptr_t;

@@ -1,0 +1,76 @@
+// Shared pieces of the attention kernels (attn.hip forward, attn_bwd.hip backward): the LDS tile layout and the per-lane
+// fragment addresses of v_mfma_f32_32x32x16_bf16 operands.
+//
+// A tile is 64 rows x 256 bytes (one row = one key / query, up to 128 bf16 features).  The 16-byte part p of row r lives at
+// part p ^ swz(r), swz(r) = ((r & 3) << 2) | ((r >> 2) & 3).  That single layout is conflict-free for
+//   * row reads (ds_read_b128): the 16 lanes of a group read 16 rows whose (r & 15) are all different -> 16 different
+//     physical parts -> all 64 banks;
+//   * transposed reads (ds_read_b64_tr_b16): a 16-lane group reads a [4 rows x 16 columns] block; rows 4a .. 4a+3 move the
+//     64-byte column block to 4 different 64-byte groups -> all 64 banks over the two groups served together.
+// Tiles are filled by global_load_lds_dwordx4, which writes LDS lane-linearly (wave-uniform base + 16 * lane): the swizzle
+// is therefore applied to the SOURCE address -- LDS position (r, p) receives global part p ^ swz(r) (swz is an involution
+// on the part index for a fixed row).
+#pragma once
+#include "common.h"
+
+namespace vsel {
+namespace attn {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kRowBytes = 256;
+constexpr int kTileRows = 64;
+constexpr int kTileBytes = kTileRows * kRowBytes;   // 16 KiB
+
+__device__ __forceinline__ bf16x8_t as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8_t, v); }
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int chunk_off(int row, int part) { return row * kRowBytes + ((part ^ swz(row)) << 4); }
+
+// A-operand row i of a 32-row block holds tile row perm_row(i) (bits 2 and 3 swapped), so that C registers 8m .. 8m+7 of
+// lane half hh are the 8 CONSECUTIVE tile rows 16m + 8hh .. +7 and feed the next MFMA's B operand without a shuffle.
+__device__ __forceinline__ int perm_row(int j) { return (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1); }
+
+// Row-form A fragments: lane (j, hh) reads 16 bytes = features 16 st + 8 hh .. +7 of tile row perm_row(j) (+ 32 per block,
+// added as an immediate by the caller).
+template <int KSTEPS>
+__device__ __forceinline__ void make_row_addr(int (&row_addr)[KSTEPS], int j, int hh) {
+  const int row = perm_row(j);
+#pragma unroll
+  for (int st = 0; st < KSTEPS; ++st) row_addr[st] = chunk_off(row, 2 * st + hh);
+}
+
+// Transposed A fragments: for d-tile dt, lane (i, hh) receives the 8 consecutive tile rows rbase + 8 hh .. +7 of feature
+// 32 dt + i as two ds_read_b64_tr_b16 (rows +0..3 and +4..7); within a 16-lane group lane p supplies the address of row
+// p >> 2, 4-feature chunk p & 3.  rbase (a multiple of 16) is added as an immediate by the caller.
+template <int DTILES>
+__device__ __forceinline__ void make_tr_addr(int (&tr_addr)[DTILES][2], int lane) {
+  const int p16 = lane & 15, hh = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < DTILES; ++dt)
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi)
+      tr_addr[dt][hi] = chunk_off(8 * hh + (p16 >> 2) + 4 * hi, 4 * dt + 2 * ((lane >> 4) & 1) + ((p16 & 3) >> 1)) + 8 * (p16 & 1);
+}
+
+__device__ __forceinline__ bf16x8_t tr_read(const char* tile, const int (&addr)[2], int imm) {
+  typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(tile + addr[0] + imm));
+  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(tile + addr[1] + imm));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// Source-swizzled direct load of one 1-KiB slice (4 tile rows) of a tile: lane l lands at (row 4 i + (l >> 4), position
+// l & 15).  `src_row_ptr` points at the first feature of that lane's source row; `part8` = source part * 8 elements.
+__device__ __forceinline__ void load_slice_lds(const uint16_t* src_row_ptr, int part8, char* tile, int i) {
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  __builtin_amdgcn_global_load_lds((gptr_t)(src_row_ptr + part8), (lptr_t)(tile + i * 1024), 16, 0, 0);
+}
+
+// Source part (in 16-byte units) for lane l of wave w issuing slices w, w + n_waves, ...: position (l & 15) of row
+// 4 i + (l >> 4) holds part (l & 15) ^ swz(row), and swz(row) = ((l >> 4) << 2) | (w & 3) for every such slice.
+__device__ __forceinline__ int slice_src_part(int lane, int wave) { return (lane & 15) ^ (((lane >> 4) << 2) | (wave & 3)); }
+
+}  // namespace attn
+}  // namespace vsel

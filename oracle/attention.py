@@ -1,15 +1,17 @@
 """numpy restatement of the prefill attention math (TEST INFRASTRUCTURE ONLY).
 
-PARITY UNPINNED against the third-party kernel the reference actually calls
-(flash_attn==2.7.4.post1 via transformers 4.50/4.53 ``_flash_attention_forward``;
-call sites /root/reference/qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py:900,
+PINNED against the reference's in-tree EAGER attention module: tests/golden/make_golden.py runs
+/root/reference/qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py::Qwen2_5_VLAttention.forward (:749-800: repeat_kv,
+QK^T/sqrt(d) + causal mask, fp32 softmax, PV) and torch autograd through it on seeded q / k / v (selection-matrix
+projections, identity rotation) and commits outputs and gradients (tests/golden/attn_eager_*.npz);
+tests/test_oracle_golden.py::test_attention_oracle_matches_reference_eager_module checks varlen_attention and
+varlen_attention_backward against them.
+PARITY UNPINNED against the third-party kernel the reference calls in its flash_attention_2 configuration
+(flash_attn==2.7.4.post1 via transformers 4.50/4.53 ``_flash_attention_forward``; call sites
+/root/reference/qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py:900,
 /root/reference/llava-ov-15/llavaonevision1_5/modeling_llavaonevision1_5.py:686 and
-/root/reference/qwen-vl-finetune/qwenvl/train/trainer.py:101).  flash_attn is not in
-/root/reference and no reference test pins attention outputs.  This oracle follows the
-reference's in-tree EAGER formula instead
-(/root/reference/qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py:777-791: repeat_kv,
-QK^T/sqrt(d), + causal mask, fp32 softmax, PV) and the var-len contract of
-trainer.py:79-113 (cu_seqlens delimit independent causal sequences; q and k share them).
+/root/reference/qwen-vl-finetune/qwenvl/train/trainer.py:101): flash_attn is not in /root/reference and cannot run here.
+The var-len contract follows trainer.py:79-113 (cu_seqlens delimit independent causal sequences; q and k share them).
 """
 from __future__ import annotations
 

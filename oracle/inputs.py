@@ -52,3 +52,23 @@ def make_prompt(n_visual: int, n_pre: int, n_post: int, visual_token_id: int, se
     post = rng.integers(10, vocab, n_post)
     ids = np.concatenate((pre, [vision_start_id], np.full(n_visual, visual_token_id), [vision_end_id], post))
     return ids.astype(np.int64)[None, :]
+
+
+# ---- attention goldens (tests/golden/attn_eager_*.npz, produced by the reference's own eager Qwen2_5_VLAttention) ----
+#        name            lens          hq  hkv  d    causal  seed
+ATTN_GOLDEN_CASES = [
+    ("small_causal", [37, 53], 4, 2, 16, True, 31),
+    ("small_full", [24, 9, 40], 4, 4, 16, False, 32),
+    ("d128_causal", [70, 33], 4, 2, 128, True, 33),      # a shape the HIP kernels run as well
+    ("d128_full", [64, 64, 20], 2, 1, 128, False, 34),
+]
+
+
+def make_attention_inputs(lens, hq, hkv, d, seed):
+    """q [T,Hq,d], k / v [T,Hkv,d], dout [T,Hq,d]: N(0,1) rounded to bf16-representable fp32 (so that a bf16 kernel and the
+    fp32 reference see the same numbers)."""
+    from . import lis as _l
+    rng = np.random.default_rng(seed)
+    t = int(sum(lens))
+    f = lambda *s: _l.bf16_round(rng.standard_normal(s, dtype=np.float32))  # noqa: E731
+    return f(t, hq, d), f(t, hkv, d), f(t, hkv, d), f(t, hq, d)

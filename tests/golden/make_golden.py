@@ -15,6 +15,9 @@ What is executed from the reference (paths under /root/reference):
         Qwen2_5_VLForConditionalGeneration_Selector.forward (splice, lines 243-320) on a stub LLM that
         records what it is handed; get_rope_index is the vendored one
         (qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py:1550).
+  * qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py          Qwen2_5_VLAttention.forward (the in-tree EAGER attention,
+        lines 749-800: repeat_kv, QK^T/sqrt(d) + mask, fp32 softmax, PV) and torch autograd through it, with
+        selection-matrix projections and an identity rotation so that it computes attention of the given q, k, v
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 """
@@ -266,6 +269,53 @@ def gen_splice_case(name, ev, kind, n_visual, grid, n_pre, n_post, k, seed, d_ll
     print(f"splice {name}: L={ids.shape[1]} -> L'={seen['inputs_embeds'].shape[1]}")
 
 
+def gen_attention_case(name, lens, hq, hkv, d, causal, seed):
+    """Outputs and q/k/v gradients of the reference's eager attention module on seeded inputs, sequence by sequence."""
+    sys.path.insert(0, f"{REF}/qwen-evaluation")
+    from qwen25vl import modeling_qwen2_5_vl as m
+    sys.path.remove(f"{REF}/qwen-evaluation")
+    q, k, v, dout = oin.make_attention_inputs(lens, hq, hkv, d, seed)
+    att = object.__new__(m.Qwen2_5_VLAttention)                  # no config / rotary construction (4.50-era API)
+    torch.nn.Module.__init__(att)
+    width = (hq + 2 * hkv) * d
+    att.hidden_size, att.num_heads, att.head_dim = width, hq, d
+    att.num_key_value_heads, att.num_key_value_groups = hkv, hq // hkv
+    att.is_causal, att.attention_dropout, att.layer_idx = True, 0.0, 0
+    att.rope_scaling = {"mrope_section": [d // 2 - 2 * (d // 6), d // 6, d // 6]}
+    eye = torch.eye(width)
+    att.q_proj = torch.nn.Linear(width, hq * d)
+    att.k_proj = torch.nn.Linear(width, hkv * d)
+    att.v_proj = torch.nn.Linear(width, hkv * d)
+    att.o_proj = torch.nn.Linear(hq * d, hq * d, bias=False)
+    with torch.no_grad():
+        att.q_proj.weight.copy_(eye[: hq * d]); att.q_proj.bias.zero_()
+        att.k_proj.weight.copy_(eye[hq * d: (hq + hkv) * d]); att.k_proj.bias.zero_()
+        att.v_proj.weight.copy_(eye[(hq + hkv) * d:]); att.v_proj.bias.zero_()
+        att.o_proj.weight.copy_(torch.eye(hq * d))
+    att.eval()
+    outs, dqs, dks, dvs = [], [], [], []
+    a = 0
+    for n in lens:
+        x = torch.cat([torch.from_numpy(t_[a:a + n]).reshape(n, -1) for t_ in (q, k, v)], dim=1)[None].clone().requires_grad_(True)
+        cos = torch.ones(3, 1, n, d)
+        sin = torch.zeros(3, 1, n, d)
+        mask = None
+        if causal:
+            mask = torch.full((n, n), torch.finfo(torch.float32).min).triu(1)[None, None]
+        y = att(x, attention_mask=mask, position_embeddings=(cos, sin))[0]
+        y.backward(torch.from_numpy(dout[a:a + n]).reshape(1, n, hq * d))
+        g = x.grad[0]
+        outs.append(y.detach()[0].reshape(n, hq, d).numpy())
+        dqs.append(g[:, : hq * d].reshape(n, hq, d).numpy())
+        dks.append(g[:, hq * d: (hq + hkv) * d].reshape(n, hkv, d).numpy())
+        dvs.append(g[:, (hq + hkv) * d:].reshape(n, hkv, d).numpy())
+        a += n
+    np.savez_compressed(os.path.join(HERE, f"attn_eager_{name}.npz"), lens=np.asarray(lens), hq=hq, hkv=hkv, d=d,
+                        causal=causal, seed=seed, out=np.concatenate(outs), dq=np.concatenate(dqs), dk=np.concatenate(dks),
+                        dv=np.concatenate(dvs))
+    print(f"attention {name}: T={sum(lens)} hq={hq} hkv={hkv} d={d} causal={causal}")
+
+
 def main():
     ft, TransformerScorer = load_ft()
     ev = load_ev()
@@ -275,6 +325,8 @@ def main():
     gen_splice_case("image_a", ev, "image", 64, (1, 16, 16), 7, 12, 12, 21)
     gen_splice_case("image_b", ev, "image", 256, (1, 32, 32), 20, 33, 51, 22)
     gen_splice_case("video_a", ev, "video", 128, (2, 16, 16), 9, 14, 25, 23)
+    for case in oin.ATTN_GOLDEN_CASES:
+        gen_attention_case(*case)
 
 
 if __name__ == "__main__":

@@ -229,3 +229,21 @@ def test_attention_oracle_forward_backward_match_torch_autograd(causal):
     assert np.allclose(dq, tq.grad.numpy(), atol=1e-11)
     assert np.allclose(dk, tk.grad.numpy(), atol=1e-11)
     assert np.allclose(dv, tv.grad.numpy(), atol=1e-11)
+
+
+@pytest.mark.parametrize("name", [c[0] for c in oin.ATTN_GOLDEN_CASES])
+def test_attention_oracle_matches_reference_eager_module(golden_dir, name):
+    """oracle.attention (forward and closed-form backward) against outputs / autograd gradients of the REFERENCE's own eager
+    attention module (qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py Qwen2_5_VLAttention.forward, run by
+    tests/golden/make_golden.py).  fp32 reference vs fp64 oracle."""
+    from oracle import attention as oattn
+    g = np.load(os.path.join(golden_dir, f"attn_eager_{name}.npz"))
+    lens, hq, hkv, d = [int(x) for x in g["lens"]], int(g["hq"]), int(g["hkv"]), int(g["d"])
+    causal = bool(g["causal"])
+    q, k, v, dout = oin.make_attention_inputs(lens, hq, hkv, d, int(g["seed"]))
+    cu = np.concatenate(([0], np.cumsum(lens)))
+    out = oattn.varlen_attention(q, k, v, cu, causal=causal)
+    dq, dk, dv = oattn.varlen_attention_backward(q, k, v, cu, dout, causal=causal)
+    for got, want in ((out, g["out"]), (dq, g["dq"]), (dk, g["dk"]), (dv, g["dv"])):
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())

@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 D, HD, N_VIS = 3584, 1792, 2304
 
@@ -343,8 +344,34 @@ def bench_attention(ops, k, text=64, hq=28, hkv=4, dh=128, layers=28, iters=20):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
         flops = 4.0 * L * L * hq * dh / 2
-        out[tag] = {"L": L, "ms_per_layer": ms, "ms_28_layers": ms * layers, "tflops": flops / (ms * 1e-3) / 1e12}
+        tf = flops / (ms * 1e-3) / 1e12
+        out[tag] = {"L": L, "ms_per_layer": ms, "ms_28_layers": ms * layers, "tflops": tf,
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None}}
     out["speedup"] = out["full"]["ms_per_layer"] / out["retain20"]["ms_per_layer"]
+    # the same kernel where it is not latency-bound: a packed batch (16 sequences x 4096 tokens, the training shape)
+    try:
+        n_seq, L = 16, 4096
+        gen = torch.Generator(device="cuda").manual_seed(8)
+        q = torch.randn(n_seq * L, hq, dh, device="cuda", generator=gen).bfloat16()
+        kk = torch.randn(n_seq * L, hkv, dh, device="cuda", generator=gen).bfloat16()
+        v = torch.randn(n_seq * L, hkv, dh, device="cuda", generator=gen).bfloat16()
+        cu = torch.arange(0, n_seq * L + 1, L, dtype=torch.int32, device="cuda")
+        for _ in range(2):
+            ops.varlen_attn(q, kk, v, cu, L)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            ops.varlen_attn(q, kk, v, cu, L)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        tf = 4.0 * L * L * hq * dh / 2 * n_seq / (ms * 1e-3) / 1e12
+        out["packed_16x4096"] = {"ms": ms, "tflops": tf,
+                                 "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                              "frac": tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None}}
+    except Exception as e:  # optional
+        out["packed_16x4096"] = {"error": str(e)[:200]}
     return out
 
 

@@ -695,3 +695,39 @@ def test_vision_tower_through_packed_native_attention_matches_sdpa():
     ref, got = outs["sdpa"], outs[ATTN_NAME_PACKED]
     # TOLERANCE 3e-2 of the output's max: two bf16 attention implementations through 4 bf16 ViT blocks + merger
     assert float((got - ref).abs().max()) <= 3e-2 * float(ref.abs().max())
+
+
+def test_native_attention_padded_prefill_batch_matches_sdpa():
+    """A right- and a left-padded prefill batch through the flash-flavoured interface (2-D token mask): unpad -> one packed
+    var-len launch per layer -> pad back, vs SDPA with the same mask; decode against a padded cache raises."""
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    from visionselector_amd.attention import ATTN_NAME_PACKED, replace_qwen2_vl_attention_class
+    replace_qwen2_vl_attention_class()
+    torch.manual_seed(0)
+    cfg = Qwen2Config(hidden_size=512, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, vocab_size=128, max_position_embeddings=2048, head_dim=128)
+    model = Qwen2ForCausalLM(cfg).cuda().bfloat16().eval()
+    ids = torch.randint(0, 128, (3, 40), device="cuda")
+    for side in ("right", "left"):
+        mask = torch.ones(3, 40, dtype=torch.int64, device="cuda")
+        if side == "right":
+            mask[0, 25:] = 0
+            mask[2, 33:] = 0
+        else:
+            mask[0, :15] = 0
+            mask[2, :7] = 0
+        outs = {}
+        for impl in ("sdpa", ATTN_NAME_PACKED):
+            model.config._attn_implementation = impl
+            with torch.no_grad():
+                outs[impl] = model(input_ids=ids, attention_mask=mask).logits.float()
+        keep = mask.bool()
+        a, b = outs[ATTN_NAME_PACKED][keep], outs["sdpa"][keep]             # logits at real tokens
+        # TOLERANCE 3e-2 of the logits' max magnitude: two bf16 attention implementations through 2 bf16 layers
+        assert float((a - b).abs().max()) <= 3e-2 * max(1.0, float(b.abs().max())), side
+    model.config._attn_implementation = ATTN_NAME_PACKED
+    with torch.no_grad():
+        o = model(input_ids=ids, attention_mask=mask, use_cache=True)
+        with pytest.raises(NotImplementedError, match="padded"):
+            model(input_ids=ids[:, :1], attention_mask=torch.cat((mask, mask[:, :1] * 0 + 1), 1),
+                  past_key_values=o.past_key_values, use_cache=True)

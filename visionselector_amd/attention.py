@@ -12,6 +12,7 @@ FlashAttnVarlenFunc behind trainer.py:101-113).  There is no eager / CPU fallbac
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -89,11 +90,24 @@ def vsel_attention_forward(module, query, key, value, attention_mask, dropout: f
         raise NotImplementedError("attention dropout is not supported")
     b, hq, lq, d = query.shape
     lk = key.shape[2]
+    pad = _padding_info(attention_mask, b, lk) if (attention_mask is not None and b > 1) else None
     if lq != lk:
+        if pad is not None:
+            raise NotImplementedError("vsel attention against the cache does not handle padded batches (keys must be "
+                                      "contiguous from position 0): decode one sequence per call or pack the batch")
         return _decode_attention(query, key, value, scaling, is_causal), None
     q = query.transpose(1, 2).reshape(b * lq, hq, d).contiguous()
     k = key.transpose(1, 2).reshape(b * lk, key.shape[1], d).contiguous()
     v = value.transpose(1, 2).reshape(b * lk, value.shape[1], d).contiguous()
+    if pad is not None:
+        # padded prefill batch (2-D mask, 1 = token): unpad -> one packed var-len call -> pad back with zeros, the
+        # flash-attn recipe (bert_padding.unpad_input / pad_input); the padded rows' outputs are zeros
+        indices, cu, max_len = pad
+        causal = True if is_causal is None else bool(is_causal)
+        out_tok = varlen_attention(q[indices].contiguous(), k[indices].contiguous(), v[indices].contiguous(), cu, max_len,
+                                   causal=causal, softmax_scale=scaling)
+        out = torch.zeros(b * lq, hq, d, dtype=out_tok.dtype, device=out_tok.device).index_copy(0, indices, out_tok)
+        return out.view(b, lq, hq, d), None
     cu = kwargs.get("cu_seq_lens_q")
     if cu is not None:
         cu = cu.to(torch.int32).contiguous()
@@ -104,6 +118,31 @@ def vsel_attention_forward(module, query, key, value, attention_mask, dropout: f
     causal = True if is_causal is None else bool(is_causal)
     out = varlen_attention(q, k, v, cu, max_len, causal=causal, softmax_scale=scaling)
     return out.view(b, lq, hq, d), None
+
+
+_pad_cache = {}
+
+
+def _padding_info(attention_mask, b: int, lk: int):
+    """2-D [B, Lk] token mask with at least one padded position -> (token indices [nnz], cu_seqlens int32 [B+1], max length);
+    None when there is no padding or the mask is not a 2-D token mask (4-D additive masks are assumed to be plain causal:
+    use the flash-flavoured interface name for padded batches).  The result is cached per mask tensor: the 28 layers of one
+    forward see the same mask and the check costs one host sync."""
+    if attention_mask.dim() != 2 or tuple(attention_mask.shape) != (b, lk):
+        return None
+    # identity of the tensor OBJECT (all layers of one forward receive the same one) + its version counter; a data_ptr key
+    # would go stale when the allocator hands the same block to the next forward's mask
+    ref = _pad_cache.get("ref")
+    hit = ref is not None and ref() is attention_mask and _pad_cache.get("version") == attention_mask._version
+    if not hit:
+        mask = attention_mask.to(torch.bool)
+        info = None
+        if not bool(mask.all()):
+            lens = mask.sum(dim=1, dtype=torch.int32)
+            cu = torch.nn.functional.pad(torch.cumsum(lens, 0, dtype=torch.int32), (1, 0))
+            info = (torch.nonzero(mask.flatten(), as_tuple=False).flatten(), cu.contiguous(), int(lens.max().item()))
+        _pad_cache["ref"], _pad_cache["version"], _pad_cache["info"] = weakref.ref(attention_mask), attention_mask._version, info
+    return _pad_cache["info"]
 
 
 def _decode_attention(query, key, value, scaling, is_causal):
@@ -138,6 +177,13 @@ def replace_qwen2_vl_attention_class():
     from transformers import AttentionInterface
     AttentionInterface.register(ATTN_NAME, vsel_attention_forward)
     AttentionInterface.register(ATTN_NAME_PACKED, vsel_attention_forward)
+    try:        # mask flavour: the un-padded (flash) one -- None when the batch has no padding, else the 2-D token mask, which
+        #         vsel_attention_forward turns into cu_seqlens; without this a custom interface receives no mask at all
+        from transformers.masking_utils import AttentionMaskInterface, flash_attention_mask
+        AttentionMaskInterface.register(ATTN_NAME, flash_attention_mask)
+        AttentionMaskInterface.register(ATTN_NAME_PACKED, flash_attention_mask)
+    except ImportError:      # transformers < 4.53: masks are prepared by the model's _update_causal_mask (patched below)
+        pass
     for mod_name, cls_name in (("qwen2_vl", "Qwen2VLModel"), ("qwen2_5_vl", "Qwen2_5_VLModel")):
         mod = getattr(getattr(transformers.models, mod_name, None), f"modeling_{mod_name}", None)
         if mod is None:

@@ -731,3 +731,28 @@ def test_native_attention_padded_prefill_batch_matches_sdpa():
         with pytest.raises(NotImplementedError, match="padded"):
             model(input_ids=ids[:, :1], attention_mask=torch.cat((mask, mask[:, :1] * 0 + 1), 1),
                   past_key_values=o.past_key_values, use_cache=True)
+
+
+def test_model_constructs_and_loads_with_flash_flavoured_name(tmp_path):
+    """attn_implementation="vsel_flash_varlen" at construction and at from_pretrained time (where the reference's harness
+    passes "flash_attention_2"): transformers' flash pre-loading must accept the registered name."""
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    from visionselector_amd.attention import ATTN_NAME_PACKED, replace_qwen2_vl_attention_class
+    replace_qwen2_vl_attention_class()
+    cfg = Qwen2Config(hidden_size=256, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2,
+                      num_key_value_heads=1, vocab_size=64, max_position_embeddings=512, head_dim=128)
+    cfg._attn_implementation = ATTN_NAME_PACKED
+    torch.manual_seed(0)
+    m = Qwen2ForCausalLM(cfg).cuda().bfloat16().eval()
+    assert m.config._attn_implementation == ATTN_NAME_PACKED
+    m.save_pretrained(tmp_path / "m")
+    m2 = Qwen2ForCausalLM.from_pretrained(tmp_path / "m", attn_implementation=ATTN_NAME_PACKED, dtype=torch.bfloat16).cuda().eval()
+    assert m2.config._attn_implementation == ATTN_NAME_PACKED
+    ids = torch.randint(0, 64, (1, 33), device="cuda")
+    from visionselector_amd import _native as N
+    N.profile_start()
+    with torch.no_grad():
+        a, b = m(input_ids=ids).logits, m2(input_ids=ids).logits
+    assert N.profile_stop()["varlen_attn_fwd_kernel"][1] == 2
+    # (m's rotary buffer went through .bfloat16(), m2's did not: compare loosely)
+    assert float((a.float() - b.float()).abs().max()) <= 3e-2 * max(1.0, float(a.float().abs().max()))

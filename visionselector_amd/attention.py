@@ -75,6 +75,23 @@ def _flash_attention_forward(query_states, key_states, value_states, attention_m
     return out.unsqueeze(0)
 
 
+def _preload_flash_flavour():
+    """Constructing / loading a model WITH attn_implementation="vsel_flash_varlen" makes transformers (>= 5) call
+    lazy_import_flash_attention(name) for any name containing "flash", which would look for a hub kernel of that name.
+    Mark the name as already loaded, with our flash-attn-compatible functions behind transformers' own flash helpers."""
+    try:
+        from transformers import modeling_flash_attention_utils as fu
+        from . import flash_attn_compat as compat
+        if not hasattr(fu, "_loaded_implementation"):
+            return
+        fu._loaded_implementation = ATTN_NAME_PACKED
+        fu._flash_fn, fu._flash_varlen_fn, fu._flash_with_kvcache_fn = compat.flash_attn_func, compat.flash_attn_varlen_func, None
+        fu._pad_fn, fu._unpad_fn = fu._pad_input, fu._unpad_input
+        fu._process_flash_kwargs_fn = fu._lazy_define_process_function(fu._flash_varlen_fn)
+    except Exception:       # older / newer transformers without these internals: set config._attn_implementation after loading
+        pass
+
+
 def _update_causal_mask(self, attention_mask, input_tensor, cache_position, past_key_values, output_attentions):
     return attention_mask                                                                   # trainer.py:123-131
 
@@ -184,6 +201,7 @@ def replace_qwen2_vl_attention_class():
         AttentionMaskInterface.register(ATTN_NAME_PACKED, flash_attention_mask)
     except ImportError:      # transformers < 4.53: masks are prepared by the model's _update_causal_mask (patched below)
         pass
+    _preload_flash_flavour()
     for mod_name, cls_name in (("qwen2_vl", "Qwen2VLModel"), ("qwen2_5_vl", "Qwen2_5_VLModel")):
         mod = getattr(getattr(transformers.models, mod_name, None), f"modeling_{mod_name}", None)
         if mod is None:

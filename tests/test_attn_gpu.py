@@ -183,3 +183,54 @@ def test_attention_rejects_unsupported_head_dim(ops):
     q = torch.zeros(8, 2, 96, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(VselError, match="head_dim"):
         ops.varlen_attn(q, q, q, torch.tensor([0, 8], dtype=torch.int32, device="cuda"), 8)
+
+
+@pytest.mark.parametrize("hq,hkv,qlens,klens", [(28, 4, [1, 1, 1, 1, 1], [524, 37, 64, 1, 2368]),      # decode, 7B heads
+                                                  (16, 2, [3, 1, 4], [100, 999, 4]),                       # rep 8, chunks of <= 4
+                                                  (8, 8, [20, 32, 1], [300, 32, 5])])                      # rep 1
+@pytest.mark.parametrize("causal", [True, False])
+def test_gqa_packed_decode_matches_oracle_and_unpacked_kernel(ops, hq, hkv, qlens, klens, causal):
+    """Decode / short chunks against a paged cache: one wave serves the whole GQA group (lane = (query, head) pair), K/V
+    streamed once per kv head.  Against the oracle, and against the per-head kernel (pack mode 0)."""
+    lib = N_lib()
+    page_size = 64
+    rng = np.random.default_rng(hq + len(qlens))
+    pages_per = [-(-kk // page_size) for kk in klens]
+    n_pages = sum(pages_per) + 2
+    perm = rng.permutation(n_pages)
+    bt = np.zeros((len(qlens), max(pages_per)), np.int32)
+    cur = 0
+    for s, pp in enumerate(pages_per):
+        bt[s, :pp] = perm[cur:cur + pp]
+        cur += pp
+    f = lambda *sh: torch.from_numpy(rng.standard_normal(sh, dtype=np.float32)).bfloat16()  # noqa: E731
+    q = f(sum(qlens), hq, 128)
+    kc, vc = f(n_pages, page_size, hkv, 128), f(n_pages, page_size, hkv, 128)
+    cu_q = np.concatenate(([0], np.cumsum(qlens))).astype(np.int32)
+    args = (q.cuda(), kc.cuda(), vc.cuda(), torch.from_numpy(cu_q).cuda(), torch.tensor(klens, dtype=torch.int32).cuda(),
+            torch.from_numpy(bt).cuda(), max(qlens))
+    from visionselector_amd import _native as N
+    outs = {}
+    try:
+        for mode in (0, 1):
+            lib.vsel_debug_attn_pack(mode)
+            N.profile_start()
+            outs[mode] = ops.paged_attn(*args, causal=causal)
+            prof = N.profile_stop()
+            assert prof["varlen_attn_fwd_kernel"][1] == 1
+    finally:
+        lib.vsel_debug_attn_pack(2)
+    ref = oattn.paged_attention(q.float().numpy(), kc.float().numpy(), vc.float().numpy(), cu_q, np.array(klens), bt, causal=causal)
+    for mode in (0, 1):
+        err = np.abs(outs[mode].float().cpu().numpy().astype(np.float64) - ref)
+        check(err.max(), err.mean(), np.abs(ref).max())
+    # same tiles, same order of operations per (query, head): the two forms agree to the last bit
+    assert torch.equal(outs[0], outs[1])
+
+
+def N_lib():
+    from visionselector_amd import _native as N
+    lib = N.lib()
+    lib.vsel_debug_attn_pack.argtypes = [ctypes.c_int]
+    lib.vsel_debug_attn_pack.restype = None
+    return lib

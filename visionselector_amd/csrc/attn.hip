@@ -52,7 +52,10 @@ struct PagedKV {
 // stream among its 8 waves: half the global loads and LDS stores per FLOP, used when the grid is large enough).
 // D = head_dim (64, 80, 128): D / 16 k-steps for S, ceil(D / 32) d-tiles for O (columns past D are computed on whatever the
 // unused LDS parts hold and never stored).
-template <bool USE_TR, int NW, int D>
+// PACK (decode / short query chunks against a cache, NW = 1): one wave serves a whole GQA group of one sequence -- lane j is
+// the pair (query j / rep, head kvh * rep + j % rep), qlen * rep <= 32 -- so the K/V of a kv head is streamed ONCE for its rep
+// query heads instead of once per head, and a workgroup is a single wave (4x more sequences resident).
+template <bool USE_TR, int NW, int D, bool PACK = false>
 __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                               const uint16_t* __restrict__ v,
                                                               const int32_t* __restrict__ cu, int hq, int hkv,
@@ -70,7 +73,9 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   __shared__ int s_item;
   char* const k_sm = smem;
   char* const v_sm = smem + 2 * kBuf;
-  const int n_items = q_tiles * hq * n_seq;
+  static_assert(!PACK || NW == 1, "the GQA-packed form is single-wave");
+  const int rep = hq / hkv;
+  const int n_items = PACK ? hkv * n_seq : q_tiles * hq * n_seq;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hh = lane >> 5;
   // A-row i of the K operand holds key pi(i) (bits 2 and 3 swapped) so that C registers 8m..8m+7 of lane half hh are
@@ -84,8 +89,12 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   // lands at (row 4i + (l >> 4), position l & 15) and therefore fetches global part (l & 15) ^ swz(row)
   // (a source part past the row's data, head_dim < 128, is redirected to part 0: its LDS position is never read for S and only
   // feeds output columns >= D)
-  const int ld_src = slice_src_part(lane, wave);
-  const int ld_part = (ld_src < kParts ? ld_src : 0) * 8;
+  // slice i holds tile rows 4i .. 4i+3, whose swizzle key is ((l >> 4) << 2) | (i & 3); i & 3 == wave & 3 when NW is a
+  // multiple of 4, otherwise (single-wave workgroups) it changes from slice to slice
+  auto src_part8 = [&](int i) {
+    const int src = slice_src_part(lane, NW % 4 == 0 ? wave : i);
+    return (src < kParts ? src : 0) * 8;
+  };
 
   for (int round = 0;; ++round) {
   int item;
@@ -99,9 +108,19 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
     __syncthreads();
   }
   if (item >= n_items) return;
-  const int qtile = q_tiles - 1 - item / (hq * n_seq);
-  const int rest = item % (hq * n_seq);
-  const int head = rest % hq, seq = rest / hq;
+  int qtile, head, seq, kvh;
+  if constexpr (PACK) {
+    qtile = 0;
+    kvh = item % hkv;
+    seq = item / hkv;
+    head = kvh * rep + (j % rep);                             // per lane
+  } else {
+    qtile = q_tiles - 1 - item / (hq * n_seq);
+    const int rest = item % (hq * n_seq);
+    head = rest % hq;
+    seq = rest / hq;
+    kvh = head / rep;
+  }
   const int qs = cu[seq];
   const int qlen = cu[seq + 1] - qs;
   const int q0 = qtile * kBlockQ;
@@ -111,10 +130,11 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   const int len = pg.seqlens_k ? pg.seqlens_k[seq] : qlen;
   const int shift = len - qlen;
   const int ks = pg.cu_k ? pg.cu_k[seq] : qs;
-  const int kvh = head / (hq / hkv);
-  const int my_q = min(q0 + wave * 32 + j, qlen - 1);         // clamped: padding lanes replay the last query
-  const bool q_valid = (q0 + wave * 32 + j) < qlen;
-  const int wave_qmax = min(q0 + wave * 32 + 31, qlen - 1);
+  const int vq = PACK ? j / rep : q0 + wave * 32 + j;         // this lane's query
+  const int my_q = min(vq, qlen - 1);                         // clamped: padding lanes replay the last query
+  const bool q_valid = vq < qlen;
+  const int wave_qmax = PACK ? qlen - 1 : min(q0 + wave * 32 + 31, qlen - 1);
+  const int wave_qmin = PACK ? 0 : q0 + wave * 32;
 
   // Q^T fragments (B operand of S^T = K Q^T): lane (j, hh) holds q[my_q][16*step + 8*hh .. +7]
   u32x4 qf[kSteps];
@@ -130,7 +150,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
 
-  const int kv_end = causal ? max(0, min(len, q0 + kBlockQ + shift)) : len;
+  const int kv_end = causal ? max(0, min(len, (PACK ? qlen : q0 + kBlockQ) + shift)) : len;
   const int n_tiles = (kv_end + kTileK - 1) / kTileK;
   if (n_tiles <= 0) {     // no visible key for this whole q-tile (key sequence shorter than the query offset): zeros
     if (q_valid) {
@@ -143,7 +163,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
     continue;
   }
 
-  const int64_t kv_base = ((int64_t)ks * hkv + kvh) * kHeadDim + ld_part;        // contiguous keys: row r adds r * hkv * D
+  const int64_t kv_base = ((int64_t)ks * hkv + kvh) * kHeadDim;                  // contiguous keys: row r adds r * hkv * D
   auto load_tile = [&](int t, int buf) {
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -154,7 +174,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
       const int key = 4 * i + (lane >> 4);
       int64_t off;
       if (!pg.block_table && !tail) {
-        off = kv_base + (int64_t)(t * kTileK + key) * hkv * kHeadDim;
+        off = kv_base + (int64_t)(t * kTileK + key) * hkv * kHeadDim + src_part8(i);
       } else {
         const int kpos = min(t * kTileK + key, len - 1);
         int64_t row;
@@ -164,7 +184,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
         } else {
           row = ks + kpos;
         }
-        off = (row * hkv + kvh) * kHeadDim + ld_part;
+        off = (row * hkv + kvh) * kHeadDim + src_part8(i);
       }
       __builtin_amdgcn_global_load_lds((gptr_t)(k + off), (lptr_t)(k_sm + buf * kBuf + i * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(v + off), (lptr_t)(v_sm + buf * kBuf + i * 1024), 16, 0, 0);
@@ -177,7 +197,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   auto tile_body = [&](auto cur_c, int t) {
     constexpr int CUR = decltype(cur_c)::value;
     // a wave whose 32 query slots are all padding (short q-tiles: decode, ragged tails) only helps with the loads
-    const bool wave_active = (q0 + wave * 32 < qlen) && (!causal || (t * kTileK <= wave_qmax + shift));
+    const bool wave_active = (wave_qmin < qlen) && (!causal || (t * kTileK <= wave_qmax + shift));
     if (wave_active) {
       const char* kt = smem + CUR * kBuf;
       const char* vt = smem + (2 + CUR) * kBuf;
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
       // wave-uniform (made explicit with readfirstlane so the compiler emits ONE scalar branch, not an exec-mask dance per
       // element): only tiles that straddle the causal diagonal or the end of the key sequence pay for the mask
       const bool need_mask = __builtin_amdgcn_readfirstlane(
-          (int)((t * kTileK + kTileK > len) || (causal && (t * kTileK + kTileK - 1 > q0 + wave * 32 + shift)))) != 0;
+          (int)((t * kTileK + kTileK > len) || (causal && (t * kTileK + kTileK - 1 > wave_qmin + shift)))) != 0;
       float mx = -INFINITY;
       if (need_mask) {
         const int kmax = causal ? min(len - 1, my_q + shift) : len - 1;     // last visible key of this lane's query
@@ -309,6 +329,8 @@ static bool g_attn_use_tr = true;
 static int g_attn_nw = 0;      // 0 = choose by grid size, 4 / 8 = force the workgroup size
 extern "C" void vsel_debug_attn_use_tr(int on) { g_attn_use_tr = on != 0; }
 extern "C" void vsel_debug_attn_waves(int nw) { g_attn_nw = nw; }
+static int g_attn_pack = 2;    // 0 = never, 1 = whenever qlen * rep <= 32, 2 (default) = against a cache when the per-head grid exceeds one round
+extern "C" void vsel_debug_attn_pack(int mode) { g_attn_pack = mode; }
 
 static int attn_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
                        int64_t max_seqlen_q, int64_t hq, int64_t hkv, int64_t d, float scale, int causal, void* out,
@@ -317,11 +339,16 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   const int64_t items8 = cdiv(max_seqlen_q, 256) * hq * n_seq;
   // measured on MI355X (tools/exp_attn_nw.py): 8 waves +12-16 % at L >= 4096, +4 % at 16 x 2368, -20 % at L = 524
   const bool big = g_attn_nw == 8 || (g_attn_nw == 0 && max_seqlen_q >= 2048 && items8 >= 1024);
+  // decode / short chunks against a cache with d = 128: one wave per (kv head, sequence) serving the whole GQA group
+  // (measured, tools/bench_decode.py, 28 / 4 heads, Lk = 524: 2.1x at 64 sequences, 2.75x at 256; but a lone wave stages whole
+  // tiles by itself, so below one round of per-head workgroups -- n_seq * hq <= 512 -- the per-head form is faster: 24 vs 41 us)
+  const bool pack = g_attn_pack != 0 && d == 128 && g_attn_nw == 0 && max_seqlen_q * (hq / hkv) <= 32 &&
+                    (g_attn_pack == 1 || (pg.seqlens_k != nullptr && n_seq * hq > 512));
   const int block_q = big ? 256 : 128;
   const int q_tiles = (int)cdiv(max_seqlen_q, block_q);
-  const int64_t n_items = (int64_t)q_tiles * hq * n_seq;
+  const int64_t n_items = pack ? hkv * n_seq : (int64_t)q_tiles * hq * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
-  const int64_t slots = big ? 256 : 512;                           // resident workgroups
+  const int64_t slots = big ? 256 : 512;                           // resident workgroups (64 KiB LDS each)
   static unsigned next_slot = 0;
   int slot = -1;                                                   // -1: direct mapping, one item per workgroup
   if (n_items > slots) {
@@ -335,7 +362,10 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
 #define VSEL_ATTN_LAUNCH(TR, NWV, DV)                                                                                          \
   hipLaunchKernelGGL((varlen_attn_fwd_kernel<TR, NWV, DV>), grid, dim3(64 * NWV), 0, st, (const uint16_t*)q, (const uint16_t*)k, \
                      (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg, lse)
-  if (d == 128) {
+  if (pack) {
+    hipLaunchKernelGGL((varlen_attn_fwd_kernel<true, 1, 128, true>), grid, dim3(64), 0, st, (const uint16_t*)q, (const uint16_t*)k,
+                       (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg, lse);
+  } else if (d == 128) {
     if (g_attn_use_tr) {
       if (big) VSEL_ATTN_LAUNCH(true, 8, 128); else VSEL_ATTN_LAUNCH(true, 4, 128);
     } else {

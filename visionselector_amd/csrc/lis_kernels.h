@@ -51,16 +51,16 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     int r = rb + wave;
     for (; r + 12 < re; r += 16) {
       float v0[V], v1[V], v2[V], v3[V];
-      load_vec(base + (int64_t)r * d, v0);
-      load_vec(base + (int64_t)(r + 4) * d, v1);
-      load_vec(base + (int64_t)(r + 8) * d, v2);
-      load_vec(base + (int64_t)(r + 12) * d, v3);
+      load_vec_stream(base + (int64_t)r * d, v0);
+      load_vec_stream(base + (int64_t)(r + 4) * d, v1);
+      load_vec_stream(base + (int64_t)(r + 8) * d, v2);
+      load_vec_stream(base + (int64_t)(r + 12) * d, v3);
 #pragma unroll
       for (int i = 0; i < V; ++i) acc[i] = ((acc[i] + v0[i]) + v1[i]) + (v2[i] + v3[i]);
     }
     for (; r < re; r += 4) {
       float v0[V];
-      load_vec(base + (int64_t)r * d, v0);
+      load_vec_stream(base + (int64_t)r * d, v0);
 #pragma unroll
       for (int i = 0; i < V; ++i) acc[i] += v0[i];
     }
@@ -310,9 +310,9 @@ __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, Seg
       const T* p1 = base + (int64_t)(r + 4) * d;
       u32x4 x0[ITERS], x1[ITERS];
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) x0[it] = *reinterpret_cast<const u32x4*>(p0 + it * 64 * V);
+      for (int it = 0; it < ITERS; ++it) x0[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p0 + it * 64 * V));
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) x1[it] = *reinterpret_cast<const u32x4*>(p1 + it * 64 * V);
+      for (int it = 0; it < ITERS; ++it) x1[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p1 + it * 64 * V));
       float a0 = 0.f, a1 = 0.f;
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, Seg
       const T* p0 = base + (int64_t)r * d;
       u32x4 x0[ITERS];
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) x0[it] = *reinterpret_cast<const u32x4*>(p0 + it * 64 * V);
+      for (int it = 0; it < ITERS; ++it) x0[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p0 + it * 64 * V));
       float a0 = 0.f;
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) a0 = dot_raw<T>(x0[it], wr[it], a0);
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
     const int64_t src = src_map ? src_map[lsrc] : lsrc;
     const u32x4* sp = reinterpret_cast<const u32x4*>(h + src * d);
     u32x4* dp = reinterpret_cast<u32x4*>(out + (ob + j) * d);
-    for (int v = lane; v < d / V; v += 64) dp[v] = sp[v];
+    for (int v = lane; v < d / V; v += 64) __builtin_nontemporal_store(sp[v], dp + v);
   }
 }
 

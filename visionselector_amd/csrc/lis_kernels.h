@@ -30,7 +30,10 @@ constexpr int kSliceNN = 128;        // split-K slice of the w projection
 //     but 2 % slower inside the pipeline, where sweep 1 overlaps the write-back of the previous gather; tools/membw2.hip
 //     shows the bare access pattern reaches the 6.2-6.3 TB/s ceiling either way.)
 // =================================================================================================
-template <typename T>
+// NT: non-temporal loads (the token tensor is streamed once per sweep and does not fit the caches); chosen per launch by
+// stream_policy() -- below ~384 MB the default policy is faster because sweep 2 and the gather hit what sweep 1 left in the
+// Infinity Cache (tools/exp_small_batch.py: B = 8 images 86 vs 96 us, B = 32 271 vs 238 us).  Results are identical.
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ h, SegView sv, int d,
                                                              int row_splits, float* __restrict__ partial) {
   constexpr int V = Elem<T>::kVec;
@@ -46,6 +49,10 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   float acc[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) acc[i] = 0.f;
+  auto ld = [](const T* p, float (&v)[V]) {
+    if constexpr (NT) load_vec_stream(p, v);
+    else load_vec(p, v);
+  };
   if (col < d) {
     const T* base = h + (r0 * (int64_t)d + col);
     int r = rb + wave;
@@ -53,14 +60,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     // so results are unchanged.
     for (; r + 28 < re; r += 32) {
       float v0[V], v1[V], v2[V], v3[V], v4[V], v5[V], v6[V], v7[V];
-      load_vec_stream(base + (int64_t)r * d, v0);
-      load_vec_stream(base + (int64_t)(r + 4) * d, v1);
-      load_vec_stream(base + (int64_t)(r + 8) * d, v2);
-      load_vec_stream(base + (int64_t)(r + 12) * d, v3);
-      load_vec_stream(base + (int64_t)(r + 16) * d, v4);
-      load_vec_stream(base + (int64_t)(r + 20) * d, v5);
-      load_vec_stream(base + (int64_t)(r + 24) * d, v6);
-      load_vec_stream(base + (int64_t)(r + 28) * d, v7);
+      ld(base + (int64_t)r * d, v0);
+      ld(base + (int64_t)(r + 4) * d, v1);
+      ld(base + (int64_t)(r + 8) * d, v2);
+      ld(base + (int64_t)(r + 12) * d, v3);
+      ld(base + (int64_t)(r + 16) * d, v4);
+      ld(base + (int64_t)(r + 20) * d, v5);
+      ld(base + (int64_t)(r + 24) * d, v6);
+      ld(base + (int64_t)(r + 28) * d, v7);
 #pragma unroll
       for (int i = 0; i < V; ++i) {
         acc[i] = ((acc[i] + v0[i]) + v1[i]) + (v2[i] + v3[i]);
@@ -69,16 +76,16 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     }
     for (; r + 12 < re; r += 16) {
       float v0[V], v1[V], v2[V], v3[V];
-      load_vec_stream(base + (int64_t)r * d, v0);
-      load_vec_stream(base + (int64_t)(r + 4) * d, v1);
-      load_vec_stream(base + (int64_t)(r + 8) * d, v2);
-      load_vec_stream(base + (int64_t)(r + 12) * d, v3);
+      ld(base + (int64_t)r * d, v0);
+      ld(base + (int64_t)(r + 4) * d, v1);
+      ld(base + (int64_t)(r + 8) * d, v2);
+      ld(base + (int64_t)(r + 12) * d, v3);
 #pragma unroll
       for (int i = 0; i < V; ++i) acc[i] = ((acc[i] + v0[i]) + v1[i]) + (v2[i] + v3[i]);
     }
     for (; r < re; r += 4) {
       float v0[V];
-      load_vec_stream(base + (int64_t)r * d, v0);
+      ld(base + (int64_t)r * d, v0);
 #pragma unroll
       for (int i = 0; i < V; ++i) acc[i] += v0[i];
     }
@@ -293,7 +300,7 @@ __device__ __forceinline__ float dot_raw<float>(u32x4 raw, const float (&w)[4], 
 // K4  scores[row] = (x_row . w[s] + c[s]) / sqrt(Hd).  grid (row_chunks, n_seg), block 256.
 //     ITERS > 0: D == ITERS * 64 * V exactly and w[s] lives in registers; ITERS == 0: generic.
 // =================================================================================================
-template <typename T, int ITERS>
+template <typename T, int ITERS, bool NT>
 __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, SegView sv, int d,
                                                     const float* __restrict__ w, const float* __restrict__ c,
                                                     float sqrt_hd, int rows_per_block, float* __restrict__ scores,
@@ -321,6 +328,10 @@ __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, Seg
       }
     }
     // rows are kept as raw 16-byte vectors until the FMAs (4 VGPRs per load instead of 8 converted floats)
+    auto ldraw = [](const T* p) -> u32x4 {
+      if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+      else return *reinterpret_cast<const u32x4*>(p);
+    };
     const T* base = h + r0 * (int64_t)d + lane * V;
     int r = rb + wave;
     for (; r + 12 < re; r += 16) {       // 4 rows in flight per wave (same-box A/B: ~1 % faster than 2)
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, Seg
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int it = 0; it < ITERS; ++it)
-          x[u][it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + (int64_t)(r + 4 * u) * d + it * 64 * V));
+          x[u][it] = ldraw(base + (int64_t)(r + 4 * u) * d + it * 64 * V);
       float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int it = 0; it < ITERS; ++it)
@@ -346,9 +357,9 @@ __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, Seg
       const T* p1 = base + (int64_t)(r + 4) * d;
       u32x4 x0[ITERS], x1[ITERS];
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) x0[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p0 + it * 64 * V));
+      for (int it = 0; it < ITERS; ++it) x0[it] = ldraw(p0 + it * 64 * V);
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) x1[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p1 + it * 64 * V));
+      for (int it = 0; it < ITERS; ++it) x1[it] = ldraw(p1 + it * 64 * V);
       float a0 = 0.f, a1 = 0.f;
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, Seg
       const T* p0 = base + (int64_t)r * d;
       u32x4 x0[ITERS];
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) x0[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p0 + it * 64 * V));
+      for (int it = 0; it < ITERS; ++it) x0[it] = ldraw(p0 + it * 64 * V);
       float a0 = 0.f;
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) a0 = dot_raw<T>(x0[it], wr[it], a0);
@@ -495,7 +506,7 @@ static __global__ __launch_bounds__(1024) void topk_select_kernel(const float* _
 // =================================================================================================
 // K6  row gather out[ob + j] = h[rb + idx[ob + j]].  grid (row_chunks, n_seg), block 256, wave per row.
 // =================================================================================================
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ h, SegView sv, int d,
                                                           const int64_t* __restrict__ idx, T* __restrict__ out,
                                                           int rows_per_block, const int64_t* __restrict__ src_map) {
@@ -512,13 +523,21 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
     const int64_t src = src_map ? src_map[lsrc] : lsrc;
     const u32x4* sp = reinterpret_cast<const u32x4*>(h + src * d);
     u32x4* dp = reinterpret_cast<u32x4*>(out + (ob + j) * d);
-    for (int v = lane; v < d / V; v += 64) __builtin_nontemporal_store(sp[v], dp + v);
+    for (int v = lane; v < d / V; v += 64) {
+      if constexpr (NT) __builtin_nontemporal_store(sp[v], dp + v);      // keeps the write-back from slowing the next sweep 1
+      else dp[v] = sp[v];
+    }
   }
 }
 
 // =================================================================================================
 // host side
 // =================================================================================================
+// Cache policy of the three kernels that touch the token tensor: non-temporal once the tensor clearly exceeds the Infinity
+// Cache (256 MB) + L2 (32 MB).  Measured crossover between 264 MB (default policy 4 % faster) and 528 MB (nt 12 % faster).
+constexpr int64_t kStreamBytes = 384ll << 20;
+inline bool stream_policy(int64_t total_rows, int64_t d, size_t elem) { return total_rows * d * (int64_t)elem >= kStreamBytes; }
+
 struct LisPlan {
   int64_t S, maxn, d, hd;
   int row_splits;
@@ -598,13 +617,17 @@ inline int launch_score(hipStream_t st, const T* h, const SegView& sv, const vse
   while (rpb > 8 && seg->n_seg * cdiv(seg->rows_per_seg, rpb) < 2048) rpb >>= 1;
   dim3 grid((unsigned)cdiv(seg->rows_per_seg, rpb), (unsigned)seg->n_seg);
   const float sq = (float)sqrt((double)hd);
+  const bool nt = stream_policy(seg->total_rows, d, sizeof(T));
   const int iters = (d % (64 * V) == 0) ? d / (64 * V) : 0;
 #define VSEL_SCORE_CASE(I)                                                                              \
-  case I: hipLaunchKernelGGL((score_kernel<T, I>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores, out_map); break;
+  case I:                                                                                               \
+    if (nt) hipLaunchKernelGGL((score_kernel<T, I, true>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores, out_map);  \
+    else hipLaunchKernelGGL((score_kernel<T, I, false>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores, out_map);    \
+    break;
   switch (iters) {
     VSEL_SCORE_CASE(1) VSEL_SCORE_CASE(2) VSEL_SCORE_CASE(3) VSEL_SCORE_CASE(4)
     VSEL_SCORE_CASE(5) VSEL_SCORE_CASE(6) VSEL_SCORE_CASE(7) VSEL_SCORE_CASE(8)
-    default: hipLaunchKernelGGL((score_kernel<T, 0>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores, out_map);
+    default: hipLaunchKernelGGL((score_kernel<T, 0, false>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores, out_map);
   }
 #undef VSEL_SCORE_CASE
   VSEL_AFTER_LAUNCH(st, "score_kernel");
@@ -612,10 +635,14 @@ inline int launch_score(hipStream_t st, const T* h, const SegView& sv, const vse
 }
 
 template <typename T>
-inline int launch_colsum(hipStream_t st, const T* h, const SegView& sv, int d, int S, int row_splits, float* partial) {
+inline int launch_colsum(hipStream_t st, const T* h, const SegView& sv, int d, int S, int row_splits, float* partial,
+                         int64_t total_rows) {
   constexpr int V = Elem<T>::kVec;
-  hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3((unsigned)cdiv(d, 64 * V), row_splits, S), dim3(256), 0, st, h, sv, d,
-                     row_splits, partial);
+  const dim3 grid((unsigned)cdiv(d, 64 * V), row_splits, S);
+  if (stream_policy(total_rows, d, sizeof(T)))
+    hipLaunchKernelGGL((colsum_partial_kernel<T, true>), grid, dim3(256), 0, st, h, sv, d, row_splits, partial);
+  else
+    hipLaunchKernelGGL((colsum_partial_kernel<T, false>), grid, dim3(256), 0, st, h, sv, d, row_splits, partial);
   VSEL_AFTER_LAUNCH(st, "colsum_partial_kernel");
   return VSEL_OK;
 }
@@ -623,7 +650,7 @@ inline int launch_colsum(hipStream_t st, const T* h, const SegView& sv, int d, i
 // stage 1: sweep 1 (column-sum partials)
 template <typename T>
 inline int run_colsum(hipStream_t st, const T* h, const vsel_segments* seg, int d, char* ws, const LisPlan& p) {
-  return launch_colsum<T>(st, h, make_view(seg), d, (int)seg->n_seg, p.row_splits, (float*)(ws + p.off_partial));
+  return launch_colsum<T>(st, h, make_view(seg), d, (int)seg->n_seg, p.row_splits, (float*)(ws + p.off_partial), seg->total_rows);
 }
 
 // stage 2: partials -> xbar -> kbar -> (w, c)   (small, latency-bound kernels)
@@ -724,8 +751,11 @@ inline int launch_gather(hipStream_t st, const T* h, int d, const vsel_segments*
                          const int64_t* src_map = nullptr) {
   int64_t rpb = 32;
   while (rpb > 4 && seg->n_seg * cdiv(seg->k, rpb) < 2048) rpb >>= 1;
-  hipLaunchKernelGGL((gather_rows_kernel<T>), dim3((unsigned)cdiv(seg->k, rpb), (unsigned)seg->n_seg), dim3(256), 0, st, h,
-                     make_view(seg), d, idx, out, (int)rpb, src_map);
+  const dim3 grid((unsigned)cdiv(seg->k, rpb), (unsigned)seg->n_seg);
+  if (stream_policy(seg->total_rows, d, sizeof(T)))
+    hipLaunchKernelGGL((gather_rows_kernel<T, true>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map);
+  else
+    hipLaunchKernelGGL((gather_rows_kernel<T, false>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map);
   VSEL_AFTER_LAUNCH(st, "gather_rows_kernel");
   return VSEL_OK;
 }

@@ -138,6 +138,7 @@ def vsel_attention_forward(module, query, key, value, attention_mask, dropout: f
 
 
 _pad_cache = {}
+_decode_meta = {}
 
 
 def _padding_info(attention_mask, b: int, lk: int):
@@ -176,9 +177,14 @@ def _decode_attention(query, key, value, scaling, is_causal):
     k_pages = key.transpose(1, 2).contiguous()                    # [B pages, Lk, Hkv, d]
     v_pages = value.transpose(1, 2).contiguous()
     dev = query.device
-    cu_q = torch.arange(0, (b + 1) * lq, lq, dtype=torch.int32, device=dev)
-    seqlens_k = torch.full((b,), lk, dtype=torch.int32, device=dev)
-    block_table = torch.arange(b, dtype=torch.int32, device=dev).view(b, 1)
+    # the index tensors are the same for every layer of a decode step: build them once per (B, Lq, Lk, device)
+    meta_key = (b, lq, lk, dev)
+    if _decode_meta.get("key") != meta_key:
+        _decode_meta["key"] = meta_key
+        _decode_meta["val"] = (torch.arange(0, (b + 1) * lq, lq, dtype=torch.int32, device=dev),
+                               torch.full((b,), lk, dtype=torch.int32, device=dev),
+                               torch.arange(b, dtype=torch.int32, device=dev).view(b, 1))
+    cu_q, seqlens_k, block_table = _decode_meta["val"]
     causal = True if is_causal is None else bool(is_causal)
     out = ops.paged_attn(q, k_pages, v_pages, cu_q, seqlens_k, block_table, lq, causal=causal, softmax_scale=scaling)
     return out.view(b, lq, hq, d)

@@ -84,7 +84,20 @@ def cpu_baseline(budget, seconds_budget=14.0):
         t0 = time.perf_counter()
         lis_torch.select_forward_collapsed(h, wq, bq, wk, bk, budget)
         ct.append(time.perf_counter() - t0)
+    # the reference's own dtype on a GPU is bf16; the same ATen ops in bf16 on the host cores (SURVEY.md section 8d asks for both)
+    bt = []
+    try:
+        hb, wqb, bqb, wkb, bkb = (t.bfloat16() for t in (h, wq, bq, wk, bk))
+        lis_torch.select_forward(hb, wqb, bqb, wkb, bkb, budget)
+        for _ in range(5):
+            t0 = time.perf_counter()
+            lis_torch.select_forward(hb, wqb, bqb, wkb, bkb, budget)
+            bt.append(time.perf_counter() - t0)
+    except Exception:
+        bt = []
     return {"value": N_VIS / best[0], "unit": "tokens/s", "cores": best[1], "kind": "port", "host_cpus": ncpu,
+            "bf16_reference_formulation": ({"tokens_per_s": N_VIS / min(bt), "ms_per_image": min(bt) * 1e3, "cores": best[1]}
+                                           if bt else None),
             "collapsed_formulation": {"tokens_per_s": N_VIS / min(ct), "ms_per_image": min(ct) * 1e3, "cores": best[1],
                                       "note": "same selection with the scorer algebraically collapsed (not what the reference runs)"},
             "sample": f"{total} images of N={N_VIS}, D={D}, Hd={HD} over thread counts {cands}: fp32 reference formulation "

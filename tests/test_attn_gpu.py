@@ -66,12 +66,14 @@ def test_attention_transpose_read_equals_plain_reads(ops):
     lib = _native.lib()
     q, k, v = make_qkv(600, 8, 2, 11)
     cu = torch.tensor([0, 250, 600], dtype=torch.int32).cuda()
-    a = ops.varlen_attn(q.cuda(), k.cuda(), v.cuda(), cu, 350)
-    lib.vsel_debug_attn_use_tr(ctypes.c_int(0))
+    _set_split(0)                      # same single-stream schedule on both sides
     try:
+        a = ops.varlen_attn(q.cuda(), k.cuda(), v.cuda(), cu, 350)
+        lib.vsel_debug_attn_use_tr(ctypes.c_int(0))
         b = ops.varlen_attn(q.cuda(), k.cuda(), v.cuda(), cu, 350)
     finally:
         lib.vsel_debug_attn_use_tr(ctypes.c_int(1))
+        _set_split(2)
     assert torch.equal(a, b)
 
 
@@ -89,9 +91,17 @@ def test_attention_full_size_properties(ops):
     for s0 in (0, lens[0]):
         exp = vg[s0].float().repeat_interleave(hq // hkv, dim=0)
         assert float((out[s0].float() - exp).abs().max()) <= 2e-2        # softmax over one key = that V row (bf16)
-    o2 = ops.varlen_attn(qg[lens[0]:].contiguous(), kg[lens[0]:].contiguous(), vg[lens[0]:].contiguous(),
-                         torch.tensor([0, lens[1]], dtype=torch.int32).cuda(), lens[1])
-    assert torch.equal(out[lens[0]:], o2)
+    cu1 = torch.tensor([0, lens[1]], dtype=torch.int32).cuda()
+    tail = [t[lens[0]:].contiguous() for t in (qg, kg, vg)]
+    # the short sequence alone is a small grid -> two KV streams per workgroup (different summation order): equal to bf16
+    # rounding; with the same schedule (split off) a sequence's output does not depend on what it is packed with, bit for bit
+    o2 = ops.varlen_attn(*tail, cu1, lens[1])
+    assert float((out[lens[0]:].float() - o2.float()).abs().max()) <= 2 ** -6 * float(o2.float().abs().max())
+    _set_split(0)
+    try:
+        assert torch.equal(out[lens[0]:], ops.varlen_attn(*tail, cu1, lens[1]))
+    finally:
+        _set_split(2)
     # spot-check a slice against the oracle (one kv group, last 64 queries of the long sequence)
     sl = slice(lens[0] - 64, lens[0])
     ref = oattn.varlen_attention(q[:lens[0], :7].float().numpy(), k[:lens[0], :1].float().numpy(),
@@ -211,6 +221,7 @@ def test_gqa_packed_decode_matches_oracle_and_unpacked_kernel(ops, hq, hkv, qlen
             torch.from_numpy(bt).cuda(), max(qlens))
     from visionselector_amd import _native as N
     outs = {}
+    _set_split(0)                      # compare the packed form with the plain per-head form (not the two-stream one)
     try:
         for mode in (0, 1):
             lib.vsel_debug_attn_pack(mode)
@@ -220,6 +231,7 @@ def test_gqa_packed_decode_matches_oracle_and_unpacked_kernel(ops, hq, hkv, qlen
             assert prof["varlen_attn_fwd_kernel"][1] == 1
     finally:
         lib.vsel_debug_attn_pack(2)
+        _set_split(2)
     ref = oattn.paged_attention(q.float().numpy(), kc.float().numpy(), vc.float().numpy(), cu_q, np.array(klens), bt, causal=causal)
     for mode in (0, 1):
         err = np.abs(outs[mode].float().cpu().numpy().astype(np.float64) - ref)
@@ -234,3 +246,50 @@ def N_lib():
     lib.vsel_debug_attn_pack.argtypes = [ctypes.c_int]
     lib.vsel_debug_attn_pack.restype = None
     return lib
+
+
+def _set_split(mode):
+    from visionselector_amd import _native as N
+    lib = N.lib()
+    lib.vsel_debug_attn_split.argtypes = [ctypes.c_int]
+    lib.vsel_debug_attn_split.restype = None
+    lib.vsel_debug_attn_split(mode)
+
+
+@pytest.mark.parametrize("lens,hq,hkv", [([524], 28, 4), ([65], 4, 2), ([1], 2, 1), ([300, 129, 64], 4, 2), ([2368], 4, 4)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_two_kv_stream_workgroups_match_oracle_and_single_stream(ops, lens, hq, hkv, causal):
+    """Small grids run with two KV streams per workgroup (the 4-wave groups split the KV tiles and merge their softmax
+    states): against the oracle, and against the single-stream kernel within bf16 rounding (different summation order)."""
+    q, k, v = make_qkv(sum(lens), hq, hkv, seed=len(lens) + hq)
+    cu = torch.from_numpy(np.concatenate(([0], np.cumsum(lens))).astype(np.int32)).cuda()
+    outs = {}
+    try:
+        for mode in (0, 1):
+            _set_split(mode)
+            outs[mode] = ops.varlen_attn_fwd_lse(q.cuda(), k.cuda(), v.cuda(), cu, max(lens), causal=causal)
+    finally:
+        _set_split(2)
+    ref = oattn.varlen_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu.cpu().numpy(), causal=causal)
+    for mode in (0, 1):
+        err = np.abs(outs[mode][0].float().cpu().numpy().astype(np.float64) - ref)
+        check(err.max(), err.mean(), np.abs(ref).max())
+    assert float((outs[0][0].float() - outs[1][0].float()).abs().max()) <= 2 ** -6 * max(1.0, float(outs[0][0].float().abs().max()))
+    assert float((outs[0][1] - outs[1][1]).abs().max()) <= 1e-4          # log-sum-exp agrees
+
+
+def test_two_kv_streams_with_paged_cache(ops):
+    """Chunked prefill / decode of ONE sequence against a long paged cache: the two-stream form is the default there."""
+    rng = np.random.default_rng(5)
+    f = lambda *sh: torch.from_numpy(rng.standard_normal(sh, dtype=np.float32)).bfloat16()  # noqa: E731
+    hq, hkv, page = 8, 2, 64
+    for qlen, klen in ((1, 1000), (40, 700), (128, 128)):
+        n_pages = -(-klen // page)
+        bt = torch.from_numpy(rng.permutation(n_pages).astype(np.int32))[None]
+        q, kc, vc = f(qlen, hq, 128), f(n_pages, page, hkv, 128), f(n_pages, page, hkv, 128)
+        cu_q = torch.tensor([0, qlen], dtype=torch.int32)
+        out = ops.paged_attn(q.cuda(), kc.cuda(), vc.cuda(), cu_q.cuda(), torch.tensor([klen], dtype=torch.int32).cuda(), bt.cuda(), qlen)
+        ref = oattn.paged_attention(q.float().numpy(), kc.float().numpy(), vc.float().numpy(), cu_q.numpy(), np.array([klen]),
+                                    bt.numpy(), causal=True)
+        err = np.abs(out.float().cpu().numpy().astype(np.float64) - ref)
+        check(err.max(), err.mean(), np.abs(ref).max())

@@ -55,29 +55,37 @@ struct PagedKV {
 // PACK (decode / short query chunks against a cache, NW = 1): one wave serves a whole GQA group of one sequence -- lane j is
 // the pair (query j / rep, head kvh * rep + j % rep), qlen * rep <= 32 -- so the K/V of a kv head is streamed ONCE for its rep
 // query heads instead of once per head, and a workgroup is a single wave (4x more sequences resident).
-template <bool USE_TR, int NW, int D, bool PACK = false>
+// KVS = 2 (NW = 8, latency-bound small grids): the workgroup's two 4-wave groups serve the SAME 128 queries and split the KV
+// tiles between them (group g takes tiles g, g + 2, ...; each group streams its own K/V tiles through its own LDS buffers),
+// then merge their online-softmax states through LDS -- the dependent chain of KV tiles, which is what a single short
+// sequence costs, is halved (L' = 524: 9 tiles -> 5).
+template <bool USE_TR, int NW, int D, bool PACK = false, int KVS = 1>
 __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                               const uint16_t* __restrict__ v,
                                                               const int32_t* __restrict__ cu, int hq, int hkv,
                                                               float scale_log2e, int causal, uint16_t* __restrict__ out,
                                                               int q_tiles, int n_seq, int slot, PagedKV pg,
                                                               float* __restrict__ lse) {
-  constexpr int kBlockQ = 32 * NW;
+  constexpr int GW = NW / KVS;                     // waves that share one K/V stream (and cover kBlockQ queries)
+  constexpr int kBlockQ = 32 * GW;
   constexpr int kThreads = 64 * NW;
-  constexpr int kLoadsPerWave = 16 / NW;           // 1-KiB wave-instructions per tile per tensor
+  constexpr int kLoadsPerWave = 16 / GW;           // 1-KiB wave-instructions per tile per tensor
+  static_assert(KVS == 1 || (KVS == 2 && NW == 8 && !PACK), "two KV streams need 8 waves");
   constexpr int kHeadDim = D;
   constexpr int kSteps = D / 16;                   // k-steps of S^T = K Q^T
   constexpr int kDTiles = (D + 31) / 32;           // 32-wide d-tiles of O^T
   constexpr int kParts = D / 8;                    // 16-byte parts per row that hold data
-  __shared__ __attribute__((aligned(16))) char smem[kLds];
+  __shared__ __attribute__((aligned(16))) char smem[KVS * kLds];
   __shared__ int s_item;
-  char* const k_sm = smem;
-  char* const v_sm = smem + 2 * kBuf;
   static_assert(!PACK || NW == 1, "the GQA-packed form is single-wave");
   const int rep = hq / hkv;
   const int n_items = PACK ? hkv * n_seq : q_tiles * hq * n_seq;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
+  const int grp = KVS == 1 ? 0 : wave_all / GW;                // KV stream of this wave
+  const int wave = KVS == 1 ? wave_all : wave_all % GW;        // wave inside its group
   const int j = lane & 31, hh = lane >> 5;
+  char* const k_sm = smem + grp * kLds;
+  char* const v_sm = k_sm + 2 * kBuf;
   // A-row i of the K operand holds key pi(i) (bits 2 and 3 swapped) so that C registers 8m..8m+7 of lane half hh are
   // the 8 consecutive keys 16m + 8hh .. +7 of the 32-key block.
   // per-lane LDS byte offsets inside a tile; the buffer, the 32-key block and the 16-key step add immediates.  K rows are
@@ -85,6 +93,12 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   int row_addr[kSteps], tr_addr[kDTiles][2];
   make_row_addr<kSteps>(row_addr, j, hh);
   make_tr_addr<kDTiles>(tr_addr, lane);
+  if constexpr (KVS > 1) {                                     // this group's tile buffers
+#pragma unroll
+    for (int st = 0; st < kSteps; ++st) row_addr[st] += grp * kLds;
+#pragma unroll
+    for (int dt = 0; dt < kDTiles; ++dt) { tr_addr[dt][0] += grp * kLds; tr_addr[dt][1] += grp * kLds; }
+  }
   // direct-to-LDS loads: wave w issues wave-instructions w, w + NW, ...; instruction i covers tile rows 4i .. 4i+3, lane l
   // lands at (row 4i + (l >> 4), position l & 15) and therefore fetches global part (l & 15) ^ swz(row)
   // (a source part past the row's data, head_dim < 128, is redirected to part 0: its LDS position is never read for S and only
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   // slice i holds tile rows 4i .. 4i+3, whose swizzle key is ((l >> 4) << 2) | (i & 3); i & 3 == wave & 3 when NW is a
   // multiple of 4, otherwise (single-wave workgroups) it changes from slice to slice
   auto src_part8 = [&](int i) {
-    const int src = slice_src_part(lane, NW % 4 == 0 ? wave : i);
+    const int src = slice_src_part(lane, GW % 4 == 0 ? wave : i);
     return (src < kParts ? src : 0) * 8;
   };
 
@@ -170,7 +184,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
     const bool tail = __builtin_amdgcn_readfirstlane((int)(t * kTileK + kTileK > len)) != 0;
 #pragma unroll
     for (int u = 0; u < kLoadsPerWave; ++u) {
-      const int i = wave + NW * u;
+      const int i = wave + GW * u;
       const int key = 4 * i + (lane >> 4);
       int64_t off;
       if (!pg.block_table && !tail) {
@@ -190,7 +204,9 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
       __builtin_amdgcn_global_load_lds((gptr_t)(v + off), (lptr_t)(v_sm + buf * kBuf + i * 1024), 16, 0, 0);
     }
   };
-  load_tile(0, 0);
+  // group g walks tiles g, g + KVS, ...; every wave executes the same number of rounds (and barriers)
+  const int n_rounds = (n_tiles + KVS - 1) / KVS;
+  if (grp < n_tiles) load_tile(grp, 0);
   __syncthreads();
 
   // one 64-key tile from LDS buffer CUR (compile-time, so that every LDS address is a per-lane base + an immediate)
@@ -286,14 +302,56 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
         }
     }
   };
-  for (int t = 0; t < n_tiles; t += 2) {
-    if (t + 1 < n_tiles) load_tile(t + 1, 1);
-    tile_body(std::integral_constant<int, 0>{}, t);
-    __syncthreads();                         // also drains this wave's global_load_lds queue (vmcnt(0)) before the release
-    if (t + 1 >= n_tiles) break;
-    if (t + 2 < n_tiles) load_tile(t + 2, 0);
-    tile_body(std::integral_constant<int, 1>{}, t + 1);
+  if constexpr (KVS == 1) {
+    for (int t = 0; t < n_tiles; t += 2) {
+      if (t + 1 < n_tiles) load_tile(t + 1, 1);
+      tile_body(std::integral_constant<int, 0>{}, t);
+      __syncthreads();                       // also drains this wave's global_load_lds queue (vmcnt(0)) before the release
+      if (t + 1 >= n_tiles) break;
+      if (t + 2 < n_tiles) load_tile(t + 2, 0);
+      tile_body(std::integral_constant<int, 1>{}, t + 1);
+      __syncthreads();
+    }
+  } else {
+    for (int r = 0; r < n_rounds; r += 2) {
+      const int t0 = KVS * r + grp, t1 = t0 + KVS, t2 = t1 + KVS;
+      if (t1 < n_tiles) load_tile(t1, 1);
+      if (t0 < n_tiles) tile_body(std::integral_constant<int, 0>{}, t0);
+      __syncthreads();
+      if (r + 1 >= n_rounds) break;
+      if (t2 < n_tiles) load_tile(t2, 0);
+      if (t1 < n_tiles) tile_body(std::integral_constant<int, 1>{}, t1);
+      __syncthreads();
+    }
+  }
+
+  if constexpr (KVS == 2) {
+    // merge the two groups' online-softmax states: group 1 publishes (m, l, O) through LDS (the tile buffers are free now),
+    // group 0 rescales both to the common maximum and adds
+    float* ex = reinterpret_cast<float*>(smem);
+    constexpr int kState = kDTiles * 16 + 2;
     __syncthreads();
+    if (grp == 1) {
+      float* mine = ex + (size_t)wave * kState * 64 + lane;
+      mine[0] = m_run;
+      mine[64] = l_run;
+#pragma unroll
+      for (int dt = 0; dt < kDTiles; ++dt)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) mine[(2 + dt * 16 + rr) * 64] = o[dt][rr];
+    }
+    __syncthreads();
+    if (grp == 1) continue;                  // (both groups took the same path up to here; group 0 stores the result)
+    const float* other = ex + (size_t)wave * kState * 64 + lane;
+    const float m1 = other[0], l1 = other[64];
+    const float m_new = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - m_new), a1 = __builtin_amdgcn_exp2f(m1 - m_new);
+    m_run = m_new;
+    l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+    for (int dt = 0; dt < kDTiles; ++dt)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) o[dt][rr] = o[dt][rr] * a0 + other[(2 + dt * 16 + rr) * 64] * a1;
   }
 
   // ---- epilogue: O^T[d][query] / l, 4 consecutive d per store ------------------------------------------------------
@@ -331,6 +389,8 @@ extern "C" void vsel_debug_attn_use_tr(int on) { g_attn_use_tr = on != 0; }
 extern "C" void vsel_debug_attn_waves(int nw) { g_attn_nw = nw; }
 static int g_attn_pack = 2;    // 0 = never, 1 = whenever qlen * rep <= 32, 2 (default) = against a cache when the per-head grid exceeds one round
 extern "C" void vsel_debug_attn_pack(int mode) { g_attn_pack = mode; }
+static int g_attn_split = 2;   // 0 = never, 1 = whenever the 4-wave grid has <= 256 items, 2 (default) = ... and the sequences are not tiny
+extern "C" void vsel_debug_attn_split(int mode) { g_attn_split = mode; }
 
 static int attn_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
                        int64_t max_seqlen_q, int64_t hq, int64_t hkv, int64_t d, float scale, int causal, void* out,
@@ -344,11 +404,18 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   // tiles by itself, so below one round of per-head workgroups -- n_seq * hq <= 512 -- the per-head form is faster: 24 vs 41 us)
   const bool pack = g_attn_pack != 0 && d == 128 && g_attn_nw == 0 && max_seqlen_q * (hq / hkv) <= 32 &&
                     (g_attn_pack == 1 || (pg.seqlens_k != nullptr && n_seq * hq > 512));
+  // one short sequence (or a few): the grid does not fill the chip and the cost is the dependent chain of KV tiles -> two
+  // KV streams per workgroup (tools/bench_attn.py: L' = 524 19.5 -> see profiles/r01_attention.txt)
+  const int64_t items4 = cdiv(max_seqlen_q, 128) * hq * n_seq;
+  // (not for the LSE-saving training forward: the split changes the summation order, and training keeps "a sequence's
+  // results do not depend on what it is packed with" bit for bit)
+  const bool split2 = g_attn_split != 0 && d == 128 && !pack && !big && g_attn_nw == 0 && g_attn_use_tr && items4 <= 256 &&
+                      (g_attn_split == 1 || (lse == nullptr && (pg.seqlens_k != nullptr || max_seqlen_q >= 256)));
   const int block_q = big ? 256 : 128;
   const int q_tiles = (int)cdiv(max_seqlen_q, block_q);
   const int64_t n_items = pack ? hkv * n_seq : (int64_t)q_tiles * hq * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
-  const int64_t slots = big ? 256 : 512;                           // resident workgroups (64 KiB LDS each)
+  const int64_t slots = (big || split2) ? 256 : 512;               // resident workgroups (64 KiB LDS each; 128 KiB with two streams)
   static unsigned next_slot = 0;
   int slot = -1;                                                   // -1: direct mapping, one item per workgroup
   if (n_items > slots) {
@@ -362,7 +429,11 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
 #define VSEL_ATTN_LAUNCH(TR, NWV, DV)                                                                                          \
   hipLaunchKernelGGL((varlen_attn_fwd_kernel<TR, NWV, DV>), grid, dim3(64 * NWV), 0, st, (const uint16_t*)q, (const uint16_t*)k, \
                      (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg, lse)
-  if (pack) {
+  if (split2) {
+    hipLaunchKernelGGL((varlen_attn_fwd_kernel<true, 8, 128, false, 2>), grid, dim3(512), 0, st, (const uint16_t*)q,
+                       (const uint16_t*)k, (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles,
+                       (int)n_seq, slot, pg, lse);
+  } else if (pack) {
     hipLaunchKernelGGL((varlen_attn_fwd_kernel<true, 1, 128, true>), grid, dim3(64), 0, st, (const uint16_t*)q, (const uint16_t*)k,
                        (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg, lse);
   } else if (d == 128) {

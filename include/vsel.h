@@ -242,6 +242,18 @@ int vsel_varlen_attn_fwd_kv(void* stream, const void* q, const void* k, const vo
                             const int32_t* cu_seqlens_k, const int32_t* seqlens_k, int64_t n_seq, int64_t max_seqlen_q,
                             int64_t hq, int64_t hkv, int64_t d, float scale, int causal, void* out);
 
+/* Strided form of the two entries above, for callers that hold q / k / v head-major ([B, H, L, d], the layout of
+ * HuggingFace attention modules after the rotary embedding, EV/qwen25vl/modeling_qwen2_5_vl.py:765-775): element (sequence s,
+ * row l, head h) of q lives at  cu_seqlens_q[s] * hq * d + l * q_row_stride + h * q_head_stride  (k and v likewise with
+ * cu_seqlens_k or cu_seqlens_q, hkv and their own strides -- HF keeps v as a transposed view of the packed projection); packed [T, H, d] is row stride H * d, head stride d, head-major
+ * is row stride d, head stride L * d with cu = [0, L, 2L, ...].  cu_seqlens_k / seqlens_k NULL: keys share the query
+ * packing.  out is always packed [T, hq, d].  Saves the two transposing copies per layer of the HF path.             */
+int vsel_varlen_attn_fwd_strided(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens_q,
+                                 const int32_t* cu_seqlens_k, const int32_t* seqlens_k, int64_t n_seq, int64_t max_seqlen_q,
+                                 int64_t hq, int64_t hkv, int64_t d, int64_t q_row_stride, int64_t q_head_stride,
+                                 int64_t k_row_stride, int64_t k_head_stride, int64_t v_row_stride, int64_t v_head_stride,
+                                 float scale, int causal, void* out);
+
 /* -------- var-len attention for TRAINING: forward that also saves the log-sum-exp, and the backward -------------
  * The reference trains the LIS through the frozen LLM with flash_attn_varlen_func (FT/qwenvl/train/trainer.py:101-113,
  * patched in by replace_qwen2_vl_attention_class :150-160), so dQ / dK / dV of the same op are on the training path.

@@ -293,3 +293,29 @@ def test_two_kv_streams_with_paged_cache(ops):
                                     bt.numpy(), causal=True)
         err = np.abs(out.float().cpu().numpy().astype(np.float64) - ref)
         check(err.max(), err.mean(), np.abs(ref).max())
+
+
+@pytest.mark.parametrize("b,hq,hkv,lq,lk,causal", [(2, 8, 2, 200, 200, True), (1, 28, 4, 524, 524, True), (3, 4, 4, 1, 77, True),
+                                                    (2, 4, 2, 5, 300, True), (2, 4, 2, 130, 130, False), (70, 8, 1, 1, 200, True)])
+def test_head_major_strided_entry_matches_packed(ops, b, hq, hkv, lq, lk, causal):
+    """vsel_varlen_attn_fwd_strided on HuggingFace-layout tensors [B, H, L, d] == the packed entries on transposed copies
+    (bit for bit: same kernels, only the addressing differs), incl. decode against a longer cache and the GQA-packed form."""
+    rng = np.random.default_rng(b + lq)
+    f = lambda *sh: torch.from_numpy(rng.standard_normal(sh, dtype=np.float32)).bfloat16().cuda()  # noqa: E731
+    q, k, v = f(b, hq, lq, 128), f(b, hkv, lk, 128), f(b, hkv, lk, 128)
+    out = ops.attn_head_major(q, k, v, causal=causal)
+    assert out.shape == (b, lq, hq, 128)
+    qp = q.transpose(1, 2).reshape(b * lq, hq, 128).contiguous()
+    kp = k.transpose(1, 2).reshape(b * lk, hkv, 128).contiguous()
+    vp = v.transpose(1, 2).reshape(b * lk, hkv, 128).contiguous()
+    cu_q = torch.arange(0, (b + 1) * lq, lq, dtype=torch.int32).cuda()
+    if lq == lk:
+        ref = ops.varlen_attn(qp, kp, vp, cu_q, lq, causal=causal)
+    else:
+        cu_k = torch.arange(0, (b + 1) * lk, lk, dtype=torch.int32).cuda()
+        ref = ops.varlen_attn_kv(qp, kp, vp, cu_q, cu_k, lq, causal=causal)
+    assert torch.equal(out.reshape(b * lq, hq, 128), ref)
+    # HF hands v over as a transposed VIEW of the packed projection output: same result without a copy
+    v_view = vp.view(b, lk, hkv, 128).transpose(1, 2)
+    assert not v_view.is_contiguous() or lk == 1 or hkv == 1
+    assert torch.equal(ops.attn_head_major(q, k, v_view, causal=causal), out)

@@ -59,6 +59,8 @@ SIGNATURES = {
     "vsel_varlen_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, C.c_int, _P, _SZ,
                                        _P, _P, _P]),
     "vsel_varlen_attn_fwd_kv": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _F, C.c_int, _P]),
+    "vsel_varlen_attn_fwd_strided": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64,
+                                               _I64, _F, C.c_int, _P]),
     "vsel_paged_attn_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, C.c_int, _P]),
 }
 

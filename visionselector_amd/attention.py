@@ -108,6 +108,13 @@ def vsel_attention_forward(module, query, key, value, attention_mask, dropout: f
     b, hq, lq, d = query.shape
     lk = key.shape[2]
     pad = _padding_info(attention_mask, b, lk) if (attention_mask is not None and b > 1) else None
+    needs_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
+    if (pad is None and not needs_grad and kwargs.get("cu_seq_lens_q") is None and lq <= lk and query.dtype == torch.bfloat16
+            and key.shape == value.shape and all(ops.head_major_ok(t) for t in (query, key, value))):
+        # inference, HF's own head-major [B, H, L, d] tensors: no transposing copies (vsel_varlen_attn_fwd_strided); covers the
+        # prefill (Lq == Lk) and decode / chunked prefill against the cache (Lq < Lk, bottom-right causal mask)
+        causal = True if is_causal is None else bool(is_causal)
+        return ops.attn_head_major(query, key, value, causal=causal, softmax_scale=scaling), None
     if lq != lk:
         if pad is not None:
             raise NotImplementedError("vsel attention against the cache does not handle padded batches (keys must be "

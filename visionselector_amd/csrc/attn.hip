@@ -46,6 +46,10 @@ struct PagedKV {
   const int32_t* cu_k;          // [n_seq + 1] key row offsets when keys are contiguous but differ from the queries (or NULL)
   int max_pages;
   int page_size;
+  // Layout of q and of k / v in elements (0 = packed [T, H, d]: row stride H * d, head stride d).  Head-major tensors
+  // ([B, H, L, d] as HuggingFace attention modules hold them): row stride d, head stride L * d; the sequence base stays
+  // cu[seq] * H * d in both layouts (cu = b * L).
+  int64_t q_row_stride, q_head_stride, kv_row_stride, kv_head_stride, v_row_stride, v_head_stride;   // v_*: 0 = same as k
 };
 
 // NW = waves per workgroup (4 -> 128 queries, two workgroups per CU; 8 -> 256 queries, one workgroup per CU sharing ONE K/V
@@ -80,6 +84,12 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   static_assert(!PACK || NW == 1, "the GQA-packed form is single-wave");
   const int rep = hq / hkv;
   const int n_items = PACK ? hkv * n_seq : q_tiles * hq * n_seq;
+  const int64_t q_rs = pg.q_row_stride ? pg.q_row_stride : (int64_t)hq * kHeadDim;
+  const int64_t q_hs = pg.q_row_stride ? pg.q_head_stride : kHeadDim;
+  const int64_t kv_rs = pg.kv_row_stride ? pg.kv_row_stride : (int64_t)hkv * kHeadDim;
+  const int64_t kv_hs = pg.kv_row_stride ? pg.kv_head_stride : kHeadDim;
+  const int64_t v_rs = pg.v_row_stride ? pg.v_row_stride : kv_rs;
+  const int64_t v_hs = pg.v_row_stride ? pg.v_head_stride : kv_hs;
   const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
   const int grp = KVS == 1 ? 0 : wave_all / GW;                // KV stream of this wave
   const int wave = KVS == 1 ? wave_all : wave_all % GW;        // wave inside its group
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   // Q^T fragments (B operand of S^T = K Q^T): lane (j, hh) holds q[my_q][16*step + 8*hh .. +7]
   u32x4 qf[kSteps];
   {
-    const uint16_t* qp = q + ((int64_t)(qs + my_q) * hq + head) * kHeadDim + 8 * hh;
+    const uint16_t* qp = q + (int64_t)qs * hq * kHeadDim + my_q * q_rs + head * q_hs + 8 * hh;
 #pragma unroll
     for (int st = 0; st < kSteps; ++st) qf[st] = *reinterpret_cast<const u32x4*>(qp + 16 * st);
   }
@@ -177,7 +187,8 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
     continue;
   }
 
-  const int64_t kv_base = ((int64_t)ks * hkv + kvh) * kHeadDim;                  // contiguous keys: row r adds r * hkv * D
+  const int64_t kv_base = (int64_t)ks * hkv * kHeadDim + kvh * kv_hs;            // contiguous keys: row r adds r * kv_rs
+  const int64_t v_base = (int64_t)ks * hkv * kHeadDim + kvh * v_hs;
   auto load_tile = [&](int t, int buf) {
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -186,9 +197,10 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
     for (int u = 0; u < kLoadsPerWave; ++u) {
       const int i = wave + GW * u;
       const int key = 4 * i + (lane >> 4);
-      int64_t off;
+      int64_t off, off_v;
       if (!pg.block_table && !tail) {
-        off = kv_base + (int64_t)(t * kTileK + key) * hkv * kHeadDim + src_part8(i);
+        off = kv_base + (int64_t)(t * kTileK + key) * kv_rs + src_part8(i);
+        off_v = v_base + (int64_t)(t * kTileK + key) * v_rs + src_part8(i);
       } else {
         const int kpos = min(t * kTileK + key, len - 1);
         int64_t row;
@@ -196,12 +208,13 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
           const int page = kpos / pg.page_size;
           row = (int64_t)pg.block_table[(int64_t)seq * pg.max_pages + page] * pg.page_size + (kpos - page * pg.page_size);
         } else {
-          row = ks + kpos;
+          row = kpos;
         }
-        off = (row * hkv + kvh) * kHeadDim + src_part8(i);
+        off = (pg.block_table ? (row * hkv + kvh) * kHeadDim : kv_base + row * kv_rs) + src_part8(i);
+        off_v = (pg.block_table ? (row * hkv + kvh) * kHeadDim : v_base + row * v_rs) + src_part8(i);
       }
       __builtin_amdgcn_global_load_lds((gptr_t)(k + off), (lptr_t)(k_sm + buf * kBuf + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(v + off), (lptr_t)(v_sm + buf * kBuf + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(v + off_v), (lptr_t)(v_sm + buf * kBuf + i * 1024), 16, 0, 0);
     }
   };
   // group g walks tiles g, g + KVS, ...; every wave executes the same number of rounds (and barriers)
@@ -497,6 +510,23 @@ extern "C" int vsel_varlen_attn_fwd_kv(void* stream, const void* q, const void* 
   VSEL_PROF_BEGIN(st);
   return attn_launch(st, q, k, v, cu_seqlens_q, n_seq, max_seqlen_q, hq, hkv, d, scale, causal, out,
                      PagedKV{seqlens_k, nullptr, cu_seqlens_k, 0, 1});
+}
+
+extern "C" int vsel_varlen_attn_fwd_strided(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens_q,
+                                            const int32_t* cu_seqlens_k, const int32_t* seqlens_k, int64_t n_seq,
+                                            int64_t max_seqlen_q, int64_t hq, int64_t hkv, int64_t d, int64_t q_row_stride,
+                                            int64_t q_head_stride, int64_t k_row_stride, int64_t k_head_stride,
+                                            int64_t v_row_stride, int64_t v_head_stride, float scale, int causal, void* out) {
+  int rc = attn_checks(q, k, v, cu_seqlens_q, out, n_seq, max_seqlen_q, hq, hkv, d);
+  if (rc) return rc;
+  if ((cu_seqlens_k == nullptr) != (seqlens_k == nullptr)) return fail(VSEL_ERR_INVALID, "give cu_seqlens_k and seqlens_k together");
+  if (q_row_stride < d || q_head_stride < d || k_row_stride < d || k_head_stride < d || v_row_stride < d || v_head_stride < d ||
+      (q_row_stride | q_head_stride | k_row_stride | k_head_stride | v_row_stride | v_head_stride) % 8)
+    return fail(VSEL_ERR_INVALID, "strides must be >= head_dim and multiples of 8 elements (16-byte rows)");
+  hipStream_t st = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(st);
+  PagedKV pg{seqlens_k, nullptr, cu_seqlens_k, 0, 1, q_row_stride, q_head_stride, k_row_stride, k_head_stride, v_row_stride, v_head_stride};
+  return attn_launch(st, q, k, v, cu_seqlens_q, n_seq, max_seqlen_q, hq, hkv, d, scale, causal, out, pg);
 }
 
 extern "C" int vsel_paged_attn_fwd(void* stream, const void* q, const void* k_cache, const void* v_cache,

@@ -22,7 +22,7 @@ def _code(t: torch.Tensor) -> int:
         raise TypeError(f"visionselector_amd supports bfloat16 / float32 tensors, got {t.dtype}") from None
 
 
-def _dev(*ts: torch.Tensor) -> torch.device:
+def _dev(*ts: torch.Tensor, strided_ok: bool = False) -> torch.device:
     d = None
     for t in ts:
         if t is None:
@@ -30,7 +30,7 @@ def _dev(*ts: torch.Tensor) -> torch.device:
         if not t.is_cuda:
             raise RuntimeError("visionselector_amd ops run on the GPU only (HIP kernels in libvsel.so); "
                                f"got a tensor on {t.device}.  There is no CPU fallback.")
-        if not t.is_contiguous():
+        if not strided_ok and not t.is_contiguous():
             raise RuntimeError("visionselector_amd ops need contiguous tensors")
         if d is None:
             d = t.device
@@ -529,6 +529,47 @@ def varlen_attn_kv(q, k, v, cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tens
     N.check(N.lib().vsel_varlen_attn_fwd_kv(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), cu_seqlens_q.data_ptr(),
                                             cu_seqlens_k.data_ptr(), seqlens_k.data_ptr(), cu_seqlens_q.numel() - 1,
                                             int(max_seqlen_q), hq, hkv, d, scale, int(causal), out.data_ptr()))
+    return out
+
+
+_head_major_meta: dict = {}
+
+
+def head_major_ok(t: torch.Tensor) -> bool:
+    """[B, H, L, d] view the strided attention entry can address: unit feature stride, 16-byte aligned row / head strides, and
+    the batch stride of a dense tensor (the sequence base is cu[b] * H * d)."""
+    return (t.dim() == 4 and t.stride(3) == 1 and t.stride(1) % 8 == 0 and t.stride(2) % 8 == 0 and t.stride(1) >= t.shape[3]
+            and t.stride(2) >= t.shape[3] and (t.shape[0] == 1 or t.stride(0) == t.shape[1] * t.shape[2] * t.shape[3])
+            and t.data_ptr() % 16 == 0)
+
+
+def attn_head_major(query, key, value, causal: bool = True, softmax_scale: Optional[float] = None) -> torch.Tensor:
+    """HuggingFace layout without copies: query [B, Hq, Lq, d], key / value [B, Hkv, Lk, d] bf16, either contiguous in that
+    layout or a transposed view of a packed [B, L, H, d] tensor (what HF hands over for v) -> out [B, Lq, Hq, d].  Every batch
+    row is one sequence; Lq < Lk: bottom-right aligned causal mask (decode / chunked prefill against the cache)."""
+    dev = _dev(query, key, value, strided_ok=True)            # strides are validated by head_major_ok below
+    if query.dtype != torch.bfloat16 or key.dtype != torch.bfloat16 or value.dtype != torch.bfloat16:
+        raise TypeError("attn_head_major takes bfloat16 tensors")
+    b, hq, lq, d = query.shape
+    hkv, lk = key.shape[1], key.shape[2]
+    if value.shape != key.shape or not all(head_major_ok(t) for t in (query, key, value)):
+        raise ValueError("attn_head_major takes [B, H, L, d] tensors with unit feature stride and a dense batch stride")
+    scale = float(softmax_scale) if softmax_scale is not None else d ** -0.5
+    # the index tensors are the same for every layer of a forward: build them once per (B, Lq, Lk, device)
+    key_ = (b, lq, lk, dev)
+    if _head_major_meta.get("key") != key_:
+        cu_q = torch.arange(0, (b + 1) * lq, lq, dtype=torch.int32, device=dev)
+        cu_k = seqlens_k = None
+        if lk != lq:
+            cu_k = torch.arange(0, (b + 1) * lk, lk, dtype=torch.int32, device=dev)
+            seqlens_k = torch.full((b,), lk, dtype=torch.int32, device=dev)
+        _head_major_meta["key"], _head_major_meta["val"] = key_, (cu_q, cu_k, seqlens_k)
+    cu_q, cu_k, seqlens_k = _head_major_meta["val"]
+    out = torch.empty(b, lq, hq, d, dtype=query.dtype, device=dev)
+    N.check(N.lib().vsel_varlen_attn_fwd_strided(_stream(), query.data_ptr(), key.data_ptr(), value.data_ptr(), cu_q.data_ptr(),
+                                                 _p(cu_k), _p(seqlens_k), b, lq, hq, hkv, d, query.stride(2), query.stride(1),
+                                                 key.stride(2), key.stride(1), value.stride(2), value.stride(1), scale,
+                                                 int(causal), out.data_ptr()))
     return out
 
 

@@ -27,7 +27,7 @@ namespace vsel {
 
 using namespace attn;      // tile layout + fragment addressing shared with the backward (attn_common.h)
 
-constexpr int kMaxHeadDim = 128;   // LDS rows are 256 bytes for every supported head_dim (multiples of 16 up to 128)
+// LDS rows are 256 bytes for every supported head_dim (64 / 80 / 128)
 constexpr int kTileK = 64;
 constexpr int kBuf = kTileBytes;             // 16 KiB per tile
 constexpr int kLds = 4 * kBuf;               // K[2], V[2]: 64 KiB
@@ -72,7 +72,6 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
                                                               float* __restrict__ lse) {
   constexpr int GW = NW / KVS;                     // waves that share one K/V stream (and cover kBlockQ queries)
   constexpr int kBlockQ = 32 * GW;
-  constexpr int kThreads = 64 * NW;
   constexpr int kLoadsPerWave = 16 / GW;           // 1-KiB wave-instructions per tile per tensor
   static_assert(KVS == 1 || (KVS == 2 && NW == 8 && !PACK), "two KV streams need 8 waves");
   constexpr int kHeadDim = D;
@@ -484,7 +483,7 @@ extern "C" int vsel_varlen_attn_fwd(void* stream, const void* q, const void* k, 
   if (total < 1) return fail(VSEL_ERR_INVALID, "total must be >= 1");
   hipStream_t st = (hipStream_t)stream;
   VSEL_PROF_BEGIN(st);
-  return attn_launch(st, q, k, v, cu_seqlens, n_seq, max_seqlen, hq, hkv, d, scale, causal, out, PagedKV{nullptr, nullptr, nullptr, 0, 1});
+  return attn_launch(st, q, k, v, cu_seqlens, n_seq, max_seqlen, hq, hkv, d, scale, causal, out, PagedKV{nullptr, nullptr, nullptr, 0, 1, 0, 0, 0, 0, 0, 0});
 }
 
 extern "C" int vsel_varlen_attn_fwd_lse(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens,
@@ -496,7 +495,7 @@ extern "C" int vsel_varlen_attn_fwd_lse(void* stream, const void* q, const void*
   hipStream_t st = (hipStream_t)stream;
   VSEL_PROF_BEGIN(st);
   return attn_launch(st, q, k, v, cu_seqlens, n_seq, max_seqlen, hq, hkv, d, scale, causal, out,
-                     PagedKV{nullptr, nullptr, nullptr, 0, 1}, lse);
+                     PagedKV{nullptr, nullptr, nullptr, 0, 1, 0, 0, 0, 0, 0, 0}, lse);
 }
 
 extern "C" int vsel_varlen_attn_fwd_kv(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens_q,
@@ -509,7 +508,7 @@ extern "C" int vsel_varlen_attn_fwd_kv(void* stream, const void* q, const void* 
   hipStream_t st = (hipStream_t)stream;
   VSEL_PROF_BEGIN(st);
   return attn_launch(st, q, k, v, cu_seqlens_q, n_seq, max_seqlen_q, hq, hkv, d, scale, causal, out,
-                     PagedKV{seqlens_k, nullptr, cu_seqlens_k, 0, 1});
+                     PagedKV{seqlens_k, nullptr, cu_seqlens_k, 0, 1, 0, 0, 0, 0, 0, 0});
 }
 
 extern "C" int vsel_varlen_attn_fwd_strided(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens_q,
@@ -542,5 +541,5 @@ extern "C" int vsel_paged_attn_fwd(void* stream, const void* q, const void* k_ca
   hipStream_t st = (hipStream_t)stream;
   VSEL_PROF_BEGIN(st);
   return attn_launch(st, q, k_cache, v_cache, cu_seqlens_q, n_seq, max_seqlen_q, hq, hkv, d, scale, causal, out,
-                     PagedKV{seqlens_k, block_table, nullptr, (int)max_pages_per_seq, (int)page_size});
+                     PagedKV{seqlens_k, block_table, nullptr, (int)max_pages_per_seq, (int)page_size, 0, 0, 0, 0, 0, 0});
 }

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void gemm_nt_kernel(const float* __restrict__ x
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-      if (blockIdx.x * 32 + row < N) dst[row] = acc[r];
+      if ((int)blockIdx.x * 32 + row < N) dst[row] = acc[r];
     }
   }
 }

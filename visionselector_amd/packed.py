@@ -12,7 +12,7 @@ serving shards prompts over ranks (ddp.shard_units), no collective.
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import Sequence
 
 import torch
 

@@ -107,7 +107,10 @@ def vsel_attention_forward(module, query, key, value, attention_mask, dropout: f
         raise NotImplementedError("attention dropout is not supported")
     b, hq, lq, d = query.shape
     lk = key.shape[2]
-    pad = _padding_info(attention_mask, b, lk) if (attention_mask is not None and b > 1) else None
+    if kwargs.get("sliding_window") is not None or kwargs.get("softcap") is not None:
+        # the flash-attn call shapes raise for these too (_flash_attention_forward above): never run full attention silently
+        raise NotImplementedError("vsel attention does not implement sliding_window / softcap")
+    pad = _padding_info(attention_mask, b, lk) if attention_mask is not None else None
     needs_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
     if (pad is None and not needs_grad and kwargs.get("cu_seq_lens_q") is None and lq <= lk and query.dtype == torch.bfloat16
             and key.shape == value.shape and all(ops.head_major_ok(t) for t in (query, key, value))):

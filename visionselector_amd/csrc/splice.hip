@@ -13,6 +13,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <limits.h>
 
 namespace vsel {
 
@@ -80,6 +81,14 @@ __device__ __forceinline__ void splice_index_body(
     run_kv += tot_kv;
     __syncthreads();
   }
+  // rows the scan did not produce (input_ids holds fewer kept positions than the descriptors promise: the reference raises
+  // ValueError, FT/compression_method/selector_model.py:210-213; here stats report it): mark them so that the embedding
+  // copy never dereferences an uninitialised source row
+  for (int q = sq.q0 + (int)run_keep + tid; q < q_end; q += kSpliceThreads) {
+    src[q] = INT32_MAX;
+    sel[q] = -1;
+    new_ids[q] = -1;
+  }
   out_vis = run_vis;
   out_keep = run_keep;
   out_kv = run_kv;
@@ -141,18 +150,22 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_index_batched_kernel(
   }
 }
 
+// n_rows / n_vis bound the two source tensors: a descriptor outside them (a splice whose token counts disagree with
+// input_ids, reported through stats) yields a zero row instead of an out-of-bounds read.
 template <typename T>
 __global__ __launch_bounds__(256) void splice_embed_kernel(const T* __restrict__ embeds, const T* __restrict__ vis,
-                                                           const int32_t* __restrict__ src, int l_out, int d,
-                                                           T* __restrict__ out) {
+                                                           const int32_t* __restrict__ src, int l_out, int d, int n_rows,
+                                                           int n_vis, T* __restrict__ out) {
   constexpr int V = Elem<T>::kVec;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int q = blockIdx.x * 4 + wave; q < l_out; q += gridDim.x * 4) {
     const int s = src[q];
+    const bool ok = s >= 0 ? s < n_rows : (-(int64_t)s - 1) < n_vis;
     const T* from = s >= 0 ? embeds + (int64_t)s * d : vis + (int64_t)(-s - 1) * d;
     const u32x4* sp = reinterpret_cast<const u32x4*>(from);
     u32x4* dp = reinterpret_cast<u32x4*>(out + (int64_t)q * d);
-    for (int v = lane; v < d / V; v += 64) dp[v] = sp[v];
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    for (int v = lane; v < d / V; v += 64) dp[v] = ok ? sp[v] : zero;
   }
 }
 
@@ -192,10 +205,12 @@ extern "C" int vsel_splice(void* stream, const int64_t* input_ids, int64_t seq_l
   if (l_out > 0) {
     if (dtype == VSEL_BF16)
       hipLaunchKernelGGL((splice_embed_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)inputs_embeds,
-                         (const bf16_t*)visual_embeds, src_scratch, l_out, (int)d_llm, (bf16_t*)new_inputs_embeds);
+                         (const bf16_t*)visual_embeds, src_scratch, l_out, (int)d_llm, (int)seq_len, (int)k,
+                         (bf16_t*)new_inputs_embeds);
     else
       hipLaunchKernelGGL((splice_embed_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)inputs_embeds,
-                         (const float*)visual_embeds, src_scratch, l_out, (int)d_llm, (float*)new_inputs_embeds);
+                         (const float*)visual_embeds, src_scratch, l_out, (int)d_llm, (int)seq_len, (int)k,
+                         (float*)new_inputs_embeds);
     VSEL_AFTER_LAUNCH(st, "splice_embed_kernel");
   }
   return VSEL_OK;
@@ -227,6 +242,9 @@ extern "C" int vsel_splice_batched(void* stream, const int64_t* input_ids, int64
   VSEL_PROF_BEGIN(st);
   const int l_out = (int)(total_len - total_visual + total_kept);
   if (hipMemsetAsync(stats, 0, 4 * sizeof(int32_t), st) != hipSuccess) return fail(VSEL_ERR_HIP, "hipMemsetAsync(stats)");
+  // a sequence whose descriptors are rejected writes nothing: pre-mark every source row invalid (0x7f7f7f7f is past any row)
+  if (l_out > 0 && hipMemsetAsync(src_scratch, 0x7f, (size_t)l_out * sizeof(int32_t), st) != hipSuccess)
+    return fail(VSEL_ERR_HIP, "hipMemsetAsync(src)");
   const size_t lds = (size_t)((max_visual + 31) / 32) * 4 + 16;
   hipLaunchKernelGGL(splice_index_batched_kernel, dim3((unsigned)n_seq), dim3(kSpliceThreads), lds, st, input_ids, cu_seqlens,
                      cu_visual, cu_kept, (int)n_seq, (int)max_visual, visual_token_id, all_indices, position_ids, (int)pos_rows,
@@ -236,10 +254,12 @@ extern "C" int vsel_splice_batched(void* stream, const int64_t* input_ids, int64
   if (l_out > 0) {
     if (dtype == VSEL_BF16)
       hipLaunchKernelGGL((splice_embed_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)inputs_embeds,
-                         (const bf16_t*)visual_embeds, src_scratch, l_out, (int)d_llm, (bf16_t*)new_inputs_embeds);
+                         (const bf16_t*)visual_embeds, src_scratch, l_out, (int)d_llm, (int)total_len, (int)total_kept,
+                         (bf16_t*)new_inputs_embeds);
     else
       hipLaunchKernelGGL((splice_embed_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)inputs_embeds,
-                         (const float*)visual_embeds, src_scratch, l_out, (int)d_llm, (float*)new_inputs_embeds);
+                         (const float*)visual_embeds, src_scratch, l_out, (int)d_llm, (int)total_len, (int)total_kept,
+                         (float*)new_inputs_embeds);
     VSEL_AFTER_LAUNCH(st, "splice_embed_kernel");
   }
   return VSEL_OK;

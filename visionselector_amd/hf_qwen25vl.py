@@ -125,6 +125,12 @@ class Qwen2_5_VLForConditionalGeneration_Selector(_BaseCausal):
         visual_token_num = None
         selected_indices = None
         prefill = inputs_embeds is None and (pixel_values is not None or pixel_values_videos is not None)
+        # a forward on an empty cache starts a new request: whatever the previous (compressed) prompt left behind --
+        # the dropped-column count used to trim generate()'s mask during decode, the video text/visual mask -- is stale
+        cache_len = 0 if past_key_values is None else int(past_key_values.get_seq_length())
+        if cache_len == 0:
+            self._n_dropped = 0
+            _set_text_image_mask(self.model.language_model, None)
         if prefill:
             origin_input_ids = input_ids
             inputs_embeds = self.get_input_embeddings()(input_ids)
@@ -150,9 +156,10 @@ class Qwen2_5_VLForConditionalGeneration_Selector(_BaseCausal):
             # one fused device splice (vsel_splice) instead of where / cat / sort / index / masked_scatter (:246-262, :264-290)
             selected_indices, input_ids, inputs_embeds, position_ids, attention_mask = ops.splice(
                 input_ids.contiguous(), inputs_embeds.contiguous(), vis_id, all_indices, vis_embeds, visual_token_num,
-                position_ids=full_pos.contiguous(), attention_mask=None if attention_mask is None else attention_mask.contiguous())
+                position_ids=full_pos.contiguous(), attention_mask=None if attention_mask is None else attention_mask.contiguous(),
+                check=getattr(self, "check_token_count", True))     # ValueError on a placeholder / feature count mismatch (FT :210-213)
             if pixel_values_videos is not None and pixel_values is None:
-                self.model.language_model.text_image_mask = input_ids != vis_id            # :295-297
+                _set_text_image_mask(self.model.language_model, input_ids != vis_id)        # :295-298
             self._n_dropped = origin_input_ids.shape[1] - input_ids.shape[1]
             # decode positions are (uncompressed length + t) + rope_deltas in the reference (:322-334, cache_position counts
             # the ORIGINAL prompt); transformers 5.x derives them from the cache length L' + t, so fold L - L' into the deltas
@@ -160,8 +167,7 @@ class Qwen2_5_VLForConditionalGeneration_Selector(_BaseCausal):
                 self.model.rope_deltas = self.model.rope_deltas + self._n_dropped
             pixel_values = pixel_values_videos = None
             input_ids = None
-        elif attention_mask is not None and attention_mask.dim() == 2 and past_key_values is not None and \
-                getattr(self, "_n_dropped", 0):
+        elif attention_mask is not None and attention_mask.dim() == 2 and cache_len > 0 and getattr(self, "_n_dropped", 0):
             # decode step: generate() keeps the un-compressed mask (length L + t); the cache holds L' + t positions
             attention_mask = attention_mask[:, self._n_dropped:]
         outputs = _BaseCausal.forward(self, input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
@@ -195,6 +201,16 @@ def _register_checkpoint_layouts():
 
 
 _register_checkpoint_layouts()
+
+
+def _set_text_image_mask(language_model, mask):
+    """EV/token_compression/selector_model.py:295-298: the video branch publishes the text-vs-visual mask of the compressed
+    sequence on the text model AND on every decoder layer's self_attn."""
+    language_model.text_image_mask = mask
+    for layer in getattr(language_model, "layers", ()):
+        attn = getattr(layer, "self_attn", None)
+        if attn is not None:
+            attn.text_image_mask = mask
 
 
 def _mm_types_from_ids(input_ids, config):

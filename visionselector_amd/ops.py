@@ -6,6 +6,7 @@ returns torch tensors allocated by the caching allocator.  There is no CPU path:
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -40,7 +41,24 @@ def _dev(*ts: torch.Tensor, strided_ok: bool = False) -> torch.device:
 
 
 def _stream() -> int:
+    """HIP stream of the CURRENT device; every public op runs under _device_guard, which makes the tensors' device current."""
     return torch.cuda.current_stream().cuda_stream
+
+
+def _device_guard(fn):
+    """Run `fn` with the device of its first GPU tensor argument current (as every ATen op does): libvsel launches on
+    torch's current stream of the current device, so tensors on cuda:1 in a process whose current device is cuda:0
+    (HF device_map, multi-GPU processes) must switch first -- otherwise the kernels would be enqueued on the wrong GPU."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                if a.is_cuda and a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapper
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -594,3 +612,12 @@ def paged_attn(q, k_cache, v_cache, cu_seqlens_q: torch.Tensor, seqlens_k: torch
                                         seqlens_k.data_ptr(), block_table.data_ptr(), block_table.shape[1], page_size, n_seq,
                                         int(max_seqlen_q), hq, hkv, d, scale, int(causal), out.data_ptr()))
     return out
+
+
+# every op that reaches libvsel switches to its tensors' device first
+for _name in ("lis_scores", "lis_select", "lis_select_permuted", "gelu_colsum", "lis_select_presummed", "lis_select_varlen",
+              "hard_topk", "gather_rows", "soft_topk_fwd", "soft_topk_bwd", "lis_train_fwd", "lis_train_bwd", "lis_scores_bwd",
+              "splice", "splice_batched", "varlen_attn", "varlen_attn_fwd_lse", "varlen_attn_bwd", "varlen_attn_kv",
+              "attn_head_major", "paged_attn"):
+    globals()[_name] = _device_guard(globals()[_name])
+del _name

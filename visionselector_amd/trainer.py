@@ -68,16 +68,26 @@ class LisTrainer:
 
     def __init__(self, model: torch.nn.Module, max_steps: int, lr: float = 5e-5, weight_decay: float = 0.0,
                  reg_weight_start: float = 0.1, reg_weight_end: float = 2.0, max_grad_norm: float = 1.0,
-                 warmup_ratio: float = 0.03, group: Optional[dist.ProcessGroup] = None, log: Callable[[str], None] = print):
+                 warmup_ratio: float = 0.03, group: Optional[dist.ProcessGroup] = None, log: Callable[[str], None] = print,
+                 logging_steps: int = 1):
         self.model = model
         self.params = freeze_all_but_scorer(model)
         self.max_steps = max_steps
         self.reg_weight_start, self.reg_weight_end = reg_weight_start, reg_weight_end
         self.max_grad_norm = max_grad_norm
         self.opt = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay)
-        warm = max(1, int(warmup_ratio * max_steps))
-        self.sched = torch.optim.lr_scheduler.LambdaLR(
-            self.opt, lambda s: (s + 1) / warm if s < warm else 0.5 * (1 + math.cos(math.pi * (s - warm) / max(1, max_steps - warm))))
+        # transformers.get_cosine_schedule_with_warmup as HF Trainer configures it (lr_scheduler_type "cosine", warmup_ratio 0.03,
+        # scripts/sft_7b.sh:57-58): warm-up steps = ceil(ratio * max_steps), lr starts at 0 and rises linearly, then half a cosine
+        warm = int(math.ceil(warmup_ratio * max_steps))
+        self.logging_steps = max(1, int(logging_steps))
+
+        def lr_lambda(s: int) -> float:
+            if s < warm:
+                return s / max(1, warm)
+            progress = (s - warm) / max(1, max_steps - warm)
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
+
+        self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lr_lambda)
         # fp32 scorer: gradients live in ONE flat bucket (views), so the data-parallel mean is a single all-reduce, no copies
         self.sync = LisGradSync(self.params, group, bucket_view=all(p.dtype == torch.float32 for p in self.params))
         self.sync.broadcast_parameters(0)
@@ -89,8 +99,8 @@ class LisTrainer:
         """One optimizer step over the given micro-batches (gradient accumulation).  Returns the mean loss."""
         w = curriculum_weight(self.global_step, self.max_steps, self.reg_weight_start, self.reg_weight_end)
         self.model.regularization_weight = w                                   # train_qwen_selector.py:82-83
-        if self.rank == 0 and self.global_step > 0:
-            self.log(f"\\n[Step {self.global_step}] Set regularization_weight to: {w:.4f}")   # :86-89
+        if self.rank == 0 and self.global_step > 0 and self.global_step % self.logging_steps == 0:
+            self.log(f"\n[Step {self.global_step}] Set regularization_weight to: {w:.4f}")    # :86-89
         self.sync.zero_grads()
         batches = list(batches)
         total = 0.0

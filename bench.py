@@ -104,6 +104,30 @@ def cpu_baseline(budget, seconds_budget=14.0):
             "ms_per_image": best[0] * 1e3, "ms_per_image_median": best[2] * 1e3}
 
 
+def spawn_command(n_gpus, argv, port=None):
+    """argv of the one-process-per-GPU launch of this script on ONE node (the form the driver uses for N > 1)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n_gpus, argv):
+    """Re-execute under torch.distributed.run with one rank per GPU; returns the launcher's exit code."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_gpus)))
+    return subprocess.call(spawn_command(n_gpus, argv), env=env)
+
+
 def pmc_traffic(kernel, b):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json; separate
     FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if that (kernel, B) was not profiled."""
@@ -128,6 +152,10 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (config C3: fwd + bwd + grad all-reduce)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (what the reference's scripts do with torchrun /
+        # accelerate launch: qwen-vl-finetune/scripts/sft_7b.sh:71-74, qwen-evaluation/run_selector.sh:11-18)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -920,3 +920,154 @@ def test_training_with_gradient_checkpointing_matches_plain_backward():
     assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * max(1.0, abs(grads[0][0]))
     for a, b in zip(grads[0][1], grads[1][1]):
         assert torch.equal(a, b)            # deterministic kernels: recomputation reproduces the same bits
+
+
+def test_eval_time_lines_through_generate_and_log_reader(selector_model, capfd, tmp_path, monkeypatch):
+    """N3: EVAL_TIME=true -> the *_Selector forward prints the prefill lines (EV/token_compression/selector_model.py:353-359),
+    timed_generate the adapter's latency / memory lines (lmms-eval/.../qwen2_5_vl_with_token_compression.py:370-394), and the
+    log reader returns the four averages qwen-evaluation/extract_time.py:4-69 prints."""
+    from visionselector_amd import evaltime
+    m = selector_model
+    m.visual.budgets = 0.25
+    monkeypatch.setenv("EVAL_TIME", "true")
+    n_samples = 3
+    kept = []
+    for s in range(n_samples):
+        inp, n_vis = make_inputs(seed=20 + s)
+        m.model.rope_deltas = None
+        with torch.no_grad():
+            gen = evaltime.timed_generate(m, **inp, max_new_tokens=3, do_sample=False)
+        assert gen.shape[1] == inp["input_ids"].shape[1] + 3
+        kept.append(n_vis)
+    text = capfd.readouterr().out
+    lines = text.splitlines()
+    for needle in ("Input visual token number is:", "Generation prefill time is:", "Generation latency time is:",
+                   "after generation memory:"):
+        assert sum(needle in ln for ln in lines) == n_samples, (needle, text)
+    log = tmp_path / "log_eval.log"
+    log.write_text(text)
+    s = evaltime.summarize_log(str(log))
+    assert s["samples"] == n_samples
+    assert s["avg_visual_tokens"] == pytest.approx(sum(kept) / n_samples)     # the tower's total_token_num (EV :187,357)
+    assert 0 < s["avg_prefill_ms"] <= s["avg_latency_ms"]
+    assert s["avg_max_memory_GB"] > 0
+    monkeypatch.setenv("EVAL_TIME", "false")
+    inp, _ = make_inputs(seed=29)
+    m.model.rope_deltas = None
+    with torch.no_grad():
+        evaltime.timed_generate(m, **inp, max_new_tokens=2, do_sample=False)
+    assert "Generation" not in capfd.readouterr().out
+
+
+@pytest.mark.parametrize("impl", ["sdpa", "vsel_varlen"])
+def test_text_only_request_after_an_image_request_is_not_truncated(impl):
+    """A compressed image prompt leaves per-request state behind (dropped-column count for the decode mask, video mask);
+    the next request on an empty cache must not inherit it: text-only generate() == the stock model's."""
+    from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as hf
+    from visionselector_amd.attention import replace_qwen2_vl_attention_class
+    from visionselector_amd.hf_qwen25vl import Qwen2_5_VLForConditionalGeneration_Selector
+    replace_qwen2_vl_attention_class()
+    cfg = tiny_config()
+    if impl != "sdpa":                         # the HIP attention needs head_dim 128: 512 / 4 heads, tower output to match
+        cfg.text_config.hidden_size, cfg.text_config.intermediate_size = 512, 512
+        cfg.vision_config.out_hidden_size = 512
+        rp = dict(cfg.text_config.rope_parameters)
+        rp["mrope_section"] = [16, 24, 24]                                        # sums to head_dim / 2
+        cfg.text_config.rope_parameters = rp
+    torch.manual_seed(0)
+    dt = torch.bfloat16 if impl != "sdpa" else torch.float32
+    m = Qwen2_5_VLForConditionalGeneration_Selector(cfg).cuda().to(dt).eval()
+    randomize_scorer(m.visual.importance_scorer)
+    m.config.text_config._attn_implementation = impl
+    m.model.language_model.config._attn_implementation = impl
+    m.visual.budgets = 0.25
+    inp, n_vis = make_inputs(seed=31)
+    inp["pixel_values"] = inp["pixel_values"].to(dt)
+    with torch.no_grad():
+        m.generate(**inp, max_new_tokens=3, do_sample=False)
+    assert m._n_dropped == n_vis - max(1, int(n_vis * 0.25))
+    ids = torch.randint(20, 60, (2, 12), generator=torch.Generator().manual_seed(5)).cuda()
+    mask = torch.ones_like(ids)
+    if impl == "sdpa":
+        mask[1, :4] = 0            # left-padded batch: a truncated mask would be visible at once
+    text_kwargs = dict(input_ids=ids[:1] if impl != "sdpa" else ids, attention_mask=mask[:1] if impl != "sdpa" else mask)
+    with torch.no_grad():
+        got = m.generate(**text_kwargs, max_new_tokens=4, do_sample=False)
+        ref = hf.Qwen2_5_VLForConditionalGeneration.generate(m, **text_kwargs, max_new_tokens=4, do_sample=False)
+    assert m._n_dropped == 0
+    assert torch.equal(got, ref)
+
+
+def test_video_branch_publishes_text_image_mask_on_every_layer(selector_model):
+    """EV/token_compression/selector_model.py:295-298: text_image_mask on the text model and on each layer's self_attn; a
+    following image request clears it."""
+    m = selector_model
+    m.visual.budgets = 0.5
+    g = torch.Generator().manual_seed(17)
+    grid = (2, 16, 16)
+    n_patches = grid[0] * grid[1] * grid[2]
+    n_vis = n_patches // 4
+    pix = torch.randn(n_patches, 3 * 2 * 14 * 14, generator=g)
+    ids = torch.cat((torch.randint(20, 60, (4,), generator=g), torch.tensor([VSTART]), torch.full((n_vis,), VID),
+                     torch.tensor([VEND]), torch.randint(20, 60, (5,), generator=g)))[None]
+    mm = torch.zeros_like(ids, dtype=torch.int32)
+    mm[ids == VID] = 2
+    with torch.no_grad():
+        m.model.rope_deltas = None
+        out = m(input_ids=ids.cuda(), attention_mask=torch.ones_like(ids).cuda(), pixel_values_videos=pix.cuda(),
+                video_grid_thw=torch.tensor([list(grid)]).cuda(), mm_token_type_ids=mm.cuda())
+    lm = m.model.language_model
+    k = n_vis // 2
+    assert lm.text_image_mask.shape == (1, out.logits.shape[1]) and int((~lm.text_image_mask).sum()) == k
+    for layer in lm.layers:
+        assert layer.self_attn.text_image_mask is lm.text_image_mask
+    inp, _ = make_inputs(seed=2)
+    with torch.no_grad():
+        m.model.rope_deltas = None
+        m(**inp)
+    assert lm.text_image_mask is None and all(layer.self_attn.text_image_mask is None for layer in lm.layers)
+
+
+def test_splice_reports_placeholder_feature_count_mismatch():
+    """Placeholder count in input_ids != visual feature count: the reference raises ValueError
+    (FT/compression_method/selector_model.py:210-213).  ops.splice(check=True) -- what the *_Selector forward uses -- raises
+    the same; unchecked, the kernels still never read past their inputs (rows they cannot produce come out as zeros)."""
+    from visionselector_amd import ops
+    g = torch.Generator().manual_seed(4)
+    n_vis, k, d = 64, 16, 128
+    all_idx = torch.sort(torch.randperm(n_vis, generator=g)[:k]).values.cuda()
+    vis = torch.randn(k, d, generator=g).cuda().bfloat16()
+    for n_placeholders in (n_vis - 3, n_vis + 3):
+        ids = torch.cat((torch.randint(20, 60, (5,), generator=g), torch.full((n_placeholders,), IMG),
+                         torch.randint(20, 60, (9,), generator=g)))[None].cuda()
+        emb = torch.randn(1, ids.shape[1], d, generator=g).cuda().bfloat16()
+        with pytest.raises(ValueError, match="do not match"):
+            ops.splice(ids, emb, IMG, all_idx, vis, n_vis, check=True)
+        sel, new_ids, new_emb, _, _ = ops.splice(ids, emb, IMG, all_idx, vis, n_vis, check=False)
+        torch.cuda.synchronize()
+        l_out = ids.shape[1] - n_vis + k
+        assert new_emb.shape == (1, l_out, d) and bool(torch.isfinite(new_emb.float()).all())
+        if n_placeholders > n_vis:        # 3 placeholders have no feature row: 3 output rows cannot be produced
+            produced = int((sel >= 0).sum())
+            assert produced == l_out - 3 and float(new_emb[0, produced:].float().abs().max()) == 0.0
+            assert bool((new_ids[0, produced:] == -1).all())
+
+
+def test_ops_follow_the_device_of_their_tensors():
+    """ops.* switch to the tensors' device before launching (ATen semantics): on a multi-GPU box a call with tensors on
+    cuda:1 while cuda:0 is current runs on cuda:1's stream; on one GPU the guard is a no-op."""
+    from visionselector_amd import ops
+    dev = torch.device("cuda", torch.cuda.device_count() - 1)
+    g = torch.Generator().manual_seed(3)
+    h = torch.randn(96, 64, generator=g).to(dev).bfloat16()
+    wq, wk = (0.05 * torch.randn(32, 64, generator=g)).to(dev).bfloat16(), (0.05 * torch.randn(32, 64, generator=g)).to(dev).bfloat16()
+    bq, bk = torch.zeros(32, device=dev).bfloat16(), torch.zeros(32, device=dev).bfloat16()
+    torch.cuda.set_device(0)
+    out, idx, scores = ops.lis_select(h, wq, bq, wk, bk, 20)
+    assert out.device == dev and torch.cuda.current_device() == 0
+    torch.cuda.synchronize(dev)
+    assert torch.equal(out, h[idx])
+    ref = eager_scores(h.float(), type("S", (), {"k_proj": type("L", (), {"weight": wk.float(), "bias": bk.float()}),
+                                                  "q_proj": type("L", (), {"weight": wq.float(), "bias": bq.float()}),
+                                                  "hidden_dim": 32}))
+    assert float((scores - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))

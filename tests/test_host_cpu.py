@@ -255,3 +255,28 @@ def test_flash_attn_shim_helpers_cpu():
     assert torch.allclose(outi[..., 0:8:2], xs[..., 0:8:2] * c - xs[..., 1:8:2] * s, atol=1e-6)
     with pytest.raises(NotImplementedError):
         flash_attn_varlen_func(xs, xs, xs, cu, cu, 5, 5, dropout_p=0.1)
+
+
+# ---- bench.py launcher (python bench.py --gpus N must start N ranks by itself) -------------------------------------
+def test_bench_spawn_command_is_the_driver_form():
+    import bench
+    cmd = bench.spawn_command(4, ["--gpus", "4", "--steps", "3"], port=29517)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29517"
+    assert cmd[-5] == os.path.join(ROOT, "bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    # a free port is picked when none is given
+    auto = bench.spawn_command(2, [])
+    assert int(auto[auto.index("--master-port") + 1]) > 0
+
+
+def test_bench_gpus_without_enough_devices_exits_loudly():
+    import subprocess
+    import sys as _sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([_sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "only" in r.stderr and "GPU" in r.stderr

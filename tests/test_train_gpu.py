@@ -80,7 +80,7 @@ def test_soft_topk_batched_and_edges(ops):
 # ---------------------------------------------------------------------------------------------------
 # training block forward
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["tiny", "qwen3b_256", "qwen3b_576", "qwen7b_2304"])
+@pytest.mark.parametrize("name", ["tiny", "qwen3b_256", "qwen3b_576", "qwen7b_2304", "ov8b_5832"])
 @pytest.mark.parametrize("storage", ["f32", "bf16"])
 def test_train_forward_golden(ops, golden_dir, name, storage):
     g = load(golden_dir, name)
@@ -108,7 +108,7 @@ def test_train_forward_golden(ops, golden_dir, name, storage):
 # ---------------------------------------------------------------------------------------------------
 # training block backward vs the reference's autograd (golden projections / full tensors)
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["tiny", "qwen3b_256", "qwen3b_576", "qwen7b_2304"])
+@pytest.mark.parametrize("name", ["tiny", "qwen3b_256", "qwen3b_576", "qwen7b_2304", "ov8b_5832"])
 @pytest.mark.parametrize("fused_bce", [True, False])
 def test_train_backward_golden(ops, golden_dir, name, fused_bce):
     g = load(golden_dir, name)

@@ -18,6 +18,10 @@ What is executed from the reference (paths under /root/reference):
   * qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py          Qwen2_5_VLAttention.forward (the in-tree EAGER attention,
         lines 749-800: repeat_kv, QK^T/sqrt(d) + mask, fp32 softmax, PV) and torch autograd through it, with
         selection-matrix projections and an identity rotation so that it computes attention of the given q, k, v
+  * llava-ov-15/compression_method/modeling_selector.py      RiceTransformerPretrainedModel_Selector.forward (CLS insertion /
+        removal loops :131-166 and the inference LIS block :173-184) on a stub Rice tower (identity patch_embed / blocks /
+        merger), and LLaVAOneVision1_5_Model_Selector.forward (splice :259-276, 1-D position_ids / cache_position /
+        attention_mask selection :308-314) on a recording language model
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 """
@@ -316,7 +320,112 @@ def gen_attention_case(name, lens, hq, hkv, d, causal, seed):
     print(f"attention {name}: T={sum(lens)} hq={hq} hkv={hkv} d={d} causal={causal}")
 
 
+# ---------------------------------------------------------------------------------------------------
+# LLaVA-OneVision-1.5 goldens (the reference's OV classes run as they are)
+# ---------------------------------------------------------------------------------------------------
+OV_IMAGE_TOKEN = 151655
+
+
+def load_ov():
+    sys.path.insert(0, f"{REF}/llava-ov-15")
+    from compression_method import modeling_selector as ov
+    from compression_method.selector_scorer import TransformerScorer as OVScorer
+    sys.path.remove(f"{REF}/llava-ov-15")
+    return ov, OVScorer
+
+
+def gen_ov_lis_case(name, ov, OVScorer, d, hd, grids, seed):
+    """RiceTransformerPretrainedModel_Selector.forward with identity tower pieces: several images (grid_thw rows) scored
+    JOINTLY (the mean runs over all tokens of the call), budgets 0.1 / 0.2 / 0.5."""
+    n = int(sum(t * h * w for t, h, w in grids))
+    case = oin.make_case(d, hd, n, seed)
+    scorer = build_scorer(OVScorer, case)
+    h = torch.from_numpy(case["h"])
+    out = {"d": d, "hd": hd, "n": n, "seed": seed, "grids": np.asarray(grids, np.int64)}
+
+    def stub_tower(width, cls_value, scorer_, budget, seen):
+        def merger(x):
+            seen.append(x)
+            return x
+        return types.SimpleNamespace(
+            patch_embed=lambda x: x, rot_pos_emb=lambda g: torch.zeros(n, 4), class_embedding=torch.full((width,), cls_value),
+            class_pos_emb=torch.zeros(4), pre_layernorm=lambda x: x, blocks=[], gradient_checkpointing=False, training=False,
+            merger=merger, importance_scorer=scorer_, budgets=budget)
+
+    # Which row of the tower input reaches the LIS block at each position?  The reference's CLS insertion / removal loops
+    # (:131-166) run as they are on a row-id tensor (CLS = -1): with several images the removal reads seg_start+1 of the
+    # CLS-extended layout for every segment, so rows of later images are shifted -- that IS the reference's merger input.
+    seen = []
+    ov.RiceTransformerPretrainedModel_Selector.forward(
+        stub_tower(1, -1.0, lambda x: x[..., 0], 0.5, seen), torch.arange(n, dtype=torch.float32)[:, None], torch.tensor(grids))
+    rowmap = seen[0][:, 0].to(torch.int64)
+    out["lis_rowmap"] = rowmap.numpy()
+    h_lis = torch.where((rowmap >= 0)[:, None], h[rowmap.clamp(min=0)], torch.zeros(()))
+    for r in oin.BUDGETS:
+        seen = []
+        stub = stub_tower(d, 0.0, scorer, r, seen)
+        with torch.no_grad():
+            kept, idx, total = ov.RiceTransformerPretrainedModel_Selector.forward(stub, h, torch.tensor(grids))
+        assert torch.equal(seen[0], h_lis)
+        assert total == n and torch.equal(kept, h_lis[idx]) and torch.equal(stub.last_selected_indices, idx)
+        tag = str(r).replace(".", "p")
+        out[f"idx_{tag}"] = idx.numpy().astype(np.int64)
+        out[f"ps_{tag}"] = stub.last_combined_scores.numpy().astype(np.float32)
+    h = h_lis
+    with torch.no_grad():
+        out["scores"] = scorer(h[None])[0].numpy().astype(np.float32)
+    srt = np.sort(out["scores"])[::-1]
+    out["gaps"] = np.array([srt[max(1, int(n * r)) - 1] - srt[max(1, int(n * r))] for r in oin.BUDGETS], np.float32)
+    out["score_std"] = np.float32(out["scores"].std())
+    np.savez_compressed(os.path.join(HERE, f"ovlis_{name}.npz"), **out)
+    print(f"ov lis {name}: N={n} (images {len(grids)}) gaps/std={out['gaps'] / out['score_std']}")
+
+
+def gen_ov_splice_case(name, ov, n_visual, n_pre, n_post, k, seed, d_llm=32, with_position_ids=False):
+    """LLaVAOneVision1_5_Model_Selector.forward on a recording language model: what the LLM is handed after the splice."""
+    ids = torch.from_numpy(oin.make_prompt(n_visual, n_pre, n_post, OV_IMAGE_TOKEN, seed))
+    rng = np.random.default_rng(seed + 1)
+    all_idx = np.sort(rng.choice(n_visual, size=k, replace=False)).astype(np.int64)
+    vis_embeds = rng.standard_normal((k, d_llm), dtype=np.float32)
+    seen = {}
+
+    def language_model(**kw):
+        seen.update(kw)
+        return types.SimpleNamespace(last_hidden_state=kw["inputs_embeds"], past_key_values=None, hidden_states=None,
+                                     attentions=None)
+
+    stub = types.SimpleNamespace(
+        config=types.SimpleNamespace(output_attentions=False, output_hidden_states=False, use_return_dict=True,
+                                     image_token_id=OV_IMAGE_TOKEN, video_token_id=151656),
+        get_input_embeddings=lambda: (lambda t: embed_fn(t, d_llm)),
+        get_image_features=lambda pv, grid: (torch.from_numpy(vis_embeds), torch.from_numpy(all_idx), n_visual),
+        language_model=language_model, rope_deltas=None)
+    L = ids.shape[1]
+    kw = dict(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=torch.zeros(1, 1),
+              image_grid_thw=torch.tensor([[1, 2, n_visual // 2]]), use_cache=False,
+              cache_position=torch.arange(L))        # generate() always passes it (the reference indexes it with positions of
+                                                     # the ORIGINAL prompt, :312, so its own arange over L' would not do)
+    if with_position_ids:
+        kw["position_ids"] = (torch.arange(L) + 5)[None]          # a caller-supplied 1-D position row is sliced the same way
+    with torch.no_grad():
+        _, visual_token_num = ov.LLaVAOneVision1_5_Model_Selector.forward(stub, **kw)
+    assert visual_token_num == n_visual
+    out = dict(n_visual=n_visual, n_pre=n_pre, n_post=n_post, k=k, seed=seed, d_llm=d_llm, all_idx=all_idx,
+               vis_embeds=vis_embeds, with_position_ids=with_position_ids,
+               position_ids=seen["position_ids"].numpy(), cache_position=seen["cache_position"].numpy(),
+               attention_mask=seen["attention_mask"].numpy(), inputs_embeds=seen["inputs_embeds"].numpy())
+    np.savez_compressed(os.path.join(HERE, f"ovsplice_{name}.npz"), **out)
+    print(f"ov splice {name}: L={L} -> L'={seen['inputs_embeds'].shape[1]}")
+
+
 def main():
+    if "--ov-only" in sys.argv:
+        ov, OVScorer = load_ov()
+        gen_ov_lis_case("8x81", ov, OVScorer, 256, 128, [[1, 9, 9]] * 8, 41)
+        gen_ov_lis_case("3ragged", ov, OVScorer, 512, 256, [[1, 10, 12], [1, 6, 7], [2, 8, 8]], 42)
+        gen_ov_splice_case("a", ov, 64, 7, 12, 12, 51)
+        gen_ov_splice_case("b", ov, 290, 20, 33, 58, 52, with_position_ids=True)
+        return
     ft, TransformerScorer = load_ft()
     ev = load_ev()
     torch.manual_seed(0)
@@ -327,6 +436,7 @@ def main():
     gen_splice_case("video_a", ev, "video", 128, (2, 16, 16), 9, 14, 25, 23)
     for case in oin.ATTN_GOLDEN_CASES:
         gen_attention_case(*case)
+    print("LLaVA-OV goldens: run again with --ov-only (separate process: the OV tree has its own compression_method package)")
 
 
 if __name__ == "__main__":

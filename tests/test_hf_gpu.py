@@ -1071,3 +1071,92 @@ def test_ops_follow_the_device_of_their_tensors():
                                                   "q_proj": type("L", (), {"weight": wq.float(), "bias": bq.float()}),
                                                   "hidden_dim": 32}))
     assert float((scores - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+# ---- LLaVA-OV surface against goldens produced by the reference's own OV classes (tests/golden/ov*.npz) -------------------
+@pytest.mark.parametrize("name", ["8x81", "3ragged"])
+def test_llavaov15_tower_block_matches_reference_golden(golden_dir, name):
+    """llavaov15_vision_tower_forward_selector_eval around a tower that hands over the reference's LIS input: indices
+    bit-exact, kept rows exact, last_combined_scores within 1e-5 (fp32) of RiceTransformerPretrainedModel_Selector.forward
+    (llava-ov-15/compression_method/modeling_selector.py:173-184), several images scored jointly."""
+    import os
+    import types
+    from oracle import inputs as oin
+    from visionselector_amd.hf_generic import make_vision_tower_forward_selector
+    from visionselector_amd.selector import TransformerScorer
+    g = np.load(os.path.join(golden_dir, f"ovlis_{name}.npz"))
+    d, hd, n = int(g["d"]), int(g["hd"]), int(g["n"])
+    c = oin.make_case(d, hd, n, int(g["seed"]))
+    m = g["lis_rowmap"]
+    h = torch.from_numpy(np.where((m >= 0)[:, None], c["h"][np.clip(m, 0, None)], np.float32(0)).astype(np.float32)).cuda()
+
+    class Tower(torch.nn.Module):
+        def forward(self, hidden_states, grid_thw, **kw):
+            return hidden_states
+
+    for dt, exact in ((torch.float32, True), (torch.bfloat16, False)):
+        tower = Tower()
+        tower.importance_scorer = TransformerScorer(d, hd).cuda().to(dt)
+        with torch.no_grad():
+            tower.importance_scorer.q_proj.weight.copy_(torch.from_numpy(c["wq"]))
+            tower.importance_scorer.q_proj.bias.copy_(torch.from_numpy(c["bq"]))
+            tower.importance_scorer.k_proj.weight.copy_(torch.from_numpy(c["wk"]))
+            tower.importance_scorer.k_proj.bias.copy_(torch.from_numpy(c["bk"]))
+        tower.forward = types.MethodType(make_vision_tower_forward_selector(Tower.forward, "eval"), tower)
+        for r in oin.BUDGETS:
+            tag = str(r).replace(".", "p")
+            tower.budgets = r
+            with torch.no_grad():
+                kept, idx, total = tower(h.to(dt), torch.from_numpy(g["grids"]).cuda())
+            assert total == n and np.array_equal(idx.cpu().numpy(), g[f"idx_{tag}"])        # inputs are bf16-representable
+            assert torch.equal(kept, h.to(dt)[idx])
+            tol = 1e-5 if exact else 4e-3                                                       # bf16 storage of the probabilities
+            assert np.abs(tower.last_combined_scores.float().cpu().numpy() - g[f"ps_{tag}"]).max() <= tol
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_llavaov15_model_splice_matches_reference_golden(golden_dir, name):
+    """llavaov15_vlmodel_forward_selector_eval hands the language model exactly what LLaVAOneVision1_5_Model_Selector.forward
+    does (modeling_selector.py:259-276, :308-314): embeds, 1-D position_ids, cache_position, attention_mask -- bit-exact."""
+    import os
+    from oracle import inputs as oin
+    from visionselector_amd.hf_llavaov15 import llavaov15_vlmodel_forward_selector_eval
+    g = np.load(os.path.join(golden_dir, f"ovsplice_{name}.npz"))
+    n_visual, d = int(g["n_visual"]), int(g["d_llm"])
+    image_token = 151655
+    ids = torch.from_numpy(oin.make_prompt(n_visual, int(g["n_pre"]), int(g["n_post"]), image_token, int(g["seed"]))).cuda()
+    L = ids.shape[1]
+    seen = {}
+
+    class LM(torch.nn.Module):
+        def forward(self, **kw):
+            seen.update(kw)
+            import types as _t
+            return _t.SimpleNamespace(last_hidden_state=kw["inputs_embeds"], past_key_values=None, hidden_states=None, attentions=None)
+
+    class VL(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.language_model = LM()
+            self.config = type("C", (), {"image_token_id": image_token, "video_token_id": 151656, "output_attentions": False,
+                                         "output_hidden_states": False, "use_return_dict": True})()
+            self.rope_deltas = None
+
+        def get_input_embeddings(self):
+            ar = torch.arange(d, device="cuda")
+            return lambda t: (((t[..., None] * 31 + ar * 17) % 257).float() / 257.0)
+
+        def get_image_features(self, pixel_values, grid):
+            return torch.from_numpy(g["vis_embeds"]).cuda(), torch.from_numpy(g["all_idx"]).cuda(), n_visual
+
+    kw = dict(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=torch.zeros(1, 1, device="cuda"),
+              image_grid_thw=torch.tensor([[1, 2, n_visual // 2]]).cuda(), use_cache=False, cache_position=torch.arange(L, device="cuda"))
+    if bool(g["with_position_ids"]):
+        kw["position_ids"] = (torch.arange(L, device="cuda") + 5)[None]
+    with torch.no_grad():
+        _, n_vis = llavaov15_vlmodel_forward_selector_eval(VL(), **kw)
+    assert n_vis == n_visual
+    assert np.array_equal(seen["inputs_embeds"].cpu().numpy(), g["inputs_embeds"])
+    assert np.array_equal(seen["position_ids"].cpu().numpy(), g["position_ids"])
+    assert np.array_equal(seen["cache_position"].cpu().numpy(), g["cache_position"])
+    assert np.array_equal(seen["attention_mask"].cpu().numpy(), g["attention_mask"])

@@ -247,3 +247,50 @@ def test_attention_oracle_matches_reference_eager_module(golden_dir, name):
     for got, want in ((out, g["out"]), (dq, g["dq"]), (dk, g["dk"]), (dv, g["dv"])):
         assert got.shape == want.shape
         assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+
+
+# ---- LLaVA-OneVision-1.5 goldens (produced by the reference's OWN OV classes, make_golden.py --ov-only) ----------------
+OV_LIS = ["8x81", "3ragged"]
+OV_SPLICE = ["a", "b"]
+
+
+def ov_lis_input(g):
+    """Tokens that reach the LIS block of RiceTransformerPretrainedModel_Selector.forward for the seeded tower input: the
+    reference's CLS insertion / removal loops shift the rows of every image after the first (lis_rowmap, -1 = the zero CLS)."""
+    c = oin.make_case(int(g["d"]), int(g["hd"]), int(g["n"]), int(g["seed"]))
+    m = g["lis_rowmap"]
+    h = np.where((m >= 0)[:, None], c["h"][np.clip(m, 0, None)], np.float32(0))
+    return h.astype(np.float32), c
+
+
+@pytest.mark.parametrize("name", OV_LIS)
+def test_ov_tower_lis_block(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"ovlis_{name}.npz"))
+    h, c = ov_lis_input(g)
+    s = lis.scorer_reference(h[None], c["wq"], c["bq"], c["wk"], c["bk"])[0]
+    assert np.abs(s - g["scores"]).max() <= 2e-6 * max(1.0, np.abs(g["scores"]).max())
+    n = int(g["n"])
+    for r in oin.BUDGETS:                                  # several images, ONE joint selection (modeling_selector.py:173-180)
+        tag = str(r).replace(".", "p")
+        k = lis.budget_k_eval(n, r)
+        assert np.array_equal(lis.hard_topk_indices(g["scores"], k), g[f"idx_{tag}"])
+        _, ps = lis.find_ts(g["scores"][None], k)
+        assert np.abs(ps[0] - g[f"ps_{tag}"]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("name", OV_SPLICE)
+def test_ov_model_splice(golden_dir, name):
+    """LLaVAOneVision1_5_Model_Selector.forward (modeling_selector.py:259-276, :308-314): 1-D position_ids, cache_position and
+    attention_mask are index-selected with the kept positions."""
+    g = np.load(os.path.join(golden_dir, f"ovsplice_{name}.npz"))
+    ids = oin.make_prompt(int(g["n_visual"]), int(g["n_pre"]), int(g["n_post"]), IMAGE_TOKEN, int(g["seed"]))
+    L = ids.shape[1]
+    sel, new_ids = splice.splice_image(ids, IMAGE_TOKEN, g["all_idx"])
+    d = int(g["d_llm"])
+    emb = (((ids[..., None] * 31 + np.arange(d) * 17) % 257).astype(np.float32) / 257.0)
+    out = splice.splice_embeds(emb, new_ids, sel, IMAGE_TOKEN, g["vis_embeds"])
+    assert np.array_equal(out, g["inputs_embeds"])
+    pos_in = (np.arange(L) + 5)[None] if bool(g["with_position_ids"]) else np.arange(L)[None]
+    pos, am = splice.slice_positions(pos_in, np.ones((1, L), np.int64), sel)
+    assert np.array_equal(pos, g["position_ids"]) and np.array_equal(am, g["attention_mask"])
+    assert np.array_equal(np.arange(L)[sel], g["cache_position"])

@@ -7,7 +7,7 @@ Same names, argument meaning and error behaviour as the reference (paths under t
   lis_select_block             the LIS lines of Qwen2_5_VisionTransformerPretrainedModel_Selector.forward
                                (qwen-evaluation/token_compression/selector_model.py:182-194)
   curriculum_weight            ScheduledWeightTrainer.compute_loss (qwen-vl-finetune/qwenvl/train/train_qwen_selector.py:66-79)
-  splice_image / splice_video  qwen-evaluation/token_compression/selector_model.py:243-320 (index algebra, plain torch)
+  (the sequence splice, EV :243-320, is ops.splice / ops.splice_batched -- HIP; its CPU restatement lives in oracle/splice.py)
 
 All arithmetic on visual tokens runs in HIP kernels; there is no eager fallback (CPU tensors raise).
 """
@@ -186,48 +186,3 @@ def curriculum_weight(global_step: int, max_steps: int, reg_weight_start: float 
         progress = min(global_step / max_steps, 1.0)
         return reg_weight_start + (reg_weight_end - reg_weight_start) * progress
     return reg_weight_start
-
-
-# --------------------------------------------------------------------------------------------------
-# sequence splice (index algebra; plain torch, device agnostic)
-# --------------------------------------------------------------------------------------------------
-def splice_image(input_ids: torch.Tensor, inputs_embeds: torch.Tensor, image_token_id: int, all_indices: torch.Tensor,
-                 image_embeds: torch.Tensor):
-    """EV/token_compression/selector_model.py:246-262 -> (selected_indices, input_ids', inputs_embeds')."""
-    origin_image_indices = torch.where(input_ids == image_token_id)[1]
-    retain_image_indices = origin_image_indices[all_indices]
-    origin_text_indices = torch.where(input_ids != image_token_id)[1]
-    combined_indices = torch.cat((retain_image_indices, origin_text_indices))
-    selected_indices, _ = torch.sort(combined_indices)
-    new_ids = input_ids[:, selected_indices]
-    new_embeds = inputs_embeds[:, selected_indices, :]
-    image_mask = (new_ids == image_token_id).unsqueeze(-1).expand_as(new_embeds)
-    new_embeds = new_embeds.masked_scatter(image_mask, image_embeds.to(new_embeds.device, new_embeds.dtype))
-    return selected_indices, new_ids, new_embeds
-
-
-def splice_video(input_ids: torch.Tensor, inputs_embeds: torch.Tensor, video_token_id: int, all_indices: torch.Tensor,
-                 video_embeds: torch.Tensor, vision_start_id: int = 151652, vision_end_id: int = 151653):
-    """EV/token_compression/selector_model.py:264-295 -> (selected_indices, input_ids', inputs_embeds', text_image_mask)."""
-    n_video_tokens = video_embeds.shape[0]
-    total_len = input_ids.shape[-1]
-    assert input_ids.shape[0] == 1, "selector only support single batch"
-    before_idx = int((input_ids[0] == vision_start_id).nonzero(as_tuple=True)[0][0].item()) + 1
-    post_idx = int((input_ids[0] == vision_end_id).nonzero(as_tuple=True)[0][-1].item())
-    vid = torch.full((input_ids.shape[0], n_video_tokens), video_token_id, dtype=input_ids.dtype, device=input_ids.device)
-    new_ids = torch.cat((input_ids[:, :before_idx], vid, input_ids[:, post_idx:]), dim=1)
-    shifted = all_indices + before_idx
-    combined = torch.cat((torch.arange(0, before_idx, device=shifted.device), shifted,
-                          torch.arange(post_idx, total_len, device=shifted.device)))
-    selected_indices, _ = torch.sort(combined)
-    new_embeds = inputs_embeds[:, selected_indices, :]
-    video_mask = (new_ids == video_token_id).unsqueeze(-1).expand_as(new_embeds)
-    new_embeds = new_embeds.masked_scatter(video_mask, video_embeds.to(new_embeds.device, new_embeds.dtype))
-    return selected_indices, new_ids, new_embeds, new_ids != video_token_id
-
-
-def slice_positions(position_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], selected_indices: torch.Tensor):
-    """EV :318-319 (M-RoPE position_ids [3,1,L] computed from the ORIGINAL ids, then sliced) / OV :311-314."""
-    pos = position_ids[..., selected_indices]
-    am = None if attention_mask is None else attention_mask[:, selected_indices]
-    return pos, am

@@ -252,14 +252,17 @@ def main():
     dom = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else None
     roofline = None
     if dom is not None:
-        kb = kernel_bytes(dom, b, n, d, hd, k)
+        # from 32 images up libvsel cuts a call into two halves (lis.hip): each sweep / gather launch covers b / 2 images
+        b_launch = b / max(1.0, kern[dom]["launches_per_step"])
+        kb = kernel_bytes(dom, b_launch, n, d, hd, k)
         avg_s = prof[dom][0] / prof[dom][1] * 1e-3
         ach = (kb / avg_s / 1e9) if kb else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": pmc_traffic(dom, b),
-                    "algorithmic_bytes_per_launch": kb, "avg_launch_us": avg_s * 1e6,
-                    "note": "achieved = algorithmic bytes of this kernel / its HIP-event duration (instrumented single-stream pass); "
-                            "traffic = bytes/launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json)"}
+                    "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": pmc_traffic(dom, int(b_launch)),
+                    "algorithmic_bytes_per_launch": kb, "avg_launch_us": avg_s * 1e6, "images_per_launch": b_launch,
+                    "note": "achieved = algorithmic bytes of one launch of this kernel / its HIP-event duration (instrumented pass: "
+                            "the same launches as the product path, back to back on one stream); traffic = bytes/launch from the "
+                            "committed rocprofv3 PMC passes (profiles/pmc_traffic.json)"}
     path_bytes = algorithmic_bytes(b, n, d, hd, k)
     path = {"algorithmic_bytes_per_step": path_bytes, "achieved_GBps": path_bytes / (ms_per_step * 1e-3) / 1e9,
             "frac_of_8TBps": path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}

@@ -223,7 +223,8 @@ def test_full_size_properties(ops, budget):
 
 
 def test_two_half_pipeline_equals_single_stream(ops):
-    """The aux-stream software pipeline (>= 8 segments) must give bit-identical results to the single-stream order."""
+    """The opt-in aux-stream software pipeline (>= 32 segments, vsel_debug_set_pipeline(1)) must give bit-identical results to
+    the single-stream, single-piece order."""
     import ctypes
     from visionselector_amd import _native
     lib = _native.lib()
@@ -292,3 +293,75 @@ def test_permuted_select_equals_unreorder_then_select(ops):
     assert torch.equal(got[1], ref[1]) and torch.equal(got[0], ref[0])
     # scores: same per-row dot products; the column mean is summed in a different row order -> fp32 roundoff only
     assert float((got[2] - ref[2]).abs().max()) <= 4e-6 * max(1.0, float(ref[2].abs().max()))
+
+
+def _small_path(lib, on, default=2):
+    """on: the small-batch form for up to 8 segments (the library default is 2); off: never; restore with on=None."""
+    import ctypes
+    lib.vsel_debug_set_small_path(ctypes.c_int(default if on is None else (8 if on else 0)))
+
+
+@pytest.mark.parametrize("d,hd,n,k,batches", [(3584, 1792, 2304, 460, (1, 2, 4, 8)),      # Qwen2.5-VL-7B, the reference's eval call
+                                                (2048, 1024, 576, 115, (1, 3)),              # 3B
+                                                (4096, 2048, 5832, 1166, (1,)),              # LLaVA-OV 8 x 729 jointly
+                                                (64, 32, 40, 8, (1, 8)), (512, 112, 130, 1, (2,)), (1040, 528, 9000, 4500, (1,))])
+@pytest.mark.parametrize("storage", ["bf16", "f32"])
+def test_small_batch_path_is_bit_identical(ops, d, hd, n, k, batches, storage):
+    """The five-launch small-batch form (csrc/lis_small.h, <= 8 segments) against the batched nine-launch form on the same
+    inputs: scores, indices and kept rows bit for bit; also the scores-only entry."""
+    from visionselector_amd import _native
+    lib = _native.lib()
+    dt = torch.bfloat16 if storage == "bf16" else torch.float32
+    for b in batches:
+        c = oin.make_case(d, hd, n, 100 + b, batch=b)
+        h = dev(c["h"], dt)
+        wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("wq", "bq", "wk", "bk"))
+        try:
+            _small_path(lib, False)
+            ref = ops.lis_select(h, wq, bq, wk, bk, k)
+            ref_s = ops.lis_scores(h, wq, bq, wk, bk)
+            _small_path(lib, True)
+            _native.profile_start()
+            got = ops.lis_select(h, wq, bq, wk, bk, k)
+            prof = _native.profile_stop()
+            got_s = ops.lis_scores(h, wq, bq, wk, bk)
+        finally:
+            _small_path(lib, None)
+        assert "proj_nt_small_kernel" in prof and "gemm_nt_bf16x3_kernel" not in prof, prof       # the small form really ran
+        assert sum(c_ for _, c_ in prof.values()) == (5 if n <= 8192 else 6), prof
+        for x, y in zip(got, ref):
+            assert torch.equal(x, y)
+        assert torch.equal(got_s, ref_s) and torch.equal(got_s, got[2])
+
+
+def test_small_batch_path_ragged_permuted_presummed(ops):
+    """Ragged segments, the un-reorder-fused form and the producer-supplied column sums through the small-batch kernels."""
+    from visionselector_amd import _native
+    lib = _native.lib()
+    d, hd = 2048, 1024
+    lens = [300, 17, 1000, 64, 5]
+    ks = [max(1, n // 5) for n in lens]
+    c = oin.make_case(d, hd, sum(lens), 77)
+    h, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    n = 640
+    c2 = oin.make_case(d, hd, n, 78)
+    h2 = dev(c2["h"], torch.bfloat16)
+    g = torch.Generator().manual_seed(3)
+    l2p = torch.randperm(n, generator=g).cuda()
+    p2l = torch.empty_like(l2p)
+    p2l[l2p] = torch.arange(n, device="cuda")
+    sums = h2.float().sum(0, keepdim=True).contiguous()
+    outs = {}
+    try:
+        for on in (False, True):
+            _small_path(lib, on)
+            outs[on] = (ops.lis_select_varlen(h, lens, ks, wq, bq, wk, bk) + ops.lis_select_permuted(h2, l2p, p2l, wq, bq, wk, bk, 128)
+                        + ops.lis_select_presummed(h2, sums, wq, bq, wk, bk, 128, logical_to_physical=l2p, physical_to_logical=p2l))
+    finally:
+        _small_path(lib, None)
+    for x, y in zip(outs[True], outs[False]):
+        assert torch.equal(x, y)
+    # and the permuted form equals "un-reorder, then select" (kept rows / indices exact)
+    out_p, idx_p, _ = outs[True][3:6]
+    out_r, idx_r, _ = ops.lis_select(h2[l2p].contiguous(), wq, bq, wk, bk, 128)
+    assert torch.equal(idx_p, idx_r) and torch.equal(out_p, out_r)

@@ -1,5 +1,6 @@
 // C-ABI entry points of the LIS inference path (kernels in lis_kernels.h).
 #include "lis_kernels.h"
+#include "lis_small.h"
 
 #include <stdlib.h>
 
@@ -10,15 +11,26 @@ int check_segments(const vsel_segments* seg, bool need_k) { return check_segment
 using namespace vsel;
 
 // ---- two-half software pipeline ----------------------------------------------------------------------------------
-// With >= kPipelineMinSegments segments the batch is split in two halves that run on the caller's stream and on a
-// library-owned auxiliary stream (fork / join with events): the small latency-bound kernels of one half (projections,
-// finish kernels, radix select) execute underneath the HBM-bound sweeps of the other half.  Results are identical to
-// the single-stream order (each half is self-contained, every kernel is deterministic).
+// The path is bound by the fabric between the XCDs and memory (HBM and Infinity-Cache traffic are NOT additive on this part,
+// tools/membw3.hip), so the only time to win at large batch is the ~70 us of small latency-bound kernels between the sweeps
+// (projections, finish kernels, radix select).  With >= kPipelineMinSegments segments the batch is cut in two halves A, B that
+// run on the caller's stream and on a library-owned auxiliary stream, so the small kernels of one half execute underneath the
+// sweeps of the other:
+//
+//   caller's stream : S1(A) S1(B) --fork--> proj(B) S2(B) select(B) G(B) <--join--
+//   auxiliary stream:                       proj(A) S2(A) select(A) G(A)
+//
+// Exactly two cross-stream hand-offs per call: a hand-off costs ~8 us on this runtime, and a schedule that kept the sweeps on
+// one stream and only the small kernels on the other (8 hand-offs) measured 5 % SLOWER than no pipeline at all.  Every kernel
+// is deterministic and each half is self-contained with a batch-invariant plan, so the results are bit-identical to the
+// single-stream order.  Under vsel_profile_start() the same half-sized launches run back to back on the caller's stream, so
+// per-kernel HIP-event durations refer to the launches the product path really makes.
 constexpr int64_t kPipelineMinSegments = 32;
+constexpr int kEventSets = 8, kEventsPerSet = 8;
 
 struct AuxStream {
   hipStream_t stream = nullptr;
-  hipEvent_t fork[8], join[8];
+  hipEvent_t ev[kEventSets][kEventsPerSet];
   unsigned next = 0;
   bool ok = false;
 };
@@ -30,31 +42,52 @@ static AuxStream* aux_for_current_device() {
   AuxStream& a = table[dev];
   if (!a.ok) {
     if (hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    for (int i = 0; i < 8; ++i) {
-      if (hipEventCreateWithFlags(&a.fork[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-      if (hipEventCreateWithFlags(&a.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-    }
+    for (int i = 0; i < kEventSets; ++i)
+      for (int j = 0; j < kEventsPerSet; ++j)
+        if (hipEventCreateWithFlags(&a.ev[i][j], hipEventDisableTiming) != hipSuccess) return nullptr;
     a.ok = true;
   }
   return &a;
 }
 
-// OFF by default: VSEL_PIPELINE=1 in the environment (or vsel_debug_set_pipeline(1)) turns it on.  Measured +4 % tokens/s
-// at B=128 on MI355X; it is opt-in because concurrent half-batch launches make per-kernel durations (rocprofv3, HIP
-// events) incomparable with the single-stream roofline numbers bench.py reports.
+// OFF by default (VSEL_PIPELINE=1 or vsel_debug_set_pipeline(1) turns it on): measured on MI355X at B = 32 / 64 / 128 images it is
+// 264.7 / 454.3 / 884.6 us per call against 240.9 / 449.2 / 878.6 us for the single-piece, single-stream order -- the halves pay
+// the latency-bound small kernels twice and the two hand-offs, which eats what the overlap wins.
 static int g_pipeline_enabled = [] {
   const char* e = getenv("VSEL_PIPELINE");
   return (e && e[0] == '1') ? 1 : 0;
 }();
 extern "C" void vsel_debug_set_pipeline(int on) { g_pipeline_enabled = on; }
 
+// small-batch form (lis_small.h): used up to g_small_path_max_seg segments per call.  Measured on MI355X (Qwen2.5-VL-7B geometry,
+// us per call, small form vs batched form): 1 image 46.5 vs 51.7, 2 images 54.3 vs 55.8, 4 images 73.4 vs 65.5, 8 images 108.6 vs
+// 86.3 -- the redundant prologues grow with the segment count, so the default limit is 2.  VSEL_SMALL_PATH=<n> /
+// vsel_debug_set_small_path(n) set the limit (0 = never; at most kSmallMaxSeg).
+static int g_small_path_max_seg = [] {
+  const char* e = getenv("VSEL_SMALL_PATH");
+  const int v = e ? atoi(e) : 2;
+  return v < 0 ? 0 : (v > kSmallMaxSeg ? kSmallMaxSeg : v);
+}();
+extern "C" void vsel_debug_set_small_path(int max_seg) {
+  g_small_path_max_seg = max_seg < 0 ? 0 : (max_seg > kSmallMaxSeg ? kSmallMaxSeg : max_seg);
+}
+static bool use_small_path(const vsel_segments* seg, const vsel_scorer* sc, const LisPlan& p) {
+  return seg->n_seg <= g_small_path_max_seg && small_path_ok(seg, sc, p);
+}
+
 template <typename T, typename TW>
-static int select_half(hipStream_t st, const T* h, const vsel_segments* seg, const vsel_scorer* sc, char* ws, const LisPlan& p,
-                       T* out, int64_t* idx, float* scores, bool skip_colsum, const int64_t* l2p = nullptr,
-                       const int64_t* p2l = nullptr, const float* col_sums = nullptr) {
+static int select_whole(hipStream_t st, const T* h, const vsel_segments* seg, const vsel_scorer* sc, char* ws, const LisPlan& p,
+                        T* out, int64_t* idx, float* scores, const int64_t* l2p = nullptr, const int64_t* p2l = nullptr,
+                        const float* col_sums = nullptr) {
   int rc = VSEL_OK;
-  if (!skip_colsum && !col_sums) rc = run_colsum<T>(st, h, seg, (int)sc->d, ws, p);
+  if (!col_sums) rc = run_colsum<T>(st, h, seg, (int)sc->d, ws, p);
   if (rc) return rc;
+  if (use_small_path(seg, sc, p)) {
+    // a handful of segments: five launches instead of nine, bit-identical results (lis_small.h)
+    if ((rc = run_proj_small(st, seg, sc, ws, p, col_sums))) return rc;
+    if ((rc = run_score_small<T>(st, h, seg, sc, ws, p, scores, p2l))) return rc;
+    return launch_select_gather_small<T>(st, h, (int)sc->d, seg, scores, idx, out, l2p);
+  }
   rc = run_proj<TW>(st, seg, sc, ws, p, col_sums);
   if (rc) return rc;
   rc = run_score<T>(st, h, seg, sc, ws, p, scores, p2l);
@@ -69,51 +102,59 @@ static int lis_select_impl(hipStream_t st, const T* h, const vsel_segments* seg,
                            int64_t* idx, float* scores, const int64_t* l2p = nullptr, const int64_t* p2l = nullptr,
                            const float* col_sums = nullptr) {
   const int64_t S = seg->n_seg, d = sc->d;
-  AuxStream* aux = (g_pipeline_enabled && S >= kPipelineMinSegments && !prof_enabled() && !l2p && !col_sums)
-                       ? aux_for_current_device() : nullptr;
-  if (!aux) {
+  const bool halves = g_pipeline_enabled && S >= kPipelineMinSegments && !l2p && !col_sums;
+  if (!halves) {
     const LisPlan p = make_plan(S, seg->rows_per_seg, d, sc->hd);
-    return select_half<T, TW>(st, h, seg, sc, ws, p, out, idx, scores, false, l2p, p2l, col_sums);
+    return select_whole<T, TW>(st, h, seg, sc, ws, p, out, idx, scores, l2p, p2l, col_sums);
   }
   // halves A = [0, s0), B = [s0, S).  Uniform segments address rows relative to the half's base pointer; ragged
   // segments keep absolute offsets (seg_rows / seg_out are advanced instead).
   const int64_t s0 = S / 2;
-  vsel_segments a = *seg, b = *seg;
-  a.n_seg = s0;
-  b.n_seg = S - s0;
-  const T* hb = h;
-  T* outb = out;
-  int64_t* idxb = idx;
-  float* scb = scores;
+  vsel_segments sg[2] = {*seg, *seg};
+  sg[0].n_seg = s0;
+  sg[1].n_seg = S - s0;
+  const T* hh[2] = {h, h};
+  T* oo[2] = {out, out};
+  int64_t* ii[2] = {idx, idx};
+  float* ss[2] = {scores, scores};
   if (seg->seg_rows) {
-    b.seg_rows = seg->seg_rows + s0;
-    b.seg_out = seg->seg_out + s0;
-    a.total_rows = b.total_rows = seg->total_rows;   // informational only in the ragged form
+    sg[1].seg_rows = seg->seg_rows + s0;
+    sg[1].seg_out = seg->seg_out + s0;
+    sg[0].total_rows = sg[1].total_rows = seg->total_rows;   // informational only in the ragged form
   } else {
-    a.total_rows = s0 * seg->rows_per_seg;
-    a.total_out = s0 * seg->k;
-    b.total_rows = (S - s0) * seg->rows_per_seg;
-    b.total_out = (S - s0) * seg->k;
-    hb = h + a.total_rows * d;
-    outb = out + a.total_out * d;
-    idxb = idx + a.total_out;
-    scb = scores + a.total_rows;
+    sg[0].total_rows = s0 * seg->rows_per_seg;
+    sg[0].total_out = s0 * seg->k;
+    sg[1].total_rows = (S - s0) * seg->rows_per_seg;
+    sg[1].total_out = (S - s0) * seg->k;
+    hh[1] = h + sg[0].total_rows * d;
+    oo[1] = out + sg[0].total_out * d;
+    ii[1] = idx + sg[0].total_out;
+    ss[1] = scores + sg[0].total_rows;
   }
-  const LisPlan pa = make_plan(a.n_seg, seg->rows_per_seg, d, sc->hd);
-  const LisPlan pb = make_plan(b.n_seg, seg->rows_per_seg, d, sc->hd);
-  char* wsa = ws;
-  char* wsb = ws + pa.total;
-  const unsigned e = aux->next++ & 7u;
-  int rc = run_colsum<T>(st, h, &a, (int)d, wsa, pa);
-  if (rc) return rc;
-  VSEL_HIP_CHECK(hipEventRecord(aux->fork[e], st));
-  VSEL_HIP_CHECK(hipStreamWaitEvent(aux->stream, aux->fork[e], 0));
-  rc = select_half<T, TW>(aux->stream, h, &a, sc, wsa, pa, out, idx, scores, true);
-  if (rc) return rc;
-  VSEL_HIP_CHECK(hipEventRecord(aux->join[e], aux->stream));
-  rc = select_half<T, TW>(st, hb, &b, sc, wsb, pb, outb, idxb, scb, false);
-  if (rc) return rc;
-  VSEL_HIP_CHECK(hipStreamWaitEvent(st, aux->join[e], 0));
+  const PolicyScope whole_call_policy(seg->total_rows);   // cache policy of the sweeps = that of the whole call
+  const LisPlan pl[2] = {make_plan(sg[0].n_seg, seg->rows_per_seg, d, sc->hd), make_plan(sg[1].n_seg, seg->rows_per_seg, d, sc->hd)};
+  char* wss[2] = {ws, ws + pl[0].total};
+  AuxStream* aux = prof_enabled() ? nullptr : aux_for_current_device();
+  hipStream_t sx = aux ? aux->stream : st;          // where the small kernels go
+  hipEvent_t* ev = aux ? aux->ev[aux->next++ % kEventSets] : nullptr;
+  auto hand = [&](int e, hipStream_t from, hipStream_t to) -> int {   // "to" continues after what "from" has queued so far
+    if (!aux) return VSEL_OK;
+    VSEL_HIP_CHECK(hipEventRecord(ev[e], from));
+    VSEL_HIP_CHECK(hipStreamWaitEvent(to, ev[e], 0));
+    return VSEL_OK;
+  };
+  int rc;
+  for (int x = 0; x < 2; ++x)                       // S1(A) S1(B)
+    if ((rc = run_colsum<T>(st, hh[x], &sg[x], (int)d, wss[x], pl[x]))) return rc;
+  if ((rc = hand(0, st, sx))) return rc;            // fork: half A continues on the auxiliary stream
+  for (int x = 1; x >= 0; --x) {                    // the rest of B on the caller's stream, the rest of A on the auxiliary one
+    hipStream_t s = x == 1 ? st : sx;
+    if ((rc = run_proj<TW>(s, &sg[x], sc, wss[x], pl[x]))) return rc;
+    if ((rc = run_score<T>(s, hh[x], &sg[x], sc, wss[x], pl[x], ss[x]))) return rc;
+    if ((rc = launch_select(s, ss[x], &sg[x], ii[x], nullptr))) return rc;
+    if ((rc = launch_gather<T>(s, hh[x], (int)d, &sg[x], ii[x], oo[x]))) return rc;
+  }
+  if ((rc = hand(1, sx, st))) return rc;            // join
   return VSEL_OK;
 }
 
@@ -149,6 +190,17 @@ extern "C" int vsel_lis_scores(void* stream, const void* h, vsel_dtype hdtype, c
   if (!scores) return fail(VSEL_ERR_INVALID, "scores is NULL");
   hipStream_t s = (hipStream_t)stream;
   VSEL_PROF_BEGIN(s);
+  if (use_small_path(seg, sc, p)) {
+    int rc;
+    if (hdtype == VSEL_BF16) {
+      if ((rc = run_colsum<bf16_t>(s, (const bf16_t*)h, seg, (int)sc->d, (char*)ws, p))) return rc;
+      if ((rc = run_proj_small(s, seg, sc, (char*)ws, p, nullptr))) return rc;
+      return run_score_small<bf16_t>(s, (const bf16_t*)h, seg, sc, (char*)ws, p, scores, nullptr);
+    }
+    if ((rc = run_colsum<float>(s, (const float*)h, seg, (int)sc->d, (char*)ws, p))) return rc;
+    if ((rc = run_proj_small(s, seg, sc, (char*)ws, p, nullptr))) return rc;
+    return run_score_small<float>(s, (const float*)h, seg, sc, (char*)ws, p, scores, nullptr);
+  }
   if (hdtype == VSEL_BF16) return run_scores_w<bf16_t>(s, (const bf16_t*)h, seg, sc, (char*)ws, p, scores);
   return run_scores_w<float>(s, (const float*)h, seg, sc, (char*)ws, p, scores);
 }

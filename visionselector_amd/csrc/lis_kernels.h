@@ -33,7 +33,20 @@ constexpr int kSliceNN = 128;        // split-K slice of the w projection
 // NT: non-temporal loads (the token tensor is streamed once per sweep and does not fit the caches); chosen per launch by
 // stream_policy() -- below ~384 MB the default policy is faster because sweep 2 and the gather hit what sweep 1 left in the
 // Infinity Cache (tools/exp_small_batch.py: B = 8 images 86 vs 96 us, B = 32 271 vs 238 us).  Results are identical.
-template <typename T, bool NT>
+template <typename T> __device__ __forceinline__ void unpack_vec(u32x4 raw, float (&v)[Elem<T>::kVec]);
+template <> __device__ __forceinline__ void unpack_vec<bf16_t>(u32x4 raw, float (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(raw[i] << 16);
+    v[2 * i + 1] = __uint_as_float(raw[i] & 0xffff0000u);
+  }
+}
+template <> __device__ __forceinline__ void unpack_vec<float>(u32x4 raw, float (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(raw[i]);
+}
+
+template <typename T, bool NT, bool DEEP = false>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ h, SegView sv, int d,
                                                              int row_splits, float* __restrict__ partial) {
   constexpr int V = Elem<T>::kVec;
@@ -56,6 +69,27 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   if (col < d) {
     const T* base = h + (r0 * (int64_t)d + col);
     int r = rb + wave;
+    if constexpr (DEEP) {
+      // a handful of segments (latency-bound, one wave per SIMD): the wave's whole share of a full chunk -- 32 rows -- in flight
+      // at once, as raw 16-byte vectors; added in exactly the order of the loop below
+      if (r + 124 < re) {
+        u32x4 raw[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) raw[q] = *reinterpret_cast<const u32x4*>(base + (int64_t)(r + 4 * q) * d);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v[8][V];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) unpack_vec<T>(raw[8 * g + q], v[q]);
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            acc[i] = ((acc[i] + v[0][i]) + v[1][i]) + (v[2][i] + v[3][i]);
+            acc[i] = ((acc[i] + v[4][i]) + v[5][i]) + (v[6][i] + v[7][i]);
+          }
+        }
+        r += 128;
+      }
+    }
     // 8 rows in flight per wave (same-box A/B at B = 128: ~1 % faster than 4).  Summation order = two consecutive 4-row steps,
     // so results are unchanged.
     for (; r + 28 < re; r += 32) {
@@ -300,21 +334,13 @@ __device__ __forceinline__ float dot_raw<float>(u32x4 raw, const float (&w)[4], 
 // K4  scores[row] = (x_row . w[s] + c[s]) / sqrt(Hd).  grid (row_chunks, n_seg), block 256.
 //     ITERS > 0: D == ITERS * 64 * V exactly and w[s] lives in registers; ITERS == 0: generic.
 // =================================================================================================
+// body shared by score_kernel (w, c from global memory) and score_small_kernel (lis_small.h: w, c rebuilt in LDS by the block):
+// rows [rb, re) of segment s, ws = the segment's w [d], cs = its c.
 template <typename T, int ITERS, bool NT>
-__global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, SegView sv, int d,
-                                                    const float* __restrict__ w, const float* __restrict__ c,
-                                                    float sqrt_hd, int rows_per_block, float* __restrict__ scores,
-                                                    const int64_t* __restrict__ out_map) {
+__device__ __forceinline__ void score_rows(const T* __restrict__ h, int d, const float* ws, float cs, float sqrt_hd, int64_t r0,
+                                           int rb, int re, float* __restrict__ scores, const int64_t* __restrict__ out_map) {
   constexpr int V = Elem<T>::kVec;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int s = blockIdx.y;
-  const int n = sv.n_rows(s);
-  const int rb = blockIdx.x * rows_per_block;
-  if (rb >= n) return;
-  const int re = min(n, rb + rows_per_block);
-  const int64_t r0 = sv.row_begin(s);
-  const float cs = c[s];
-  const float* ws = w + (int64_t)s * d;
   if constexpr (ITERS > 0) {
     float wr[ITERS][V];
 #pragma unroll
@@ -403,6 +429,18 @@ __global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, Seg
       if (lane == 0) scores[out_map ? out_map[r0 + r] : r0 + r] = (a0 + cs) / sqrt_hd;
     }
   }
+}
+
+template <typename T, int ITERS, bool NT>
+__global__ __launch_bounds__(256) void score_kernel(const T* __restrict__ h, SegView sv, int d,
+                                                    const float* __restrict__ w, const float* __restrict__ c,
+                                                    float sqrt_hd, int rows_per_block, float* __restrict__ scores,
+                                                    const int64_t* __restrict__ out_map) {
+  const int s = blockIdx.y;
+  const int n = sv.n_rows(s);
+  const int rb = blockIdx.x * rows_per_block;
+  if (rb >= n) return;
+  score_rows<T, ITERS, NT>(h, d, w + (int64_t)s * d, c[s], sqrt_hd, sv.row_begin(s), rb, min(n, rb + rows_per_block), scores, out_map);
 }
 
 // =================================================================================================
@@ -536,7 +574,16 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
 // Cache policy of the three kernels that touch the token tensor: non-temporal once the tensor clearly exceeds the Infinity
 // Cache (256 MB) + L2 (32 MB).  Measured crossover between 264 MB (default policy 4 % faster) and 528 MB (nt 12 % faster).
 constexpr int64_t kStreamBytes = 384ll << 20;
-inline bool stream_policy(int64_t total_rows, int64_t d, size_t elem) { return total_rows * d * (int64_t)elem >= kStreamBytes; }
+// The policy is a property of the WHOLE API call: when a call is cut into halves (lis.hip) the halves inherit the call's row count.
+inline thread_local int64_t tl_policy_rows = -1;
+struct PolicyScope {
+  explicit PolicyScope(int64_t rows) { tl_policy_rows = rows; }
+  ~PolicyScope() { tl_policy_rows = -1; }
+};
+inline bool stream_policy(int64_t total_rows, int64_t d, size_t elem) {
+  const int64_t rows = tl_policy_rows >= 0 ? tl_policy_rows : total_rows;
+  return rows * d * (int64_t)elem >= kStreamBytes;
+}
 
 struct LisPlan {
   int64_t S, maxn, d, hd;
@@ -639,7 +686,9 @@ inline int launch_colsum(hipStream_t st, const T* h, const SegView& sv, int d, i
                          int64_t total_rows) {
   constexpr int V = Elem<T>::kVec;
   const dim3 grid((unsigned)cdiv(d, 64 * V), row_splits, S);
-  if (stream_policy(total_rows, d, sizeof(T)))
+  if ((int64_t)grid.x * grid.y * grid.z <= 1024)       // <= one workgroup per SIMD-quad: latency-bound, use the deep form
+    hipLaunchKernelGGL((colsum_partial_kernel<T, false, true>), grid, dim3(256), 0, st, h, sv, d, row_splits, partial);
+  else if (stream_policy(total_rows, d, sizeof(T)))
     hipLaunchKernelGGL((colsum_partial_kernel<T, true>), grid, dim3(256), 0, st, h, sv, d, row_splits, partial);
   else
     hipLaunchKernelGGL((colsum_partial_kernel<T, false>), grid, dim3(256), 0, st, h, sv, d, row_splits, partial);

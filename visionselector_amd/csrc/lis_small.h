@@ -1,0 +1,516 @@
+// Small-batch form of the LIS inference path (1 .. kSmallMaxSeg segments per call; the reference's real evaluation call is ONE
+// image: qwen-evaluation/token_compression/selector_model.py:182-194, assert :270).
+//
+// On MI355X every dependent launch costs >= ~4 us whatever it computes (dispatch, first dependent loads from another XCD's
+// write-back, end-of-kernel release), and an in-kernel grid barrier costs the same (MI355X_MICROARCH.md, barrier-xcd 4.1 us), so
+// the lever at one image is the NUMBER OF DEPENDENT PHASES, not their size.  The nine launches of the batched form
+//     colsum_partial, colsum_finish_split, gemm_nt, kbar_finish_split, gemm_nn, w_finish, score, topk_select, gather_rows
+// become five by letting every workgroup of a consumer rebuild, redundantly and from L2, the tiny reduction its producer left
+// open (for a handful of segments that is a few KB per workgroup):
+//     colsum_partial | proj_nt_small (xbar slice in the prologue) | proj_nn_small (kbar slice + c partials in the prologue)
+//                    | score_small (w, c in the prologue)         | select_gather_small (radix select per workgroup, then its rows)
+// The arithmetic is the batched form's, operation for operation: same 128-row sweep-1 chunks, same bf16x3 planes, same MFMA
+// sequence per (tile, 256 / 128-wide k-slice), same slab order, same integer select -- scores, indices and rows are bit-identical
+// to the nine-launch path (tests/test_lis_gpu.py::test_small_batch_path_is_bit_identical).
+#pragma once
+#include "lis_kernels.h"
+
+namespace vsel {
+
+constexpr int kSmallMaxSeg = 8;            // rows of the M dimension a workgroup rebuilds in its prologue
+constexpr int kSmallSelectThreads = 256;
+
+// -------------------------------------------------------------------------------------------------------------------------
+// P1  part1[ks][m][n] = sum_{k in slice ks} xbar[m][k] Wk[n][k]      (bf16x3 planes of xbar built in the prologue)
+//     grid (ceil(N / 64), KS), one wave.  partial: sweep-1 partials [S][row_splits][K] (or the producer's column sums, row_splits 1)
+// -------------------------------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(64) void proj_nt_small_kernel(const float* __restrict__ partial, SegView sv, int S, int row_splits,
+                                                                  const uint16_t* __restrict__ w, int N, int K, int kslice,
+                                                                  float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) uint16_t xs[3][kSmallMaxSeg][kSliceNT];
+  const int lane = threadIdx.x;
+  const int i = lane & 31, kg = lane >> 5;
+  const int n0 = blockIdx.x * 64;
+  const int row0 = min(n0 + i, N - 1), row1 = min(n0 + 32 + i, N - 1);
+  const int ks = blockIdx.y;
+  const int k_begin = ks * kslice;
+  const int k_end = min(K, k_begin + kslice);
+  const uint16_t* wp0 = w + (int64_t)row0 * K + 8 * kg;
+  const uint16_t* wp1 = w + (int64_t)row1 * K + 8 * kg;
+  constexpr int KB = kSliceNT / 16;      // the whole 256-wide slice: one wave per SIMD at these batch sizes, registers are free
+  // the weights do not depend on the prologue: put the loads of the whole slice in flight first (one round trip, overlapped
+  // with the partial-sum loads below)
+  u32x4 a0[KB], a1[KB];
+  const bool full = k_begin + 16 * KB <= k_end;
+  if (full) {
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      a0[u] = *reinterpret_cast<const u32x4*>(wp0 + k_begin + 16 * u);
+      a1[u] = *reinterpret_cast<const u32x4*>(wp1 + k_begin + 16 * u);
+    }
+  }
+  // prologue: xbar[m][k] = (sum_rs partial[m][rs][k]) / N_m for the slice, in rs order (= colsum_finish_split_kernel), split in 3.
+  // Lane owns 4 consecutive k (one 16-byte load per partial); up to 24 partials per batch are in flight together.
+  const int kq = k_begin + 4 * lane;
+  const bool kq_ok = kq < k_end;                     // K % 16 == 0: a 4-group is inside the slice or outside it
+  for (int m = 0; m < S; ++m) {
+    const float nf = (float)sv.n_rows(m);
+    const float* p = partial + (int64_t)m * row_splits * K + kq;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < row_splits; r0 += 24) {
+      f32x4 v[24];
+#pragma unroll
+      for (int q = 0; q < 24; ++q) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        v[q] = (kq_ok && r0 + q < row_splits) ? *reinterpret_cast<const f32x4*>(p + (int64_t)(r0 + q) * K) : z;
+      }
+#pragma unroll
+      for (int q = 0; q < 24; ++q)
+        if (r0 + q < row_splits) acc += v[q];
+    }
+    uint32_t b[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      b[0][e] = b[1][e] = b[2][e] = 0u;
+      if (kq_ok) split3(acc[e] / nf, b[0][e], b[1][e], b[2][e]);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      uint2 pk;
+      pk.x = b[pl][0] | (b[pl][1] << 16);
+      pk.y = b[pl][2] | (b[pl][3] << 16);
+      *reinterpret_cast<uint2*>(&xs[pl][m][4 * lane]) = pk;
+    }
+  }
+  __syncthreads();
+  const bool act = i < S;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  auto ldb = [&](int p, int koff) -> u32x4 {          // B fragment: lane (i, kg) holds xbar[i][koff + 8 kg .. + 7]
+    return act ? *reinterpret_cast<const u32x4*>(&xs[p][i][koff + 8 * kg]) : zero;
+  };
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  int k0 = k_begin;
+  if (full) {
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      const int ko = 16 * u;
+      const u32x4 b1 = ldb(0, ko), b2 = ldb(1, ko), b3 = ldb(2, ko);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0[u]), as_bf16x8(b3), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[u]), as_bf16x8(b3), acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0[u]), as_bf16x8(b2), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[u]), as_bf16x8(b2), acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0[u]), as_bf16x8(b1), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[u]), as_bf16x8(b1), acc1, 0, 0, 0);
+    }
+    k0 = k_end;
+  }
+  for (; k0 < k_end; k0 += 16) {
+    const u32x4 x0 = *reinterpret_cast<const u32x4*>(wp0 + k0);
+    const u32x4 x1 = *reinterpret_cast<const u32x4*>(wp1 + k0);
+    const int ko = k0 - k_begin;
+    const u32x4 b1 = ldb(0, ko), b2 = ldb(1, ko), b3 = ldb(2, ko);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(x0), as_bf16x8(b3), acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(x1), as_bf16x8(b3), acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(x0), as_bf16x8(b2), acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(x1), as_bf16x8(b2), acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(x0), as_bf16x8(b1), acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(x1), as_bf16x8(b1), acc1, 0, 0, 0);
+  }
+  // C[row = n][col = m]; compact slab [ks][m][n] (only the S live columns are stored)
+  if (act) {
+    float* dst = part + ((int64_t)ks * S + i) * N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
+      if (n0 + row < N) dst[n0 + row] = acc0[r];
+      if (n0 + 32 + row < N) dst[n0 + 32 + row] = acc1[r];
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
+// P2  part2[ks][m][n] = sum_{h in slice ks} kbar[m][h] Wq[h][n],  kbar[m][h] = sum_ks1 part1[ks1][m][h] + bk[h] (prologue);
+//     workgroups of n-tile 0 also leave cpart[m][h / 8] = sum_{8 h} bq[h] kbar[m][h].  grid (ceil(N / 256), KS2), one wave.
+// -------------------------------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(64) void proj_nn_small_kernel(const float* __restrict__ part1, int KS1, int S,
+                                                                  const uint16_t* __restrict__ bk, const uint16_t* __restrict__ bq,
+                                                                  const uint16_t* __restrict__ w, int N, int K, int kslice,
+                                                                  float* __restrict__ part2, float* __restrict__ cpart, int n_cpart) {
+  __shared__ __attribute__((aligned(16))) uint16_t ksl[3][kSmallMaxSeg][kSliceNN];
+  __shared__ float ct[kSmallMaxSeg][kSliceNN];
+  const int lane = threadIdx.x;
+  const int i = lane & 31, kg = lane >> 5;
+  const int nb = min(blockIdx.x * 256 + 8 * i, N - 8);
+  const int ks = blockIdx.y;
+  const int k_begin = ks * kslice;
+  const int k_end = min(K, k_begin + kslice);
+  const uint16_t* wp = w + (int64_t)(8 * kg) * N + nb;
+  constexpr int KB = 4;
+  u32x4 wv[KB][8];
+  const bool first_full = k_begin + 16 * KB <= k_end;
+  if (first_full) {
+#pragma unroll
+    for (int u = 0; u < KB; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wv[u][e] = *reinterpret_cast<const u32x4*>(wp + (int64_t)(k_begin + 16 * u + e) * N);
+  }
+  // prologue: kbar slice (= kbar_finish_split_kernel: slabs in ks1 order, then + bk), split in 3; c terms
+  static_assert(kSliceNN == 128, "lane owns 2 consecutive h of the 128-wide slice");
+  const int hq = k_begin + 2 * lane;
+  const bool hq_ok = hq < k_end;                     // K % 16 == 0
+  const float bk0 = hq_ok ? bf16_to_f32(bk[hq]) : 0.f, bk1 = hq_ok ? bf16_to_f32(bk[hq + 1]) : 0.f;
+  const float bq0 = hq_ok ? bf16_to_f32(bq[hq]) : 0.f, bq1 = hq_ok ? bf16_to_f32(bq[hq + 1]) : 0.f;
+  for (int m = 0; m < S; ++m) {
+    float2 v = make_float2(0.f, 0.f);
+    const float* p1 = part1 + (int64_t)m * K + hq;
+    const int64_t stride = (int64_t)S * K;
+    for (int s0 = 0; s0 < KS1; s0 += 16) {             // all slab loads of a batch in flight, added in ks1 order
+      float2 t[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        t[q] = (hq_ok && s0 + q < KS1) ? *reinterpret_cast<const float2*>(p1 + (s0 + q) * stride) : make_float2(0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (s0 + q < KS1) { v.x += t[q].x; v.y += t[q].y; }
+    }
+    uint32_t b[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
+    float c0 = 0.f, c1 = 0.f;
+    if (hq_ok) {
+      const float k0v = v.x + bk0, k1v = v.y + bk1;
+      split3(k0v, b[0][0], b[1][0], b[2][0]);
+      split3(k1v, b[0][1], b[1][1], b[2][1]);
+      c0 = bq0 * k0v;
+      c1 = bq1 * k1v;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint32_t*>(&ksl[pl][m][2 * lane]) = b[pl][0] | (b[pl][1] << 16);
+    *reinterpret_cast<float2*>(&ct[m][2 * lane]) = make_float2(c0, c1);
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    // cpart[m][by] = sum of the block's 8 consecutive h in order (kbar_finish_split_kernel's LDS reduction)
+    const int blocks = (k_end - k_begin + 7) / 8;
+    for (int e = lane; e < S * blocks; e += 64) {
+      const int m = e / blocks, q = e % blocks;
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t += ct[m][8 * q + j];
+      cpart[(int64_t)m * n_cpart + (k_begin >> 3) + q] = t;
+    }
+  }
+  const bool act = i < S;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  auto ldb = [&](int p, int koff) -> u32x4 {
+    return act ? *reinterpret_cast<const u32x4*>(&ksl[p][i][koff + 8 * kg]) : zero;
+  };
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  auto step = [&](const u32x4 (&x)[8], u32x4 b1, u32x4 b2, u32x4 b3) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const uint32_t sel = (t & 1) ? 0x07060302u : 0x05040100u;
+      u32x4 a;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] = __builtin_amdgcn_perm(x[2 * q + 1][t >> 1], x[2 * q][t >> 1], sel);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b3), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b2), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b1), acc[t], 0, 0, 0);
+    }
+  };
+  int k0 = k_begin;
+  for (; k0 + 16 * KB <= k_end; k0 += 16 * KB) {
+    if (k0 != k_begin || !first_full) {
+#pragma unroll
+      for (int u = 0; u < KB; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[u][e] = *reinterpret_cast<const u32x4*>(wp + (int64_t)(k0 + 16 * u + e) * N);
+    }
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      const int ko = k0 - k_begin + 16 * u;
+      step(wv[u], ldb(0, ko), ldb(1, ko), ldb(2, ko));
+    }
+  }
+  for (; k0 < k_end; k0 += 16) {
+    u32x4 x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = *reinterpret_cast<const u32x4*>(wp + (int64_t)(k0 + e) * N);
+    const int ko = k0 - k_begin;
+    step(x, ldb(0, ko), ldb(1, ko), ldb(2, ko));
+  }
+  // acc[t][r] = C[n = n0 + 8 irow + t][m = lane & 31]; compact slab [ks][m][n]: 8 consecutive n per (lane, r)
+  if (act) {
+    float* dst = part2 + ((int64_t)ks * S + i) * N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int irow = (r & 3) + 8 * (r >> 2) + 4 * kg;
+      const int n = blockIdx.x * 256 + 8 * irow;
+      if (n < N) {
+        const f32x4 lo = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        const f32x4 hi = {acc[4][r], acc[5][r], acc[6][r], acc[7][r]};
+        *reinterpret_cast<f32x4*>(dst + n) = lo;
+        *reinterpret_cast<f32x4*>(dst + n + 4) = hi;
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
+// P3  sweep 2 with w[s] = sum_ks part2[ks][s][:] (ks order = w_finish_kernel) and c[s] rebuilt in LDS by every workgroup.
+//     grid (row_chunks, S), block 256.  Dynamic LDS: d floats.
+// -------------------------------------------------------------------------------------------------------------------------
+template <typename T, int ITERS>
+__global__ __launch_bounds__(256) void score_small_kernel(const T* __restrict__ h, SegView sv, int d, int S,
+                                                          const float* __restrict__ part2, int KS2,
+                                                          const float* __restrict__ cpart, int n_cpart, float sqrt_hd,
+                                                          int rows_per_block, float* __restrict__ scores,
+                                                          const int64_t* __restrict__ out_map) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];      // [d] then 9 floats for c
+  float* cred = wl + d;
+  const int s = blockIdx.y;
+  const int n = sv.n_rows(s);
+  const int rb = blockIdx.x * rows_per_block;
+  if (rb >= n) return;
+  const int tid = threadIdx.x;
+  // c[s]: w_finish_kernel's order -- 8 strided partial sums (nj, nj + 8, ...) then those 8 in order
+  if (tid < 8) cred[tid] = tid < n_cpart ? strided_sum(cpart + (int64_t)s * n_cpart + tid, (n_cpart - tid + 7) / 8, 8) : 0.f;
+  const float* src = part2 + (int64_t)s * d;
+  const int64_t slab = (int64_t)S * d;
+  // two 4-column groups per thread and batch, all their slab loads in flight together (KS2 <= 16 per batch)
+  for (int c4 = tid; c4 < d / 4; c4 += 512) {
+    const int c4b = c4 + 256;
+    const bool has_b = c4b < d / 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < KS2; k0 += 16) {
+      f32x4 va[16], vb[16];
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        va[u] = k0 + u < KS2 ? *reinterpret_cast<const f32x4*>(src + (k0 + u) * slab + 4 * c4) : z;
+        vb[u] = (has_b && k0 + u < KS2) ? *reinterpret_cast<const f32x4*>(src + (k0 + u) * slab + 4 * c4b) : z;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (k0 + u < KS2) { a += va[u]; b += vb[u]; }
+    }
+    *reinterpret_cast<f32x4*>(wl + 4 * c4) = a;
+    if (has_b) *reinterpret_cast<f32x4*>(wl + 4 * c4b) = b;
+  }
+  for (int c = (d / 4) * 4 + tid; c < d; c += 256) {   // d % 4 != 0 cannot happen (D % 8 == 0 is checked), kept for safety
+    float a = 0.f;
+    for (int ks = 0; ks < KS2; ++ks) a += src[ks * slab + c];
+    wl[c] = a;
+  }
+  __syncthreads();
+  float cs = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs += cred[j];
+  score_rows<T, ITERS, false>(h, d, wl, cs, sqrt_hd, sv.row_begin(s), rb, min(n, rb + rows_per_block), scores, out_map);
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
+// P4  hard top-k + gather in one launch: every workgroup runs the segment's radix select itself, keeps the source rows of ITS
+//     output rows and copies them; workgroup 0 of a segment writes idx.  Keys live in registers (KPT per thread, N <= 256 KPT);
+//     wave w owns the CONTIGUOUS elements [w * span, (w + 1) * span), so the ordered compaction needs one exchange of wave
+//     totals instead of two barriers per 256 elements; the four histograms are separate LDS arrays zeroed once and every wave
+//     scans them itself: 7 barriers per workgroup in all.  Integer arithmetic only -> the same indices as topk_select_kernel
+//     (larger key first, then lower index).  grid (ceil(k / rows_per_block), S), block 256.
+// -------------------------------------------------------------------------------------------------------------------------
+template <typename T, int KPT>
+__global__ __launch_bounds__(256) void select_gather_small_kernel(const T* __restrict__ h, const float* __restrict__ scores,
+                                                                  SegView sv, int d, int64_t* __restrict__ idx,
+                                                                  T* __restrict__ out, int rows_per_block,
+                                                                  const int64_t* __restrict__ src_map) {
+  constexpr int V = Elem<T>::kVec;
+  constexpr int NW = kSmallSelectThreads / 64;
+  const int s = blockIdx.y;
+  const int n = sv.n_rows(s);
+  const int ko = min(sv.n_out(s), n);
+  const int jb = blockIdx.x * rows_per_block;
+  if (jb >= ko) return;
+  const int je = min(ko, jb + rows_per_block);
+  const int64_t rb = sv.row_begin(s), ob = sv.out_begin(s);
+  const float* sc = scores + rb;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  __shared__ uint32_t hist[4][256];
+  __shared__ uint32_t wtot[NW][2];
+  __shared__ int rows[64];
+
+  const int kpw = (n + kSmallSelectThreads - 1) / kSmallSelectThreads;     // 64-element groups per wave (<= KPT)
+  const int e0 = wave * kpw * 64 + lane;
+  uint32_t key[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const int e = e0 + 64 * j;
+    key[j] = (j < kpw && e < n) ? order_key(sc[e]) : 0u;
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) hist[p][tid] = 0;
+  __syncthreads();
+  uint32_t prefix = 0, maskbits = 0, kk = (uint32_t)ko;
+#pragma unroll
+  for (int pass = 3; pass >= 0; --pass) {
+    const int shift = 8 * pass;
+    uint32_t* hp = hist[pass];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j)
+      if (j < kpw && e0 + 64 * j < n && (key[j] & maskbits) == prefix) atomicAdd(&hp[(key[j] >> shift) & 255u], 1u);
+    __syncthreads();
+    // every wave finds the bin where the count from the top reaches kk (lane owns bins 4 lane .. 4 lane + 3)
+    const uint32_t c0 = hp[4 * lane], c1 = hp[4 * lane + 1], c2 = hp[4 * lane + 2], c3 = hp[4 * lane + 3];
+    const uint32_t tot = c0 + c1 + c2 + c3;
+    uint32_t suf = tot;                       // inclusive suffix sum over lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_down(suf, off, 64);
+      if (lane + off < 64) suf += o;
+    }
+    uint32_t run = suf - tot;
+    const uint32_t cs[4] = {c3, c2, c1, c0};
+    uint32_t found = 0xffffffffu;             // (bin << 16 is too small for kk) -> two words
+    uint32_t found_kk = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (run < kk && run + cs[b] >= kk) {
+        found = 4 * lane + (3 - b);
+        found_kk = kk - run;
+      }
+      run += cs[b];
+    }
+    const unsigned long long who = __ballot(found != 0xffffffffu);      // exactly one lane
+    const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)who) - 1);
+    const uint32_t bin = (uint32_t)__builtin_amdgcn_readlane((int)found, src);
+    kk = (uint32_t)__builtin_amdgcn_readlane((int)found_kk, src);
+    prefix |= bin << shift;
+    maskbits |= 0xffu << shift;
+  }
+  const uint32_t thr = prefix, need = kk;
+  // ordered compaction: wave-local counts first, one exchange of the wave totals, then positions
+  uint32_t my_gt = 0, my_eq = 0;
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const bool valid = j < kpw && e0 + 64 * j < n;
+    my_gt += __popcll(__ballot(valid && key[j] > thr));
+    my_eq += __popcll(__ballot(valid && key[j] == thr));
+  }
+  if (lane == 0) { wtot[wave][0] = my_gt; wtot[wave][1] = my_eq; }
+  __syncthreads();
+  uint32_t run_gt = 0, run_eq = 0;
+#pragma unroll
+  for (int wv = 0; wv < NW; ++wv)
+    if (wv < wave) { run_gt += wtot[wv][0]; run_eq += wtot[wv][1]; }
+  const bool writer = blockIdx.x == 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    if (j >= kpw) break;                      // uniform
+    const int e = e0 + 64 * j;
+    const bool valid = e < n;
+    const bool gt = valid && key[j] > thr;
+    const bool eq = valid && key[j] == thr;
+    const unsigned long long bgt = __ballot(gt), beq = __ballot(eq);
+    const uint32_t gt_before = run_gt + __popcll(bgt & below), eq_before = run_eq + __popcll(beq & below);
+    if (gt || (eq && eq_before < need)) {
+      const int pos = (int)(gt_before + min(eq_before, need));
+      if (writer) idx[ob + pos] = (int64_t)e;
+      if (pos >= jb && pos < je) rows[pos - jb] = e;
+    }
+    run_gt += __popcll(bgt);
+    run_eq += __popcll(beq);
+  }
+  __syncthreads();
+  for (int j = jb + wave; j < je; j += NW) {
+    const int64_t lsrc = rb + rows[j - jb];
+    const int64_t src = src_map ? src_map[lsrc] : lsrc;
+    const u32x4* sp = reinterpret_cast<const u32x4*>(h + src * d);
+    u32x4* dp = reinterpret_cast<u32x4*>(out + (ob + j) * d);
+    for (int v = lane; v < d / V; v += 64) dp[v] = sp[v];
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------------------------------
+inline bool small_path_ok(const vsel_segments* seg, const vsel_scorer* sc, const LisPlan& p) {
+  return seg->n_seg <= kSmallMaxSeg && sc->wdtype == VSEL_BF16 && p.mfma_bf16 && p.kslice1 <= kSliceNT && p.kslice2 <= kSliceNN &&
+         sc->d % 8 == 0 && sc->hd % 8 == 0;
+}
+
+// sweep 1 partials (or the producer's column sums) -> part2 slabs + c partials: two launches
+inline int run_proj_small(hipStream_t st, const vsel_segments* seg, const vsel_scorer* sc, char* ws, const LisPlan& p,
+                          const float* col_sums) {
+  const int d = (int)sc->d, hd = (int)sc->hd, S = (int)seg->n_seg;
+  const float* partial = col_sums ? col_sums : (const float*)(ws + p.off_partial);
+  const int row_splits = col_sums ? 1 : p.row_splits;
+  float* part1 = (float*)(ws + p.off_part1);
+  float* part2 = (float*)(ws + p.off_part2);
+  float* cpart = (float*)(ws + p.off_cpart);
+  hipLaunchKernelGGL(proj_nt_small_kernel, dim3((unsigned)cdiv(hd, 64), p.ks1), dim3(64), 0, st, partial, make_view(seg), S,
+                     row_splits, (const uint16_t*)sc->wk, hd, d, p.kslice1, part1);
+  VSEL_AFTER_LAUNCH(st, "proj_nt_small_kernel");
+  hipLaunchKernelGGL(proj_nn_small_kernel, dim3((unsigned)cdiv(d, 256), p.ks2), dim3(64), 0, st, part1, p.ks1, S,
+                     (const uint16_t*)sc->bk, (const uint16_t*)sc->bq, (const uint16_t*)sc->wq, d, hd, p.kslice2, part2, cpart,
+                     p.n_cpart);
+  VSEL_AFTER_LAUNCH(st, "proj_nn_small_kernel");
+  return VSEL_OK;
+}
+
+template <typename T>
+inline int run_score_small(hipStream_t st, const T* h, const vsel_segments* seg, const vsel_scorer* sc, char* ws, const LisPlan& p,
+                           float* scores, const int64_t* out_map) {
+  constexpr int V = Elem<T>::kVec;
+  const int d = (int)sc->d, S = (int)seg->n_seg;
+  // every workgroup re-reads KS2 x d x 4 bytes of slabs from L2: keep the grid near one workgroup per CU
+  int64_t rpb = 64;
+  while (rpb > 8 && seg->n_seg * cdiv(seg->rows_per_seg, rpb) < 128) rpb >>= 1;
+  const dim3 grid((unsigned)cdiv(seg->rows_per_seg, rpb), (unsigned)S);
+  const float sq = (float)sqrt((double)sc->hd);
+  const size_t lds = ((size_t)d + 16) * sizeof(float);
+  const float* part2 = (const float*)(ws + p.off_part2);
+  const float* cpart = (const float*)(ws + p.off_cpart);
+  const int iters = (d % (64 * V) == 0) ? d / (64 * V) : 0;
+#define VSEL_SCORE_SMALL_CASE(I)                                                                                          \
+  case I:                                                                                                                 \
+    hipLaunchKernelGGL((score_small_kernel<T, I>), grid, dim3(256), lds, st, h, make_view(seg), d, S, part2, p.ks2, cpart, \
+                       p.n_cpart, sq, (int)rpb, scores, out_map);                                                         \
+    break;
+  switch (iters) {
+    VSEL_SCORE_SMALL_CASE(1) VSEL_SCORE_SMALL_CASE(2) VSEL_SCORE_SMALL_CASE(3) VSEL_SCORE_SMALL_CASE(4)
+    VSEL_SCORE_SMALL_CASE(5) VSEL_SCORE_SMALL_CASE(6) VSEL_SCORE_SMALL_CASE(7) VSEL_SCORE_SMALL_CASE(8)
+    default:
+      hipLaunchKernelGGL((score_small_kernel<T, 0>), grid, dim3(256), lds, st, h, make_view(seg), d, S, part2, p.ks2, cpart,
+                         p.n_cpart, sq, (int)rpb, scores, out_map);
+  }
+#undef VSEL_SCORE_SMALL_CASE
+  VSEL_AFTER_LAUNCH(st, "score_small_kernel");
+  return VSEL_OK;
+}
+
+template <typename T>
+inline int launch_select_gather_small(hipStream_t st, const T* h, int d, const vsel_segments* seg, const float* scores,
+                                      int64_t* idx, T* out, const int64_t* src_map) {
+  const int64_t maxn = seg->rows_per_seg;
+  if (maxn > 32 * kSmallSelectThreads) {          // keys do not fit the register file: the two-launch form
+    int rc = launch_select(st, scores, seg, idx, nullptr);
+    if (rc) return rc;
+    return launch_gather<T>(st, h, d, seg, idx, out, src_map);
+  }
+  int64_t rpb = 16;
+  while (rpb > 4 && seg->n_seg * cdiv(seg->k, rpb) < 128) rpb >>= 1;
+  const dim3 grid((unsigned)cdiv(seg->k, rpb), (unsigned)seg->n_seg);
+  const SegView sv = make_view(seg);
+  if (maxn <= 12 * kSmallSelectThreads)
+    hipLaunchKernelGGL((select_gather_small_kernel<T, 12>), grid, dim3(256), 0, st, h, scores, sv, d, idx, out, (int)rpb, src_map);
+  else
+    hipLaunchKernelGGL((select_gather_small_kernel<T, 32>), grid, dim3(256), 0, st, h, scores, sv, d, idx, out, (int)rpb, src_map);
+  VSEL_AFTER_LAUNCH(st, "select_gather_small_kernel");
+  return VSEL_OK;
+}
+
+}  // namespace vsel

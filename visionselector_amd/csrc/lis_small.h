@@ -14,6 +14,7 @@
 // to the nine-launch path (tests/test_lis_gpu.py::test_small_batch_path_is_bit_identical).
 #pragma once
 #include "lis_kernels.h"
+#include <stdlib.h>
 
 namespace vsel {
 
@@ -55,15 +56,14 @@ static __global__ __launch_bounds__(64) void proj_nt_small_kernel(const float* _
   const bool kq_ok = kq < k_end;                     // K % 16 == 0: a 4-group is inside the slice or outside it
   for (int m = 0; m < S; ++m) {
     const float nf = (float)sv.n_rows(m);
-    const float* p = partial + (int64_t)m * row_splits * K + kq;
+    const float* pc = partial + (int64_t)m * row_splits * K + (kq_ok ? kq : k_begin);     // lanes past the slice read a valid dummy
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int r0 = 0; r0 < row_splits; r0 += 24) {
       f32x4 v[24];
 #pragma unroll
-      for (int q = 0; q < 24; ++q) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        v[q] = (kq_ok && r0 + q < row_splits) ? *reinterpret_cast<const f32x4*>(p + (int64_t)(r0 + q) * K) : z;
-      }
+      for (int q = 0; q < 24; ++q)       // UNCONDITIONAL loads (clamped index): a per-element "load or zero" on a runtime bound makes
+                                         // hipcc branch around every load and wait for each one (cdna_hip_programming.md, trap (c))
+        v[q] = *reinterpret_cast<const f32x4*>(pc + (int64_t)min(r0 + q, row_splits - 1) * K);
 #pragma unroll
       for (int q = 0; q < 24; ++q)
         if (r0 + q < row_splits) acc += v[q];
@@ -164,13 +164,12 @@ static __global__ __launch_bounds__(64) void proj_nn_small_kernel(const float* _
   const float bq0 = hq_ok ? bf16_to_f32(bq[hq]) : 0.f, bq1 = hq_ok ? bf16_to_f32(bq[hq + 1]) : 0.f;
   for (int m = 0; m < S; ++m) {
     float2 v = make_float2(0.f, 0.f);
-    const float* p1 = part1 + (int64_t)m * K + hq;
+    const float* p1 = part1 + (int64_t)m * K + (hq_ok ? hq : k_begin);
     const int64_t stride = (int64_t)S * K;
-    for (int s0 = 0; s0 < KS1; s0 += 16) {             // all slab loads of a batch in flight, added in ks1 order
+    for (int s0 = 0; s0 < KS1; s0 += 16) {             // all slab loads of a batch in flight (unconditional, clamped), added in ks1 order
       float2 t[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
-        t[q] = (hq_ok && s0 + q < KS1) ? *reinterpret_cast<const float2*>(p1 + (s0 + q) * stride) : make_float2(0.f, 0.f);
+      for (int q = 0; q < 16; ++q) t[q] = *reinterpret_cast<const float2*>(p1 + min(s0 + q, KS1 - 1) * stride);
 #pragma unroll
       for (int q = 0; q < 16; ++q)
         if (s0 + q < KS1) { v.x += t[q].x; v.y += t[q].y; }
@@ -277,8 +276,10 @@ __global__ __launch_bounds__(256) void score_small_kernel(const T* __restrict__ 
   const int rb = blockIdx.x * rows_per_block;
   if (rb >= n) return;
   const int tid = threadIdx.x;
-  // c[s]: w_finish_kernel's order -- 8 strided partial sums (nj, nj + 8, ...) then those 8 in order
-  if (tid < 8) cred[tid] = tid < n_cpart ? strided_sum(cpart + (int64_t)s * n_cpart + tid, (n_cpart - tid + 7) / 8, 8) : 0.f;
+  // c[s]: w_finish_kernel's order -- 8 strided partial sums (nj, nj + 8, ...) then those 8 in order.  The c partials are
+  // staged through LDS with ONE load per thread (a chain of dependent 8-load batches by 8 threads was the kernel's long pole).
+  float* cstage = cred + 16;
+  for (int e = tid; e < n_cpart; e += 256) cstage[e] = cpart[(int64_t)s * n_cpart + e];
   const float* src = part2 + (int64_t)s * d;
   const int64_t slab = (int64_t)S * d;
   // two 4-column groups per thread and batch, all their slab loads in flight together (KS2 <= 16 per batch)
@@ -288,11 +289,12 @@ __global__ __launch_bounds__(256) void score_small_kernel(const T* __restrict__ 
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < KS2; k0 += 16) {
       f32x4 va[16], vb[16];
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const int c4bc = has_b ? c4b : c4;             // unconditional loads (clamped): see proj_nt_small_kernel
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
-        va[u] = k0 + u < KS2 ? *reinterpret_cast<const f32x4*>(src + (k0 + u) * slab + 4 * c4) : z;
-        vb[u] = (has_b && k0 + u < KS2) ? *reinterpret_cast<const f32x4*>(src + (k0 + u) * slab + 4 * c4b) : z;
+        const int64_t ku = min(k0 + u, KS2 - 1);
+        va[u] = *reinterpret_cast<const f32x4*>(src + ku * slab + 4 * c4);
+        vb[u] = *reinterpret_cast<const f32x4*>(src + ku * slab + 4 * c4bc);
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u)
@@ -305,6 +307,12 @@ __global__ __launch_bounds__(256) void score_small_kernel(const T* __restrict__ 
     float a = 0.f;
     for (int ks = 0; ks < KS2; ++ks) a += src[ks * slab + c];
     wl[c] = a;
+  }
+  __syncthreads();
+  if (tid < 8) {
+    float a = 0.f;
+    for (int e = tid; e < n_cpart; e += 8) a += cstage[e];
+    cred[tid] = a;
   }
   __syncthreads();
   float cs = 0.f;
@@ -468,10 +476,11 @@ inline int run_score_small(hipStream_t st, const T* h, const vsel_segments* seg,
   const int d = (int)sc->d, S = (int)seg->n_seg;
   // every workgroup re-reads KS2 x d x 4 bytes of slabs from L2: keep the grid near one workgroup per CU
   int64_t rpb = 64;
-  while (rpb > 8 && seg->n_seg * cdiv(seg->rows_per_seg, rpb) < 128) rpb >>= 1;
+  while (rpb > 8 && seg->n_seg * cdiv(seg->rows_per_seg, rpb) < 128) rpb >>= 1;    // 72 / 144 / 288 / 576 workgroups at one
+                                                                                   // image: 13.3 / 11.7 / 11.8 / 17.7 us
   const dim3 grid((unsigned)cdiv(seg->rows_per_seg, rpb), (unsigned)S);
   const float sq = (float)sqrt((double)sc->hd);
-  const size_t lds = ((size_t)d + 16) * sizeof(float);
+  const size_t lds = ((size_t)d + 16 + p.n_cpart) * sizeof(float);
   const float* part2 = (const float*)(ws + p.off_part2);
   const float* cpart = (const float*)(ws + p.off_cpart);
   const int iters = (d % (64 * V) == 0) ? d / (64 * V) : 0;
@@ -502,7 +511,8 @@ inline int launch_select_gather_small(hipStream_t st, const T* h, int d, const v
     return launch_gather<T>(st, h, d, seg, idx, out, src_map);
   }
   int64_t rpb = 16;
-  while (rpb > 4 && seg->n_seg * cdiv(seg->k, rpb) < 128) rpb >>= 1;
+  while (rpb > 2 && seg->n_seg * cdiv(seg->k, rpb) < 128) rpb >>= 1;              // 58 / 115 / 230 / 460 workgroups at one image:
+                                                                                   // 14.7 / 12.1 / 12.1 / 13.7 us
   const dim3 grid((unsigned)cdiv(seg->k, rpb), (unsigned)seg->n_seg);
   const SegView sv = make_view(seg);
   if (maxn <= 12 * kSmallSelectThreads)

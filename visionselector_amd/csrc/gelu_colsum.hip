@@ -14,10 +14,19 @@ namespace vsel {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-constexpr int kGeluRows = 128;     // rows per workgroup (32-row chunks measured 2.3x slower at 147 k rows: tools/exp_merger_fusion.py)
+// Rows per workgroup: 128 when that already gives several rounds of workgroups, halved (down to 16) otherwise -- a 128-row
+// workgroup runs ~100 us of erf, so at 36 k rows (2880 workgroups on 2048 slots) the tail round cost 15-30 % (207 vs 159 us for
+// torch's GELU).  The column sums are a fixed function of (rows per segment, columns), not bit-identical across batch shapes; the
+// bit-exact path is the two-sweep one.
+constexpr int kGeluRowsMax = 128;
+inline int gelu_rows_per_wg(const vsel_segments* seg, int64_t cols, int vec) {
+  int rows = kGeluRowsMax;
+  while (rows > 16 && seg->n_seg * cdiv(seg->rows_per_seg, rows) * cdiv(cols, 64 * vec) < 6144) rows >>= 1;
+  return rows;
+}
 
 template <typename T>
-__global__ __launch_bounds__(256) void gelu_colsum_kernel(const T* __restrict__ x, SegView sv, int c, int row_splits,
+__global__ __launch_bounds__(256) void gelu_colsum_kernel(const T* __restrict__ x, SegView sv, int c, int row_splits, int rows_per_wg,
                                                           T* __restrict__ y, float* __restrict__ partial) {
   constexpr int V = Elem<T>::kVec;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -25,15 +34,11 @@ __global__ __launch_bounds__(256) void gelu_colsum_kernel(const T* __restrict__ 
   const int col = (blockIdx.x * 64 + lane) * V;
   const int n = sv.n_rows(s);
   const int64_t r0 = sv.row_begin(s);
-  const int rb = rs * kGeluRows;
-  const int re = min(n, rb + kGeluRows);
+  const int rb = rs * rows_per_wg;
+  const int re = min(n, rb + rows_per_wg);
   float acc[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) acc[i] = 0.f;
-  auto rounded = [](float v) -> float {
-    if constexpr (sizeof(T) == 2) return bf16_to_f32(f32_to_bf16_bits(v));
-    else return v;
-  };
   if (col < c) {
     const int64_t base = r0 * (int64_t)c + col;
     int r = rb + wave;
@@ -45,9 +50,22 @@ __global__ __launch_bounds__(256) void gelu_colsum_kernel(const T* __restrict__ 
       if (r + 8 < re) load_vec(x + base + (int64_t)(r + 8) * c, nx2);
 #pragma unroll
       for (int i = 0; i < V; ++i) cur[i] = gelu_erf(cur[i]);
-      store_vec(y + base + (int64_t)r * c, cur);
+      if constexpr (sizeof(T) == 2) {
+        // round once: the stored bf16 bits are also what the column sums add up
+        uint32_t bits[V];
 #pragma unroll
-      for (int i = 0; i < V; ++i) acc[i] += rounded(cur[i]);
+        for (int i = 0; i < V; ++i) bits[i] = f32_to_bf16_bits(cur[i]);
+        u32x4 pk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk[i] = bits[2 * i] | (bits[2 * i + 1] << 16);
+        *reinterpret_cast<u32x4*>(y + base + (int64_t)r * c) = pk;
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] += __uint_as_float(bits[i] << 16);
+      } else {
+        store_vec(y + base + (int64_t)r * c, cur);
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] += cur[i];
+      }
 #pragma unroll
       for (int i = 0; i < V; ++i) { cur[i] = nx1[i]; nx1[i] = nx2[i]; }
     }
@@ -63,15 +81,36 @@ __global__ __launch_bounds__(256) void gelu_colsum_kernel(const T* __restrict__ 
   }
 }
 
-static __global__ __launch_bounds__(256) void gelu_colsum_finish_kernel(const float* __restrict__ partial, int c, int row_splits,
-                                                                        float* __restrict__ col_sums) {
+// col_sums[s][col] = sum_rs partial[s][rs][col] in a FIXED two-level order: 16 interleaved groups (rs = g, g + 16, ...) summed in
+// rs order, then the 16 group sums in g order.  grid (ceil(c / 64), S), block 1024 = 64 columns x 16 groups.  (The first version --
+// one thread per column walking all row splits -- took 413 us at 147 k rows, 1152 splits: longer than half the GELU itself.)
+static __global__ __launch_bounds__(1024) void gelu_colsum_finish_kernel(const float* __restrict__ partial, int c, int row_splits,
+                                                                         float* __restrict__ col_sums) {
   const int s = blockIdx.y;
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= c) return;
-  const float* p = partial + (int64_t)s * row_splits * c + col;
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  __shared__ float red[16][64];
   float acc = 0.f;
-  for (int rs = 0; rs < row_splits; ++rs) acc += p[(int64_t)rs * c];
-  col_sums[(int64_t)s * c + col] = acc;
+  if (col < c) {
+    const float* p = partial + (int64_t)s * row_splits * c + col;
+    int rs = g;
+    for (; rs + 7 * 16 < row_splits; rs += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(rs + 16 * u) * c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; rs < row_splits; rs += 16) acc += p[(int64_t)rs * c];
+  }
+  red[g][lane] = acc;
+  __syncthreads();
+  if (g == 0 && col < c) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j][lane];
+    col_sums[(int64_t)s * c + col] = t;
+  }
 }
 
 }  // namespace vsel
@@ -80,7 +119,7 @@ using namespace vsel;
 
 extern "C" size_t vsel_gelu_colsum_workspace_bytes(const vsel_segments* seg, int64_t cols) {
   if (!seg || seg->n_seg < 1 || seg->rows_per_seg < 1 || cols < 1) return 0;
-  return (size_t)seg->n_seg * (size_t)cdiv(seg->rows_per_seg, kGeluRows) * (size_t)cols * sizeof(float);
+  return (size_t)seg->n_seg * (size_t)cdiv(seg->rows_per_seg, 16) * (size_t)cols * sizeof(float);     // smallest chunk
 }
 
 extern "C" int vsel_gelu_colsum(void* stream, const void* x, vsel_dtype dtype, const vsel_segments* seg, int64_t cols, void* y,
@@ -97,16 +136,17 @@ extern "C" int vsel_gelu_colsum(void* stream, const void* x, vsel_dtype dtype, c
   VSEL_PROF_BEGIN(st);
   const SegView sv = make_view(seg);
   const int S = (int)seg->n_seg;
-  const int row_splits = (int)cdiv(seg->rows_per_seg, kGeluRows);
+  const int rows_per_wg = gelu_rows_per_wg(seg, cols, vec);
+  const int row_splits = (int)cdiv(seg->rows_per_seg, rows_per_wg);
   float* partial = (float*)workspace;
   if (dtype == VSEL_BF16)
     hipLaunchKernelGGL((gelu_colsum_kernel<bf16_t>), dim3((unsigned)cdiv(cols, 64 * 8), row_splits, S), dim3(256), 0, st,
-                       (const bf16_t*)x, sv, (int)cols, row_splits, (bf16_t*)y, partial);
+                       (const bf16_t*)x, sv, (int)cols, row_splits, rows_per_wg, (bf16_t*)y, partial);
   else
     hipLaunchKernelGGL((gelu_colsum_kernel<float>), dim3((unsigned)cdiv(cols, 64 * 4), row_splits, S), dim3(256), 0, st,
-                       (const float*)x, sv, (int)cols, row_splits, (float*)y, partial);
+                       (const float*)x, sv, (int)cols, row_splits, rows_per_wg, (float*)y, partial);
   VSEL_AFTER_LAUNCH(st, "gelu_colsum_kernel");
-  hipLaunchKernelGGL(gelu_colsum_finish_kernel, dim3((unsigned)cdiv(cols, 256), S), dim3(256), 0, st, partial, (int)cols, row_splits,
+  hipLaunchKernelGGL(gelu_colsum_finish_kernel, dim3((unsigned)cdiv(cols, 64), S), dim3(1024), 0, st, partial, (int)cols, row_splits,
                      col_sums);
   VSEL_AFTER_LAUNCH(st, "gelu_colsum_finish_kernel");
   return VSEL_OK;

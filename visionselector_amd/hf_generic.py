@@ -14,6 +14,9 @@ from . import ops
 from .selector import lis_select_block, lis_train_block
 
 
+kFuseMinTokens = 65536      # merged visual tokens per call from which the merger-side column sums pay (see forward_eval)
+
+
 class _LazyRows(torch.Tensor):
     """Output of the merger during an inference tower forward.  The tower un-reorders its window-ordered tokens with
     `merged[reverse_indices, :]` (reference: EV/token_compression/selector_model.py:179-181; same line in transformers'
@@ -95,10 +98,15 @@ def make_vision_tower_forward_selector(base_forward: Callable, mode: str):
         fused_gelu, slot = None, None
         if merger is not None and not torch.is_grad_enabled() and getattr(self, "fuse_unreorder", True):
             handle = merger.register_forward_hook(lambda mod, inp, out: _LazyRows(out) if out.dim() == 2 else out)
-            # opt-in (visual.fuse_merger_colsum = True): measured on MI355X it does not pay -- the erf-bound fused GELU is
-            # 1.6-3x slower than torch's and the 73 MB fp32 GEMV costs more than the 16.5 MB sweep it replaces at one image
-            # (tools/exp_merger_fusion.py)
-            slot = _merger_gelu_slot(merger) if getattr(self, "fuse_merger_colsum", False) else None
+            # visual.fuse_merger_colsum: True / False, or None (default) = automatic: on from kFuseMinTokens merged tokens per
+            # call.  Measured on MI355X (tools/exp_merger_fusion.py, profiles/r02_merger_fusion.jsonl): GELU + LIS 1392 -> 1290 us
+            # at 147 456 tokens (-7.4 %), 391 -> 408 us at 36 864 (+4 %), and a clear loss at one image (the fused GELU costs
+            # ~25 us more than torch's, the skinny fp32 GEMM ~30 us; the sweep it removes is 5 us per image)
+            fuse = getattr(self, "fuse_merger_colsum", None)
+            if fuse is None:
+                merge = int(getattr(self, "spatial_merge_unit", 0) or getattr(self, "spatial_merge_size", 2) ** 2)
+                fuse = hidden_states.shape[0] // max(1, merge) >= kFuseMinTokens
+            slot = _merger_gelu_slot(merger) if fuse else None
             if slot is not None:
                 fused_gelu = _GeluColsum()
                 original_gelu = slot[0][slot[1]]

@@ -43,7 +43,11 @@ def kernel_bytes(name, b, n, d, hd, k, e=2):
         "colsum_partial_kernel": b * n * d * e,                    # first sweep of the tokens
         "score_kernel": b * n * d * e + b * n * 4,                 # second sweep + scores out
         "gather_rows_kernel": 2 * b * k * d * e + b * k * 8,       # read kept rows + write them
-        "lis_fused_kernel": algorithmic_bytes(b, n, d, hd, k, e),
+        # small-batch form (csrc/lis_small.h)
+        "score_small_kernel": b * n * d * e + b * n * 4,
+        "select_gather_small_kernel": 2 * b * k * d * e + b * k * 8,
+        "proj_nt_small_kernel": hd * d * e,                        # Wk streamed once
+        "proj_nn_small_kernel": hd * d * e,                        # Wq streamed once
     }.get(name)
 
 

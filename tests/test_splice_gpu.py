@@ -174,3 +174,65 @@ def test_select_splice_attend_packed_pipeline(ops):
     o = ops.varlen_attn(q, kk, vv, cu, max(seq_lens))
     ref = oattn.varlen_attention(q.float().cpu().numpy(), kk.float().cpu().numpy(), vv.float().cpu().numpy(), r_cu)
     assert np.abs(o.float().cpu().numpy() - ref).max() <= 2e-2          # bf16 output of values ~N(0,1)
+
+
+def test_config5_real_geometry_select_splice_attend(ops):
+    """BASELINE config 5 at its real geometry: Qwen2.5-VL-7B (D 3584, Hd 1792, 28 / 4 heads, head_dim 128), 8 prompts with
+    576 .. 4096 visual tokens and 16 .. 128 text tokens, per-prompt k = int(0.2 N): ragged select == each prompt scored alone
+    (bit for bit) and == the fp64 oracle's indices; packed splice offsets; var-len attention over the compressed packing ==
+    each sequence attended alone (bit for bit, same schedule) and within the forward gate of the oracle on one sequence."""
+    import parity
+    from oracle import attention as oattn
+    from oracle import lis as olis
+    d, hd, hq, hkv = 3584, 1792, 28, 4
+    rng = np.random.default_rng(5)
+    n_vis = [int(x) for x in rng.integers(576, 4097, 8)]
+    n_vis[0], n_vis[1] = 576, 4096                                   # both ends of the range
+    n_txt = [int(x) for x in rng.integers(16, 129, 8)]
+    ks = [int(n * 0.2) for n in n_vis]
+    seq = [n + t for n, t in zip(n_vis, n_txt)]
+    g = torch.Generator(device="cuda").manual_seed(50)
+    h = torch.randn(sum(n_vis), d, device="cuda", generator=g).bfloat16()
+    wq, wk = [(0.02 * torch.randn(hd, d, device="cuda", generator=g)).bfloat16() for _ in range(2)]
+    bq, bk = [(0.02 * torch.randn(hd, device="cuda", generator=g)).bfloat16() for _ in range(2)]
+    out, idx, scores = ops.lis_select_varlen(h, n_vis, ks, wq, bq, wk, bk)
+    v0 = o0 = 0
+    for i, (n, k) in enumerate(zip(n_vis, ks)):
+        o1, i1, s1 = ops.lis_select(h[v0:v0 + n].contiguous(), wq, bq, wk, bk, k)
+        assert torch.equal(i1, idx[o0:o0 + k]) and torch.equal(o1, out[o0:o0 + k]) and torch.equal(s1, scores[v0:v0 + n])
+        if i in (0, 1, 5):
+            f = lambda t: t.float().cpu().numpy()  # noqa: E731
+            ref = olis.scorer_collapsed(f(h[v0:v0 + n])[None], f(wq), f(bq), f(wk), f(bk))[0]
+            assert np.array_equal(olis.hard_topk_indices(ref.astype(np.float32), k), i1.cpu().numpy())
+        v0 += n
+        o0 += k
+    ids = torch.cat([torch.cat((torch.randint(10, 1000, (t // 2,)), torch.full((n,), IMAGE_TOKEN), torch.randint(10, 1000, (t - t // 2,))))
+                     for n, t in zip(n_vis, n_txt)]).cuda()
+    emb = torch.randn(sum(seq), d, device="cuda", generator=g).bfloat16()
+    pos = torch.arange(sum(seq), device="cuda")[None].expand(3, -1).contiguous()
+    sel, new_ids, new_emb, new_pos, cu_c = ops.splice_batched(ids, emb, IMAGE_TOKEN, seq, n_vis, ks, idx, out, position_ids=pos, check=True)
+    seq_c = [k + t for k, t in zip(ks, n_txt)]
+    assert cu_c.tolist() == np.concatenate(([0], np.cumsum(seq_c))).tolist()
+    assert int((new_ids == IMAGE_TOKEN).sum()) == sum(ks) and torch.equal(new_pos[0], sel)
+    assert torch.equal(new_emb[new_ids == IMAGE_TOKEN], out)
+    t = sum(seq_c)
+    q = torch.randn(t, hq, 128, device="cuda", generator=g).bfloat16()
+    kk = torch.randn(t, hkv, 128, device="cuda", generator=g).bfloat16()
+    vv = torch.randn(t, hkv, 128, device="cuda", generator=g).bfloat16()
+    o = ops.varlen_attn(q, kk, vv, cu_c, max(seq_c))
+    _set = __import__("ctypes").c_int
+    from visionselector_amd import _native
+    lib = _native.lib()
+    lib.vsel_debug_attn_split.restype = None
+    lib.vsel_debug_attn_split(0)             # single-stream schedule on both sides: packing invariance is bit-exact
+    try:
+        o_same = ops.varlen_attn(q, kk, vv, cu_c, max(seq_c))
+        a = int(cu_c[3]); b = int(cu_c[4])
+        alone = ops.varlen_attn(q[a:b].contiguous(), kk[a:b].contiguous(), vv[a:b].contiguous(),
+                                torch.tensor([0, b - a], dtype=torch.int32, device="cuda"), b - a)
+    finally:
+        lib.vsel_debug_attn_split(2)
+    assert torch.equal(o_same[a:b], alone)
+    ref = oattn.varlen_attention(q[a:b, :7].float().cpu().numpy(), kk[a:b, :1].float().cpu().numpy(), vv[a:b, :1].float().cpu().numpy(),
+                                 np.array([0, b - a]))
+    parity.check_fwd("test_config5_real_geometry", o[a:b, :7].float().cpu().numpy().astype(np.float64), ref)

@@ -45,7 +45,8 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
                 os.path.getmtime(p) for p in [src] + glob.glob(os.path.join(CSRC, "*.h"))
                 + [os.path.join(os.path.dirname(PKG_DIR), "include", "vsel.h")]):
             continue
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("VSEL_HIPCC_FLAGS", "").split() + \
+            ["-c", src, "-o", obj]
         if verbose:
             print("[vsel build]", " ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -34,6 +34,54 @@ constexpr int kLds = 4 * kBuf;               // K[2], V[2]: 64 KiB
 
 __device__ __forceinline__ bf16x8_t to_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 
+// ---- LDS reads the compiler does not schedule ----------------------------------------------------------------------------
+// hipcc turns the tile body into "ds_read; s_waitcnt lgkmcnt(0); v_mfma" triples (every MFMA behind a full LDS round trip,
+// MFMA-busy 34 %) and, for the transpose-read builtin, puts s_waitcnt vmcnt(0) in front of the first V read, which drains the
+// direct-to-LDS prefetch of the next tile.  The reads are therefore issued from inline asm in BATCHES (8 per batch, the next
+// batch in flight behind the MFMAs of the current one) with counted lgkmcnt waits that name the batch's registers
+// (cdna_hip_programming.md 5.7, form (ii)) followed by sched_barrier(0) so that no MFMA is hoisted above its wait (rule 18).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_u32(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+// per-lane base address in a VGPR + a compile-time immediate (buffer, key block): no address arithmetic in the tile loop and no
+// address registers beyond the 8 + 8 per-lane bases
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_b128_asm(uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_read_tr16_b64_asm(uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+// wait until at most N LDS operations of this wave are outstanding; the 8 registers of the batch that must have landed are
+// read-write operands, so their consumers cannot be scheduled above the wait and their values stay in these registers
+template <int N>
+__device__ __forceinline__ void lds_wait8(u32x4 (&a)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+               : "n"(N));
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int N>
+__device__ __forceinline__ void lds_wait4(u32x4 (&a)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N));
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int N>
+__device__ __forceinline__ void lds_wait8(u32x2 (&a)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+               : "n"(N));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // Persistent work-stealing grid: items = (q-tile, head, sequence), handed out heaviest-first (largest q-tile = most KV
 // tiles under the causal mask) through one atomic counter, so the causal triangle is load-balanced over the 2 x 256
 // resident workgroups instead of being bounded by the last q-tile (1.9x fewer tiles on the critical path at L = 2368).
@@ -78,8 +126,11 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   constexpr int kSteps = D / 16;                   // k-steps of S^T = K Q^T
   constexpr int kDTiles = (D + 31) / 32;           // 32-wide d-tiles of O^T
   constexpr int kParts = D / 8;                    // 16-byte parts per row that hold data
-  __shared__ __attribute__((aligned(16))) char smem[KVS * kLds];
-  __shared__ int s_item;
+  // ONE __shared__ object: with a second one (a 4-byte work-item slot) hipcc puts s_waitcnt vmcnt(0) in front of the first ds_read
+  // of every tile, which drains the direct-to-LDS prefetch of the NEXT tile before this tile's math (cdna_hip_programming.md,
+  // "Three .s-level traps", (a))
+  __shared__ __attribute__((aligned(16))) char smem[KVS * kLds + 16];
+  int& s_item = *reinterpret_cast<int*>(smem + KVS * kLds);
   static_assert(!PACK || NW == 1, "the GQA-packed form is single-wave");
   const int rep = hq / hkv;
   const int n_items = PACK ? hkv * n_seq : q_tiles * hq * n_seq;
@@ -102,6 +153,12 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   int row_addr[kSteps], tr_addr[kDTiles][2];
   make_row_addr<kSteps>(row_addr, j, hh);
   make_tr_addr<kDTiles>(tr_addr, lane);
+  // LDS byte addresses of the per-lane bases (for the inline-asm reads)
+  uint32_t row_addr_u[kSteps], tr_addr_u[kDTiles][2];
+#pragma unroll
+  for (int st = 0; st < kSteps; ++st) row_addr_u[st] = lds_u32(smem) + row_addr[st];
+#pragma unroll
+  for (int dt = 0; dt < kDTiles; ++dt) { tr_addr_u[dt][0] = lds_u32(smem) + tr_addr[dt][0]; tr_addr_u[dt][1] = lds_u32(smem) + tr_addr[dt][1]; }
   if constexpr (KVS > 1) {                                     // this group's tile buffers
 #pragma unroll
     for (int st = 0; st < kSteps; ++st) row_addr[st] += grp * kLds;
@@ -232,13 +289,54 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
       // ---- S^T = K Q^T ----------------------------------------------------------------------------------------
       f32x16 s[2];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      if constexpr (USE_TR && kSteps == 8 && KVS == 1) {
+        // per 32-key block: its 8 K fragments in ONE batch of ds_read_b128, then its 8 MFMAs (one LDS round trip per block instead
+        // of one per MFMA; a second batch in flight would need 32 more registers and spills)
+        auto s_block = [&](auto kb_c) {
+          constexpr int KB = decltype(kb_c)::value;
+          if constexpr (NW >= 8) {
+            u32x4 ka[8];
 #pragma unroll
-        for (int st = 0; st < kSteps; ++st) {
-          const u32x4 a = *reinterpret_cast<const u32x4*>(kt + row_addr[st] + kb * 32 * kRowBytes);
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(a), to_bf16x8(qf[st]), s[kb], 0, 0, 0);
+            for (int st = 0; st < 8; ++st) ka[st] = lds_read_b128_asm<CUR * kBuf + KB * 32 * kRowBytes>(row_addr_u[st]);
+            lds_wait8<0>(ka);
+#pragma unroll
+            for (int st = 0; st < 8; ++st)
+              s[KB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(ka[st]), to_bf16x8(qf[st]), s[KB], 0, 0, 0);
+          } else {
+            // 4-wave workgroups stage twice the tile rows per wave (more address state): batches of 4 keep the kernel spill-free
+#pragma unroll
+            for (int h4 = 0; h4 < 2; ++h4) {
+              u32x4 ka[4];
+#pragma unroll
+              for (int st = 0; st < 4; ++st) ka[st] = lds_read_b128_asm<CUR * kBuf + KB * 32 * kRowBytes>(row_addr_u[4 * h4 + st]);
+              lds_wait4<0>(ka);
+#pragma unroll
+              for (int st = 0; st < 4; ++st)
+                s[KB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(ka[st]), to_bf16x8(qf[4 * h4 + st]), s[KB], 0, 0, 0);
+            }
+          }
+        };
+        s_block(std::integral_constant<int, 0>{});
+        s_block(std::integral_constant<int, 1>{});
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int st = 0; st < kSteps; ++st) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(kt + row_addr[st] + kb * 32 * kRowBytes);
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(a), to_bf16x8(qf[st]), s[kb], 0, 0, 0);
+          }
+      }
+      // the first group of V fragments does not depend on P: put its transpose reads in flight now, under the softmax
+      u32x2 vr0[8], vr1[8];
+      if constexpr (USE_TR && kDTiles == 4 && KVS == 1 && NW >= 8) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          vr0[2 * dt] = lds_read_tr16_b64_asm<(2 + CUR) * kBuf>(tr_addr_u[dt][0]);
+          vr0[2 * dt + 1] = lds_read_tr16_b64_asm<(2 + CUR) * kBuf>(tr_addr_u[dt][1]);
         }
       }
       // ---- mask + online softmax (exp2 domain; the softmax scale is folded into one FMA per element) ------------
@@ -288,6 +386,47 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
         }
       l_run += psum;
       // ---- O^T += V^T P^T -------------------------------------------------------------------------------------
+      if constexpr (USE_TR && kDTiles == 4 && KVS == 1) {
+        // four (32-key block, 16-key half) groups; a group = 8 transpose reads (4 d-tiles x lo / hi) feeding 4 MFMAs; the next
+        // group's reads are in flight behind the current group's MFMAs
+        auto issue = [&](auto g_c, u32x2 (&dst)[8]) {
+          constexpr int G = decltype(g_c)::value;
+          constexpr int OFF = (2 + CUR) * kBuf + (32 * (G >> 1) + 16 * (G & 1)) * kRowBytes;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            dst[2 * dt] = lds_read_tr16_b64_asm<OFF>(tr_addr_u[dt][0]);
+            dst[2 * dt + 1] = lds_read_tr16_b64_asm<OFF>(tr_addr_u[dt][1]);
+          }
+        };
+        auto pv = [&](auto g_c, u32x2 (&src)[8]) {
+          constexpr int G = decltype(g_c)::value;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const u32x4 w = {src[2 * dt][0], src[2 * dt][1], src[2 * dt + 1][0], src[2 * dt + 1][1]};
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(w), pf[G >> 1][G & 1], o[dt], 0, 0, 0);
+          }
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        if constexpr (NW >= 8) {
+          issue(I1{}, vr1);                    // (group 0 was issued before the softmax)
+          lds_wait8<8>(vr0);
+          pv(I0{}, vr0);
+          issue(I2{}, vr0);
+          lds_wait8<8>(vr1);
+          pv(I1{}, vr1);
+          issue(I3{}, vr1);
+          lds_wait8<8>(vr0);
+          pv(I2{}, vr0);
+          lds_wait8<0>(vr1);
+          pv(I3{}, vr1);
+        } else {
+          issue(I0{}, vr0); lds_wait8<0>(vr0); pv(I0{}, vr0);
+          issue(I1{}, vr0); lds_wait8<0>(vr0); pv(I1{}, vr0);
+          issue(I2{}, vr0); lds_wait8<0>(vr0); pv(I2{}, vr0);
+          issue(I3{}, vr0); lds_wait8<0>(vr0); pv(I3{}, vr0);
+        }
+      } else {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -312,6 +451,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
             o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][mm], o[dt], 0, 0, 0);
           }
         }
+      }
     }
   };
   if constexpr (KVS == 1) {

@@ -72,8 +72,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dvec,
     const int32_t* __restrict__ cu, int hq, int hkv, float scale, int causal, uint16_t* __restrict__ dq, int q_tiles, int n_seq,
     int slot) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * kTileB];       // K[2], V[2]
-  __shared__ int s_item;
+  // ONE __shared__ object (a second one makes hipcc drain the direct-to-LDS prefetch with s_waitcnt vmcnt(0) before the first
+  // ds_read of every tile: attn.hip)
+  __shared__ __attribute__((aligned(16))) char smem[4 * kTileB + 16];  // K[2], V[2], work-item slot
+  int& s_item = *reinterpret_cast<int*>(smem + 4 * kTileB);
   char* const k_sm = smem;
   char* const v_sm = smem + 2 * kTileB;
   const int n_items = q_tiles * hq * n_seq;
@@ -235,10 +237,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
     const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dvec,
     const int32_t* __restrict__ cu, int hq, int hkv, float scale, int causal, uint16_t* __restrict__ dk,
     uint16_t* __restrict__ dv, float* __restrict__ dk_part, float* __restrict__ dv_part, int k_blocks, int n_seq, int slot) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * kTileB];       // Q[2], dO[2]
-  __shared__ __attribute__((aligned(16))) float lse_sm[2][kTile];
-  __shared__ __attribute__((aligned(16))) float d_sm[2][kTile];
-  __shared__ int s_item;
+  // ONE __shared__ object (see attn_bwd_dq_kernel): Q[2], dO[2], lse[2][kTile], D[2][kTile], work-item slot
+  __shared__ __attribute__((aligned(16))) char smem[4 * kTileB + 4 * kTile * sizeof(float) + 16];
+  float (*lse_sm)[kTile] = reinterpret_cast<float (*)[kTile]>(smem + 4 * kTileB);
+  float (*d_sm)[kTile] = reinterpret_cast<float (*)[kTile]>(smem + 4 * kTileB + 2 * kTile * sizeof(float));
+  int& s_item = *reinterpret_cast<int*>(smem + 4 * kTileB + 4 * kTile * sizeof(float));
   char* const q_sm = smem;
   char* const do_sm = smem + 2 * kTileB;
   const int heads_per_item_dim = SPLIT ? hq : hkv;

@@ -153,18 +153,18 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   int row_addr[kSteps], tr_addr[kDTiles][2];
   make_row_addr<kSteps>(row_addr, j, hh);
   make_tr_addr<kDTiles>(tr_addr, lane);
-  // LDS byte addresses of the per-lane bases (for the inline-asm reads)
-  uint32_t row_addr_u[kSteps], tr_addr_u[kDTiles][2];
-#pragma unroll
-  for (int st = 0; st < kSteps; ++st) row_addr_u[st] = lds_u32(smem) + row_addr[st];
-#pragma unroll
-  for (int dt = 0; dt < kDTiles; ++dt) { tr_addr_u[dt][0] = lds_u32(smem) + tr_addr[dt][0]; tr_addr_u[dt][1] = lds_u32(smem) + tr_addr[dt][1]; }
   if constexpr (KVS > 1) {                                     // this group's tile buffers
 #pragma unroll
     for (int st = 0; st < kSteps; ++st) row_addr[st] += grp * kLds;
 #pragma unroll
     for (int dt = 0; dt < kDTiles; ++dt) { tr_addr[dt][0] += grp * kLds; tr_addr[dt][1] += grp * kLds; }
   }
+  // LDS byte addresses of the per-lane bases (for the inline-asm reads)
+  uint32_t row_addr_u[kSteps], tr_addr_u[kDTiles][2];
+#pragma unroll
+  for (int st = 0; st < kSteps; ++st) row_addr_u[st] = lds_u32(smem) + row_addr[st];
+#pragma unroll
+  for (int dt = 0; dt < kDTiles; ++dt) { tr_addr_u[dt][0] = lds_u32(smem) + tr_addr[dt][0]; tr_addr_u[dt][1] = lds_u32(smem) + tr_addr[dt][1]; }
   // direct-to-LDS loads: wave w issues wave-instructions w, w + NW, ...; instruction i covers tile rows 4i .. 4i+3, lane l
   // lands at (row 4i + (l >> 4), position l & 15) and therefore fetches global part (l & 15) ^ swz(row)
   // (a source part past the row's data, head_dim < 128, is redirected to part 0: its LDS position is never read for S and only
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-      if constexpr (USE_TR && kSteps == 8 && KVS == 1) {
+      if constexpr (USE_TR && kSteps == 8 && !PACK) {
         // per 32-key block: its 8 K fragments in ONE batch of ds_read_b128, then its 8 MFMAs (one LDS round trip per block instead
         // of one per MFMA; a second batch in flight would need 32 more registers and spills)
         auto s_block = [&](auto kb_c) {
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
       }
       // the first group of V fragments does not depend on P: put its transpose reads in flight now, under the softmax
       u32x2 vr0[8], vr1[8];
-      if constexpr (USE_TR && kDTiles == 4 && KVS == 1 && NW >= 8) {
+      if constexpr (USE_TR && kDTiles == 4 && NW >= 8 && !PACK) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           vr0[2 * dt] = lds_read_tr16_b64_asm<(2 + CUR) * kBuf>(tr_addr_u[dt][0]);
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
         }
       l_run += psum;
       // ---- O^T += V^T P^T -------------------------------------------------------------------------------------
-      if constexpr (USE_TR && kDTiles == 4 && KVS == 1) {
+      if constexpr (USE_TR && kDTiles == 4 && !PACK) {
         // four (32-key block, 16-key half) groups; a group = 8 transpose reads (4 d-tiles x lo / hi) feeding 4 MFMAs; the next
         // group's reads are in flight behind the current group's MFMAs
         auto issue = [&](auto g_c, u32x2 (&dst)[8]) {

@@ -72,5 +72,54 @@ __device__ __forceinline__ void load_slice_lds(const uint16_t* src_row_ptr, int 
 // 4 i + (l >> 4) holds part (l & 15) ^ swz(row), and swz(row) = ((l >> 4) << 2) | (w & 3) for every such slice.
 __device__ __forceinline__ int slice_src_part(int lane, int wave) { return (lane & 15) ^ (((lane >> 4) << 2) | (wave & 3)); }
 
+// ---- LDS reads the compiler does not schedule ----------------------------------------------------------------------------
+// hipcc turns the tile body into "ds_read; s_waitcnt lgkmcnt(0); v_mfma" triples (every MFMA behind a full LDS round trip,
+// MFMA-busy 34 %) and, for the transpose-read builtin, puts s_waitcnt vmcnt(0) in front of the first V read, which drains the
+// direct-to-LDS prefetch of the next tile.  The reads are therefore issued from inline asm in BATCHES (8 per batch, the next
+// batch in flight behind the MFMAs of the current one) with counted lgkmcnt waits that name the batch's registers
+// (cdna_hip_programming.md 5.7, form (ii)) followed by sched_barrier(0) so that no MFMA is hoisted above its wait (rule 18).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_u32(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+// per-lane base address in a VGPR + a compile-time immediate (buffer, key block): no address arithmetic in the tile loop and no
+// address registers beyond the 8 + 8 per-lane bases
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_b128_asm(uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_read_tr16_b64_asm(uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+// wait until at most N LDS operations of this wave are outstanding; the 8 registers of the batch that must have landed are
+// read-write operands, so their consumers cannot be scheduled above the wait and their values stay in these registers
+template <int N>
+__device__ __forceinline__ void lds_wait8(u32x4 (&a)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+               : "n"(N));
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int N>
+__device__ __forceinline__ void lds_wait4(u32x4 (&a)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N));
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int N>
+__device__ __forceinline__ void lds_wait8(u32x2 (&a)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+               : "n"(N));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+
 }  // namespace attn
 }  // namespace vsel

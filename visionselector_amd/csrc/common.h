@@ -136,6 +136,19 @@ __device__ __forceinline__ float wave_reduce_dpp(float v, Op op) {
   const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
   return op(op(r0, r1), op(r2, r3));
 }
+// inclusive prefix sum over the 64 lanes (integer => exact): 4 row_shr DPP steps inside each 16-lane row, then the totals of
+// the lower rows through v_readlane.  (__shfl_up / __shfl_down cost one ds_bpermute_b32 round trip per step.)
+__device__ __forceinline__ uint32_t wave_prefix_sum_u32(uint32_t v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);    // row_shr:1 (lanes without a source add 0)
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);    // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);    // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);    // row_shr:8
+  const int t0 = __builtin_amdgcn_readlane(x, 15), t1 = __builtin_amdgcn_readlane(x, 31), t2 = __builtin_amdgcn_readlane(x, 47);
+  const int lane = (int)(threadIdx.x & 63);
+  x += (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+  return (uint32_t)x;
+}
 __device__ __forceinline__ float wave_sum(float v) { return wave_reduce_dpp(v, [](float a, float b) { return a + b; }); }
 __device__ __forceinline__ float wave_max(float v) { return wave_reduce_dpp(v, [](float a, float b) { return fmaxf(a, b); }); }
 __device__ __forceinline__ float wave_min(float v) { return wave_reduce_dpp(v, [](float a, float b) { return fminf(a, b); }); }

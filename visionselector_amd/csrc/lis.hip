@@ -71,6 +71,19 @@ static int g_small_path_max_seg = [] {
 extern "C" void vsel_debug_set_small_path(int max_seg) {
   g_small_path_max_seg = max_seg < 0 ? 0 : (max_seg > kSmallMaxSeg ? kSmallMaxSeg : max_seg);
 }
+#ifdef VSEL_TRACE
+// copies the stamps of the last small-batch call: out[kTraceKernels][kTraceBlocks][kTraceSlots] (tools/trace_small.py)
+extern "C" int vsel_debug_read_trace(unsigned long long* out, int clear) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(g_trace)) != hipSuccess) return VSEL_ERR_HIP;
+  if (clear) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_trace)) != hipSuccess || hipMemset(p, 0, sizeof(g_trace)) != hipSuccess)
+      return VSEL_ERR_HIP;
+  }
+  return VSEL_OK;
+}
+#endif
+
 static bool use_small_path(const vsel_segments* seg, const vsel_scorer* sc, const LisPlan& p) {
   return seg->n_seg <= g_small_path_max_seg && small_path_ok(seg, sc, p);
 }

@@ -19,6 +19,30 @@
 
 namespace vsel {
 
+// -DVSEL_TRACE (tools/trace_small.py builds with it; never in the shipped library): thread 0 of every workgroup leaves
+// s_memrealtime stamps (100 MHz, one clock for the whole device) at the phase edges of the small-batch kernels.
+#ifdef VSEL_TRACE
+constexpr int kTraceKernels = 8, kTraceBlocks = 1024, kTraceSlots = 8;
+static __device__ unsigned long long g_trace[kTraceKernels][kTraceBlocks][kTraceSlots];
+#define VSEL_STAMP(kern, slot)                                                                                         \
+  do {                                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    if (threadIdx.x == 0) {                                                                                            \
+      const unsigned b_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                              \
+      if (b_ < (unsigned)kTraceBlocks) g_trace[kern][b_][slot] = __builtin_amdgcn_s_memrealtime();                     \
+    }                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  } while (0)
+#define VSEL_STAMP_DRAIN(kern, slot)                                                                                   \
+  do {                                                                                                                 \
+    __builtin_amdgcn_s_waitcnt(0);                                                                                     \
+    VSEL_STAMP(kern, slot);                                                                                            \
+  } while (0)
+#else
+#define VSEL_STAMP(kern, slot) do {} while (0)
+#define VSEL_STAMP_DRAIN(kern, slot) do {} while (0)
+#endif
+
 // =================================================================================================
 constexpr int kRowsPerChunk = 128;   // sweep-1 row chunk (batch-invariant summation order)
 constexpr int kSliceNT = 256;        // split-K slice of the kbar projection (fixed => batch-invariant)
@@ -59,6 +83,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   // else is in the batch; chunks past the segment's end contribute exact zeros
   const int rb = rs * kRowsPerChunk;
   const int re = min(n, rb + kRowsPerChunk);
+  VSEL_STAMP(0, 0);
   float acc[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) acc[i] = 0.f;
@@ -128,6 +153,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 #pragma unroll
   for (int i = 0; i < V; ++i) red[wave][lane][i] = acc[i];
   __syncthreads();
+  VSEL_STAMP(0, 1);
   if (wave == 0 && col < d) {
     float out[V];
 #pragma unroll
@@ -139,6 +165,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
       *reinterpret_cast<f32x4*>(dst + i) = o;
     }
   }
+  VSEL_STAMP_DRAIN(0, 2);
 }
 
 // K1b  xbar[s][c] = sum_rs partial[s][rs][c] / N_s   (fixed order)

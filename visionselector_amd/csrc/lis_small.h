@@ -38,6 +38,7 @@ static __global__ __launch_bounds__(64) void proj_nt_small_kernel(const float* _
   const int k_end = min(K, k_begin + kslice);
   const uint16_t* wp0 = w + (int64_t)row0 * K + 8 * kg;
   const uint16_t* wp1 = w + (int64_t)row1 * K + 8 * kg;
+  VSEL_STAMP(1, 0);
   constexpr int KB = kSliceNT / 16;      // the whole 256-wide slice: one wave per SIMD at these batch sizes, registers are free
   // the weights do not depend on the prologue: put the loads of the whole slice in flight first (one round trip, overlapped
   // with the partial-sum loads below)
@@ -83,6 +84,7 @@ static __global__ __launch_bounds__(64) void proj_nt_small_kernel(const float* _
     }
   }
   __syncthreads();
+  VSEL_STAMP(1, 1);
   const bool act = i < S;
   const u32x4 zero = {0u, 0u, 0u, 0u};
   auto ldb = [&](int p, int koff) -> u32x4 {          // B fragment: lane (i, kg) holds xbar[i][koff + 8 kg .. + 7]
@@ -119,6 +121,10 @@ static __global__ __launch_bounds__(64) void proj_nt_small_kernel(const float* _
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(x1), as_bf16x8(b1), acc1, 0, 0, 0);
   }
   // C[row = n][col = m]; compact slab [ks][m][n] (only the S live columns are stored)
+#ifdef VSEL_TRACE
+  asm volatile("" ::"v"(acc0[0]), "v"(acc1[0]));
+#endif
+  VSEL_STAMP(1, 2);
   if (act) {
     float* dst = part + ((int64_t)ks * S + i) * N;
 #pragma unroll
@@ -128,6 +134,7 @@ static __global__ __launch_bounds__(64) void proj_nt_small_kernel(const float* _
       if (n0 + 32 + row < N) dst[n0 + 32 + row] = acc1[r];
     }
   }
+  VSEL_STAMP_DRAIN(1, 3);
 }
 
 // -------------------------------------------------------------------------------------------------------------------------
@@ -147,6 +154,7 @@ static __global__ __launch_bounds__(64) void proj_nn_small_kernel(const float* _
   const int k_begin = ks * kslice;
   const int k_end = min(K, k_begin + kslice);
   const uint16_t* wp = w + (int64_t)(8 * kg) * N + nb;
+  VSEL_STAMP(2, 0);
   constexpr int KB = 4;
   u32x4 wv[KB][8];
   const bool first_full = k_begin + 16 * KB <= k_end;
@@ -188,6 +196,7 @@ static __global__ __launch_bounds__(64) void proj_nn_small_kernel(const float* _
     *reinterpret_cast<float2*>(&ct[m][2 * lane]) = make_float2(c0, c1);
   }
   __syncthreads();
+  VSEL_STAMP(2, 1);
   if (blockIdx.x == 0) {
     // cpart[m][by] = sum of the block's 8 consecutive h in order (kbar_finish_split_kernel's LDS reduction)
     const int blocks = (k_end - k_begin + 7) / 8;
@@ -243,6 +252,10 @@ static __global__ __launch_bounds__(64) void proj_nn_small_kernel(const float* _
     step(x, ldb(0, ko), ldb(1, ko), ldb(2, ko));
   }
   // acc[t][r] = C[n = n0 + 8 irow + t][m = lane & 31]; compact slab [ks][m][n]: 8 consecutive n per (lane, r)
+#ifdef VSEL_TRACE
+  asm volatile("" ::"v"(acc[0][0]), "v"(acc[7][0]));
+#endif
+  VSEL_STAMP(2, 2);
   if (act) {
     float* dst = part2 + ((int64_t)ks * S + i) * N;
 #pragma unroll
@@ -257,45 +270,73 @@ static __global__ __launch_bounds__(64) void proj_nn_small_kernel(const float* _
       }
     }
   }
+  VSEL_STAMP_DRAIN(2, 3);
 }
 
 // -------------------------------------------------------------------------------------------------------------------------
 // P3  sweep 2 with w[s] = sum_ks part2[ks][s][:] (ks order = w_finish_kernel) and c[s] rebuilt in LDS by every workgroup.
-//     grid (row_chunks, S), block 256.  Dynamic LDS: d floats.
+//     grid (row_chunks, S), block 512 (8 waves: rows rb + wave + 8 u).  Dynamic LDS: d floats + 16 + n_cpart.
+//     One memory round trip: the wave's first two token rows (they do not depend on the projections), the c partials and the
+//     slab loads of the w rebuild (2 column groups x <= 16 slabs per thread) are issued back to back before anything is
+//     consumed (tools/trace_small.py: two 32-load batches, then the c chain, then the rows took 5.6 + 1.1 + 3.3 us in a row).
+//     Per row the arithmetic is score_rows' (dot_raw over the column groups in order, wave_sum, (a + c) / sqrt(Hd)).
 // -------------------------------------------------------------------------------------------------------------------------
+constexpr int kSmallScoreThreads = 512;
+
 template <typename T, int ITERS>
-__global__ __launch_bounds__(256) void score_small_kernel(const T* __restrict__ h, SegView sv, int d, int S,
-                                                          const float* __restrict__ part2, int KS2,
-                                                          const float* __restrict__ cpart, int n_cpart, float sqrt_hd,
-                                                          int rows_per_block, float* __restrict__ scores,
-                                                          const int64_t* __restrict__ out_map) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];      // [d] then 9 floats for c
+__global__ __launch_bounds__(kSmallScoreThreads) void score_small_kernel(const T* __restrict__ h, SegView sv, int d, int S,
+                                                                         const float* __restrict__ part2, int KS2,
+                                                                         const float* __restrict__ cpart, int n_cpart,
+                                                                         float sqrt_hd, int rows_per_block,
+                                                                         float* __restrict__ scores,
+                                                                         const int64_t* __restrict__ out_map) {
+  constexpr int V = Elem<T>::kVec;
+  constexpr int XI = ITERS > 0 ? ITERS : 1;
+  constexpr int NT = kSmallScoreThreads, NWV = NT / 64;
+  extern __shared__ __attribute__((aligned(16))) float wl[];      // [d] then 16 floats for c, then the staged c partials
   float* cred = wl + d;
   const int s = blockIdx.y;
   const int n = sv.n_rows(s);
   const int rb = blockIdx.x * rows_per_block;
   if (rb >= n) return;
-  const int tid = threadIdx.x;
-  // c[s]: w_finish_kernel's order -- 8 strided partial sums (nj, nj + 8, ...) then those 8 in order.  The c partials are
-  // staged through LDS with ONE load per thread (a chain of dependent 8-load batches by 8 threads was the kernel's long pole).
+  const int re = min(n, rb + rows_per_block);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t r0 = sv.row_begin(s);
+  VSEL_STAMP(3, 0);
+  // (1) rows rb + wave, rb + wave + NWV as raw 16-byte vectors (clamped: rows past the end are loaded and not used)
+  const T* base = h + r0 * (int64_t)d + lane * V;
+  u32x4 x[2][XI];
+  if constexpr (ITERS > 0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = min(rb + wave + NWV * u, n - 1);
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) x[u][it] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * d + it * 64 * V);
+    }
+  }
+  // (2) c partials: <= 2 per thread in registers now (clamped), staged through LDS after the slab loads are out
   float* cstage = cred + 16;
-  for (int e = tid; e < n_cpart; e += 256) cstage[e] = cpart[(int64_t)s * n_cpart + e];
+  float cp[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) cp[q] = cpart[(int64_t)s * n_cpart + min(tid + NT * q, n_cpart - 1)];
+  // (3) w: two 4-column groups per thread and pass, all their slab loads in flight together, added in ks order
   const float* src = part2 + (int64_t)s * d;
   const int64_t slab = (int64_t)S * d;
-  // two 4-column groups per thread and batch, all their slab loads in flight together (KS2 <= 16 per batch)
-  for (int c4 = tid; c4 < d / 4; c4 += 512) {
-    const int c4b = c4 + 256;
-    const bool has_b = c4b < d / 4;
+  const int nc4 = d / 4;
+  for (int c4 = tid; c4 < nc4; c4 += 2 * NT) {
+    const int c4b = c4 + NT;
+    const bool has_b = c4b < nc4;
+    const int c4bc = has_b ? c4b : c4;               // unconditional loads (clamped): see proj_nt_small_kernel
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < KS2; k0 += 16) {
       f32x4 va[16], vb[16];
-      const int c4bc = has_b ? c4b : c4;             // unconditional loads (clamped): see proj_nt_small_kernel
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int64_t ku = min(k0 + u, KS2 - 1);
         va[u] = *reinterpret_cast<const f32x4*>(src + ku * slab + 4 * c4);
         vb[u] = *reinterpret_cast<const f32x4*>(src + ku * slab + 4 * c4bc);
       }
+      asm volatile("" ::: "memory");                 // every load above is issued before the first add below waits for one
 #pragma unroll
       for (int u = 0; u < 16; ++u)
         if (k0 + u < KS2) { a += va[u]; b += vb[u]; }
@@ -303,31 +344,96 @@ __global__ __launch_bounds__(256) void score_small_kernel(const T* __restrict__ 
     *reinterpret_cast<f32x4*>(wl + 4 * c4) = a;
     if (has_b) *reinterpret_cast<f32x4*>(wl + 4 * c4b) = b;
   }
-  for (int c = (d / 4) * 4 + tid; c < d; c += 256) {   // d % 4 != 0 cannot happen (D % 8 == 0 is checked), kept for safety
-    float a = 0.f;
-    for (int ks = 0; ks < KS2; ++ks) a += src[ks * slab + c];
-    wl[c] = a;
-  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    if (tid + NT * q < n_cpart) cstage[tid + NT * q] = cp[q];
+  for (int e = tid + 2 * NT; e < n_cpart; e += NT) cstage[e] = cpart[(int64_t)s * n_cpart + e];
   __syncthreads();
+  VSEL_STAMP(3, 1);
+  // c[s]: w_finish_kernel's order -- 8 strided partial sums (nj, nj + 8, ...) then those 8 in order.  The LDS reads of a
+  // thread's chain are issued together (clamped), the adds keep the order.
   if (tid < 8) {
     float a = 0.f;
-    for (int e = tid; e < n_cpart; e += 8) a += cstage[e];
+    for (int e0 = tid; e0 < n_cpart; e0 += 8 * 32) {
+      float t[32];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) t[q] = cstage[min(e0 + 8 * q, n_cpart - 1)];
+#pragma unroll
+      for (int q = 0; q < 32; ++q)
+        if (e0 + 8 * q < n_cpart) a += t[q];
+    }
     cred[tid] = a;
   }
   __syncthreads();
+  VSEL_STAMP(3, 2);
   float cs = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) cs += cred[j];
-  score_rows<T, ITERS, false>(h, d, wl, cs, sqrt_hd, sv.row_begin(s), rb, min(n, rb + rows_per_block), scores, out_map);
+  if constexpr (ITERS > 0) {
+    float wr[ITERS][V];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+      for (int q = 0; q < V; q += 4) {
+        float t4[4];
+        load_vec(wl + (it * 64 + lane) * V + q, t4);
+#pragma unroll
+        for (int z = 0; z < 4; ++z) wr[it][q + z] = t4[z];
+      }
+    }
+    for (int r = rb + wave; r < re; r += 2 * NWV) {
+      if (r != rb + wave) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int row = min(r + NWV * u, n - 1);
+#pragma unroll
+          for (int it = 0; it < ITERS; ++it) x[u][it] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * d + it * 64 * V);
+        }
+      }
+      float a[2] = {0.f, 0.f};
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) a[u] = dot_raw<T>(x[u][it], wr[it], a[u]);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        a[u] = wave_sum(a[u]);
+        const int row = r + NWV * u;
+        if (lane == 0 && row < re) scores[out_map ? out_map[r0 + row] : r0 + row] = (a[u] + cs) / sqrt_hd;
+      }
+    }
+  } else {
+    for (int r = rb + wave; r < re; r += NWV) {
+      const T* p0 = h + (r0 + r) * (int64_t)d;
+      float a0 = 0.f;
+      for (int col = lane * V; col < d; col += 64 * V) {
+        float x0[V];
+        load_vec(p0 + col, x0);
+#pragma unroll
+        for (int q = 0; q < V; q += 4) {
+          float t4[4];
+          load_vec(wl + col + q, t4);
+#pragma unroll
+          for (int z = 0; z < 4; ++z) a0 = fmaf(x0[q + z], t4[z], a0);
+        }
+      }
+      a0 = wave_sum(a0);
+      if (lane == 0) scores[out_map ? out_map[r0 + r] : r0 + r] = (a0 + cs) / sqrt_hd;
+    }
+  }
+  VSEL_STAMP_DRAIN(3, 3);
 }
 
 // -------------------------------------------------------------------------------------------------------------------------
 // P4  hard top-k + gather in one launch: every workgroup runs the segment's radix select itself, keeps the source rows of ITS
-//     output rows and copies them; workgroup 0 of a segment writes idx.  Keys live in registers (KPT per thread, N <= 256 KPT);
+//     output rows, writes their idx entries and copies them.  Keys live in registers (KPT per thread, N <= 256 KPT);
 //     wave w owns the CONTIGUOUS elements [w * span, (w + 1) * span), so the ordered compaction needs one exchange of wave
 //     totals instead of two barriers per 256 elements; the four histograms are separate LDS arrays zeroed once and every wave
 //     scans them itself: 7 barriers per workgroup in all.  Integer arithmetic only -> the same indices as topk_select_kernel
 //     (larger key first, then lower index).  grid (ceil(k / rows_per_block), S), block 256.
+//     Latency notes (tools/trace_small.py): the key loads are UNCONDITIONAL (clamped index) -- "load if in range" made hipcc
+//     wait for each of the 9 loads in turn (3.0 us to the first barrier); the bin scan is a DPP prefix sum (six dependent
+//     ds_bpermute round trips per pass before); the row copy keeps 8 x 16 B per thread in flight.
 // -------------------------------------------------------------------------------------------------------------------------
 template <typename T, int KPT>
 __global__ __launch_bounds__(256) void select_gather_small_kernel(const T* __restrict__ h, const float* __restrict__ scores,
@@ -350,43 +456,45 @@ __global__ __launch_bounds__(256) void select_gather_small_kernel(const T* __res
   __shared__ uint32_t wtot[NW][2];
   __shared__ int rows[64];
 
+  VSEL_STAMP(4, 0);
   const int kpw = (n + kSmallSelectThreads - 1) / kSmallSelectThreads;     // 64-element groups per wave (<= KPT)
   const int e0 = wave * kpw * 64 + lane;
   uint32_t key[KPT];
+  {
+    float raw[KPT];
 #pragma unroll
-  for (int j = 0; j < KPT; ++j) {
-    const int e = e0 + 64 * j;
-    key[j] = (j < kpw && e < n) ? order_key(sc[e]) : 0u;
+    for (int j = 0; j < KPT; ++j) raw[j] = sc[min(e0 + 64 * j, n - 1)];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) hist[p][tid] = 0;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) key[j] = (j < kpw && e0 + 64 * j < n) ? order_key(raw[j]) : 0u;
   }
-#pragma unroll
-  for (int p = 0; p < 4; ++p) hist[p][tid] = 0;
   __syncthreads();
+#ifdef VSEL_TRACE
+  asm volatile("" ::"v"(key[0]), "v"(key[KPT - 1]));
+#endif
+  VSEL_STAMP(4, 1);
   uint32_t prefix = 0, maskbits = 0, kk = (uint32_t)ko;
-#pragma unroll
-  for (int pass = 3; pass >= 0; --pass) {
+#pragma unroll 1
+  for (int pass = 3; pass >= 0; --pass) {        // NOT unrolled: the code of one pass is fetched once (instruction cache)
     const int shift = 8 * pass;
     uint32_t* hp = hist[pass];
 #pragma unroll
     for (int j = 0; j < KPT; ++j)
       if (j < kpw && e0 + 64 * j < n && (key[j] & maskbits) == prefix) atomicAdd(&hp[(key[j] >> shift) & 255u], 1u);
     __syncthreads();
-    // every wave finds the bin where the count from the top reaches kk (lane owns bins 4 lane .. 4 lane + 3)
-    const uint32_t c0 = hp[4 * lane], c1 = hp[4 * lane + 1], c2 = hp[4 * lane + 2], c3 = hp[4 * lane + 3];
-    const uint32_t tot = c0 + c1 + c2 + c3;
-    uint32_t suf = tot;                       // inclusive suffix sum over lanes
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t o = __shfl_down(suf, off, 64);
-      if (lane + off < 64) suf += o;
-    }
-    uint32_t run = suf - tot;
-    const uint32_t cs[4] = {c3, c2, c1, c0};
-    uint32_t found = 0xffffffffu;             // (bin << 16 is too small for kk) -> two words
+    // every wave finds the bin where the count from the top reaches kk.  Lane L owns bins 255 - 4 L .. 252 - 4 L (top first), so
+    // "keys in the bins above mine" is an exclusive prefix sum over the lanes
+    const u32x4 cv = *reinterpret_cast<const u32x4*>(&hp[252 - 4 * lane]);
+    const uint32_t cs[4] = {cv[3], cv[2], cv[1], cv[0]};
+    const uint32_t tot = cs[0] + cs[1] + cs[2] + cs[3];
+    uint32_t run = wave_prefix_sum_u32(tot) - tot;
+    uint32_t found = 0xffffffffu;
     uint32_t found_kk = 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       if (run < kk && run + cs[b] >= kk) {
-        found = 4 * lane + (3 - b);
+        found = 255 - 4 * lane - b;
         found_kk = kk - run;
       }
       run += cs[b];
@@ -399,47 +507,85 @@ __global__ __launch_bounds__(256) void select_gather_small_kernel(const T* __res
     maskbits |= 0xffu << shift;
   }
   const uint32_t thr = prefix, need = kk;
-  // ordered compaction: wave-local counts first, one exchange of the wave totals, then positions
+  VSEL_STAMP(4, 2);
+  // ordered compaction, only as far as THIS workgroup's output rows [jb, je) need it: positions are monotone in the element
+  // index, so a wave / a 64-element group whose position range misses [jb, je) is skipped with scalar arithmetic on the
+  // ballots (computing every position in every workgroup was 1.3 us).  Every workgroup writes the idx entries of its rows.
+  unsigned long long bgt[KPT], beq[KPT];
   uint32_t my_gt = 0, my_eq = 0;
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
     const bool valid = j < kpw && e0 + 64 * j < n;
-    my_gt += __popcll(__ballot(valid && key[j] > thr));
-    my_eq += __popcll(__ballot(valid && key[j] == thr));
+    bgt[j] = __ballot(valid && key[j] > thr);
+    beq[j] = __ballot(valid && key[j] == thr);
+    my_gt += __popcll(bgt[j]);
+    my_eq += __popcll(beq[j]);
   }
+  VSEL_STAMP(4, 5);
   if (lane == 0) { wtot[wave][0] = my_gt; wtot[wave][1] = my_eq; }
   __syncthreads();
+  VSEL_STAMP(4, 6);
   uint32_t run_gt = 0, run_eq = 0;
 #pragma unroll
   for (int wv = 0; wv < NW; ++wv)
     if (wv < wave) { run_gt += wtot[wv][0]; run_eq += wtot[wv][1]; }
-  const bool writer = blockIdx.x == 0;
+  run_gt = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_gt);
+  run_eq = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_eq);
   const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
-    if (j >= kpw) break;                      // uniform
-    const int e = e0 + 64 * j;
-    const bool valid = e < n;
-    const bool gt = valid && key[j] > thr;
-    const bool eq = valid && key[j] == thr;
-    const unsigned long long bgt = __ballot(gt), beq = __ballot(eq);
-    const uint32_t gt_before = run_gt + __popcll(bgt & below), eq_before = run_eq + __popcll(beq & below);
-    if (gt || (eq && eq_before < need)) {
-      const int pos = (int)(gt_before + min(eq_before, need));
-      if (writer) idx[ob + pos] = (int64_t)e;
-      if (pos >= jb && pos < je) rows[pos - jb] = e;
+    const uint32_t cg = (uint32_t)__popcll(bgt[j]), ce = (uint32_t)__popcll(beq[j]);
+    // selected elements of this group occupy positions [p0, p1)
+    const uint32_t p0 = run_gt + min(run_eq, need), p1 = run_gt + cg + min(run_eq + ce, need);
+    if (p1 > (uint32_t)jb && p0 < (uint32_t)je) {          // uniform
+      const int e = e0 + 64 * j;
+      const bool gt = (bgt[j] >> lane) & 1ull;
+      const bool eq = (beq[j] >> lane) & 1ull;
+      const uint32_t gt_before = run_gt + __popcll(bgt[j] & below), eq_before = run_eq + __popcll(beq[j] & below);
+      if (gt || (eq && eq_before < need)) {
+        const int pos = (int)(gt_before + min(eq_before, need));
+        if (pos >= jb && pos < je) {
+          rows[pos - jb] = e;
+          idx[ob + pos] = (int64_t)e;
+        }
+      }
     }
-    run_gt += __popcll(bgt);
-    run_eq += __popcll(beq);
+    run_gt += cg;
+    run_eq += ce;
   }
+  VSEL_STAMP(4, 7);
   __syncthreads();
-  for (int j = jb + wave; j < je; j += NW) {
-    const int64_t lsrc = rb + rows[j - jb];
-    const int64_t src = src_map ? src_map[lsrc] : lsrc;
-    const u32x4* sp = reinterpret_cast<const u32x4*>(h + src * d);
-    u32x4* dp = reinterpret_cast<u32x4*>(out + (ob + j) * d);
-    for (int v = lane; v < d / V; v += 64) dp[v] = sp[v];
+  VSEL_STAMP(4, 3);
+  // row copy: 4 rows x 2 column groups of 256 x 16 B in flight per thread (clamped duplicates past the end hit L1)
+  const int vpr = d / V;
+  for (int j0 = jb; j0 < je; j0 += 4) {
+    const u32x4* sp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t lsrc = rb + __builtin_amdgcn_readfirstlane(rows[min(j0 + u, je - 1) - jb]);
+      const int64_t src = src_map ? src_map[lsrc] : lsrc;
+      sp[u] = reinterpret_cast<const u32x4*>(h + src * d);
+    }
+    for (int v0 = 0; v0 < vpr; v0 += 512) {
+      const int va = v0 + tid, vb = v0 + 256 + tid;
+      const int vac = min(va, vpr - 1), vbc = min(vb, vpr - 1);
+      u32x4 xa[4], xb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xa[u] = sp[u][vac];
+        xb[u] = sp[u][vbc];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (j0 + u < je) {
+          u32x4* dp = reinterpret_cast<u32x4*>(out + (ob + j0 + u) * d);
+          if (va < vpr) dp[va] = xa[u];
+          if (vb < vpr) dp[vb] = xb[u];
+        }
+      }
+    }
   }
+  VSEL_STAMP_DRAIN(4, 4);
 }
 
 // -------------------------------------------------------------------------------------------------------------------------
@@ -486,14 +632,14 @@ inline int run_score_small(hipStream_t st, const T* h, const vsel_segments* seg,
   const int iters = (d % (64 * V) == 0) ? d / (64 * V) : 0;
 #define VSEL_SCORE_SMALL_CASE(I)                                                                                          \
   case I:                                                                                                                 \
-    hipLaunchKernelGGL((score_small_kernel<T, I>), grid, dim3(256), lds, st, h, make_view(seg), d, S, part2, p.ks2, cpart, \
+    hipLaunchKernelGGL((score_small_kernel<T, I>), grid, dim3(kSmallScoreThreads), lds, st, h, make_view(seg), d, S, part2, p.ks2, cpart, \
                        p.n_cpart, sq, (int)rpb, scores, out_map);                                                         \
     break;
   switch (iters) {
     VSEL_SCORE_SMALL_CASE(1) VSEL_SCORE_SMALL_CASE(2) VSEL_SCORE_SMALL_CASE(3) VSEL_SCORE_SMALL_CASE(4)
     VSEL_SCORE_SMALL_CASE(5) VSEL_SCORE_SMALL_CASE(6) VSEL_SCORE_SMALL_CASE(7) VSEL_SCORE_SMALL_CASE(8)
     default:
-      hipLaunchKernelGGL((score_small_kernel<T, 0>), grid, dim3(256), lds, st, h, make_view(seg), d, S, part2, p.ks2, cpart,
+      hipLaunchKernelGGL((score_small_kernel<T, 0>), grid, dim3(kSmallScoreThreads), lds, st, h, make_view(seg), d, S, part2, p.ks2, cpart,
                          p.n_cpart, sq, (int)rpb, scores, out_map);
   }
 #undef VSEL_SCORE_SMALL_CASE

@@ -295,8 +295,8 @@ def test_permuted_select_equals_unreorder_then_select(ops):
     assert float((got[2] - ref[2]).abs().max()) <= 4e-6 * max(1.0, float(ref[2].abs().max()))
 
 
-def _small_path(lib, on, default=2):
-    """on: the small-batch form for up to 8 segments (the library default is 2); off: never; restore with on=None."""
+def _small_path(lib, on, default=4):
+    """on: the small-batch form for up to 8 segments (the library default is 4); off: never; restore with on=None."""
     import ctypes
     lib.vsel_debug_set_small_path(ctypes.c_int(default if on is None else (8 if on else 0)))
 

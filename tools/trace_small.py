@@ -18,13 +18,14 @@ sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "tools", "libvsel_trace.so")
 
 KERNELS = ["sweep 1 (colsum_partial)", "kbar projection (proj_nt_small)", "w projection (proj_nn_small)",
-           "sweep 2 (score_small)", "select + gather (select_gather_small)"]
+           "sweep 2 (score_small)", "select + gather (select_gather_small)", "select + gather: radix passes"]
 SLOTS = [["start", "rows summed", "end (stores drained)"],
          ["start", "xbar slice in LDS", "MFMA done", "end (stores drained)"],
          ["start", "kbar slice in LDS", "MFMA done", "end (stores drained)"],
          ["start", "w in LDS", "c reduced", "end (stores drained)"],
          ["start", "keys in registers", "threshold found", "rows known", "end (stores drained)", "ballots done",
-          "wave totals exchanged", "positions written"]]
+          "wave totals exchanged", "positions written"],
+         ["pass bits 7:0 done", "pass bits 15:8 done", "pass bits 23:16 done", "pass bits 31:24 done"]]
 
 
 def build():
@@ -77,7 +78,7 @@ def main():
     for r in runs:
         t0 = r[0][..., 0][r[0][..., 0] > 0].min()
         call = []
-        for kern in range(5):
+        for kern in range(len(KERNELS)):
             live = r[kern][:, 0] > 0
             st = r[kern][live]
             nslot = len(SLOTS[kern])
@@ -86,7 +87,7 @@ def main():
             med = [(np.median(st[:, s]) - t0) / 100.0 for s in range(nslot)]
             call.append((int(live.sum()), first, med, last))
         rows.append(call)
-    for kern in range(5):
+    for kern in range(len(KERNELS)):
         wgs = rows[0][kern][0]
         print(f"\n{KERNELS[kern]}: {wgs} workgroups")
         for s, name in enumerate(SLOTS[kern]):

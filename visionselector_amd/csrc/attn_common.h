@@ -78,7 +78,6 @@ __device__ __forceinline__ int slice_src_part(int lane, int wave) { return (lane
 // direct-to-LDS prefetch of the next tile.  The reads are therefore issued from inline asm in BATCHES (8 per batch, the next
 // batch in flight behind the MFMAs of the current one) with counted lgkmcnt waits that name the batch's registers
 // (cdna_hip_programming.md 5.7, form (ii)) followed by sched_barrier(0) so that no MFMA is hoisted above its wait (rule 18).
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t lds_u32(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }

@@ -60,12 +60,12 @@ static int g_pipeline_enabled = [] {
 extern "C" void vsel_debug_set_pipeline(int on) { g_pipeline_enabled = on; }
 
 // small-batch form (lis_small.h): used up to g_small_path_max_seg segments per call.  Measured on MI355X (Qwen2.5-VL-7B geometry,
-// us per call, small form vs batched form): 1 image 46.5 vs 51.7, 2 images 54.3 vs 55.8, 4 images 73.4 vs 65.5, 8 images 108.6 vs
-// 86.3 -- the redundant prologues grow with the segment count, so the default limit is 2.  VSEL_SMALL_PATH=<n> /
-// vsel_debug_set_small_path(n) set the limit (0 = never; at most kSmallMaxSeg).
+// us per call, small form vs batched form): 1 image 36.2 vs 51.7, 2 images 43.8 vs 55.8, 3 images 52.2 vs 60.8, 4 images 60.4 vs
+// 65.3, 8 images 102.3 vs 86.2 -- the redundant prologues grow with the segment count, so the default limit is 4.
+// VSEL_SMALL_PATH=<n> / vsel_debug_set_small_path(n) set the limit (0 = never; at most kSmallMaxSeg).
 static int g_small_path_max_seg = [] {
   const char* e = getenv("VSEL_SMALL_PATH");
-  const int v = e ? atoi(e) : 2;
+  const int v = e ? atoi(e) : 4;
   return v < 0 ? 0 : (v > kSmallMaxSeg ? kSmallMaxSeg : v);
 }();
 extern "C" void vsel_debug_set_small_path(int max_seg) {

@@ -568,6 +568,107 @@ static __global__ __launch_bounds__(1024) void topk_select_kernel(const float* _
   }
 }
 
+// K5r  the same select with the keys held in registers (N <= 1024 KPT): one unconditional (clamped) load per key instead of a
+//      reload in each of the five sweeps, every wave scans the 256 bins itself with a DPP prefix sum (no broadcast through LDS,
+//      one barrier per pass instead of three), wave w owns the contiguous elements [w span, (w + 1) span) so the ordered
+//      compaction needs one exchange of wave totals.  Integer arithmetic only: the same indices / mask as topk_select_kernel.
+//      tools/trace_small.py found the per-key "load if in range", the ds_bpermute scan and the per-sweep reloads to be most of
+//      the 8.5-8.9 us the generic kernel takes per call.
+template <int KPT>
+__global__ __launch_bounds__(1024) void topk_select_reg_kernel(const float* __restrict__ scores, SegView sv,
+                                                               int64_t* __restrict__ idx, float* __restrict__ mask) {
+  constexpr int NW = 16;
+  const int s = blockIdx.x;
+  const int n = sv.n_rows(s);
+  const int k = min(sv.n_out(s), n);
+  const float* sc = scores + sv.row_begin(s);
+  int64_t* out = idx ? idx + sv.out_begin(s) : nullptr;
+  float* mk = mask ? mask + sv.row_begin(s) : nullptr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  __shared__ uint32_t hist[4][256];
+  __shared__ uint32_t wtot[NW][2];
+
+  if (n <= 0) return;
+  if (k <= 0) {                                      // nothing kept (the API rejects k < 1; ragged calls may carry an empty output)
+    if (mk) for (int i = tid; i < n; i += 1024) mk[i] = 0.f;
+    return;
+  }
+  const int kpw = (n + 1023) / 1024;                 // 64-element groups per wave (<= KPT)
+  const int e0 = wave * kpw * 64 + lane;
+  uint32_t key[KPT];
+  {
+    float raw[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) raw[j] = sc[min(e0 + 64 * j, n - 1)];
+    hist[tid >> 8][tid & 255] = 0;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) key[j] = (j < kpw && e0 + 64 * j < n) ? order_key(raw[j]) : 0u;
+  }
+  __syncthreads();
+  uint32_t prefix = 0, maskbits = 0, kk = (uint32_t)k;
+#pragma unroll 1
+  for (int pass = 3; pass >= 0; --pass) {
+    const int shift = 8 * pass;
+    uint32_t* hp = hist[pass];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j)
+      if (j < kpw && e0 + 64 * j < n && (key[j] & maskbits) == prefix) atomicAdd(&hp[(key[j] >> shift) & 255u], 1u);
+    __syncthreads();
+    // lane L owns bins 255 - 4 L .. 252 - 4 L (top first): "keys in the bins above mine" is an exclusive prefix sum over lanes
+    const u32x4 cv = *reinterpret_cast<const u32x4*>(&hp[252 - 4 * lane]);
+    const uint32_t cs[4] = {cv[3], cv[2], cv[1], cv[0]};
+    const uint32_t tot = cs[0] + cs[1] + cs[2] + cs[3];
+    uint32_t run = wave_prefix_sum_u32(tot) - tot;
+    uint32_t found = 0xffffffffu, found_kk = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (run < kk && run + cs[b] >= kk) {
+        found = 255 - 4 * lane - b;
+        found_kk = kk - run;
+      }
+      run += cs[b];
+    }
+    const unsigned long long who = __ballot(found != 0xffffffffu);      // exactly one lane (k >= 1)
+    const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)who) - 1);
+    const uint32_t bin = (uint32_t)__builtin_amdgcn_readlane((int)found, src);
+    kk = (uint32_t)__builtin_amdgcn_readlane((int)found_kk, src);
+    prefix |= bin << shift;
+    maskbits |= 0xffu << shift;
+  }
+  const uint32_t thr = prefix, need = kk;
+  unsigned long long bgt[KPT], beq[KPT];
+  uint32_t my_gt = 0, my_eq = 0;
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const bool valid = j < kpw && e0 + 64 * j < n;
+    bgt[j] = __ballot(valid && key[j] > thr);
+    beq[j] = __ballot(valid && key[j] == thr);
+    my_gt += __popcll(bgt[j]);
+    my_eq += __popcll(beq[j]);
+  }
+  if (lane == 0) { wtot[wave][0] = my_gt; wtot[wave][1] = my_eq; }
+  __syncthreads();
+  uint32_t run_gt = 0, run_eq = 0;
+#pragma unroll
+  for (int wv = 0; wv < NW; ++wv)
+    if (wv < wave) { run_gt += wtot[wv][0]; run_eq += wtot[wv][1]; }
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const int e = e0 + 64 * j;
+    const bool valid = j < kpw && e < n;
+    const bool gt = (bgt[j] >> lane) & 1ull;
+    const bool eq = (beq[j] >> lane) & 1ull;
+    const uint32_t gt_before = run_gt + __popcll(bgt[j] & below), eq_before = run_eq + __popcll(beq[j] & below);
+    const bool sel = gt || (eq && eq_before < need);
+    if (sel && out) out[gt_before + min(eq_before, need)] = (int64_t)e;
+    if (valid && mk) mk[e] = sel ? 1.0f : 0.0f;
+    run_gt += __popcll(bgt[j]);
+    run_eq += __popcll(beq[j]);
+  }
+}
+
 // =================================================================================================
 // K6  row gather out[ob + j] = h[rb + idx[ob + j]].  grid (row_chunks, n_seg), block 256, wave per row.
 // =================================================================================================
@@ -817,7 +918,13 @@ inline int run_scores_w(hipStream_t st, const T* h, const vsel_segments* seg, co
 }
 
 inline int launch_select(hipStream_t st, const float* scores, const vsel_segments* seg, int64_t* idx, float* mask) {
-  hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)seg->n_seg), dim3(1024), 0, st, scores, make_view(seg), idx, mask);
+  const int64_t maxn = seg->rows_per_seg;            // (= the longest segment for ragged calls)
+  if (maxn <= 4 * 1024)
+    hipLaunchKernelGGL(topk_select_reg_kernel<4>, dim3((unsigned)seg->n_seg), dim3(1024), 0, st, scores, make_view(seg), idx, mask);
+  else if (maxn <= 16 * 1024)
+    hipLaunchKernelGGL(topk_select_reg_kernel<16>, dim3((unsigned)seg->n_seg), dim3(1024), 0, st, scores, make_view(seg), idx, mask);
+  else
+    hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)seg->n_seg), dim3(1024), 0, st, scores, make_view(seg), idx, mask);
   VSEL_AFTER_LAUNCH(st, "topk_select_kernel");
   return VSEL_OK;
 }

@@ -64,17 +64,25 @@ struct PagedKV {
 // tiles between them (group g takes tiles g, g + 2, ...; each group streams its own K/V tiles through its own LDS buffers),
 // then merge their online-softmax states through LDS -- the dependent chain of KV tiles, which is what a single short
 // sequence costs, is halved (L' = 524: 9 tiles -> 5).
-template <bool USE_TR, int NW, int D, bool PACK = false, int KVS = 1>
+// KH = 2 (with KVS = 2, one short sequence): 64 queries per workgroup, and the two waves that share a 32-query slice inside a
+// KV stream take one 32-key block of every tile each (four partial softmax states per slice, merged at the end).
+// tools/trace_attn.py on L' = 524: with 128-query workgroups a round costs 2.35 us -- two waves per SIMD run the same phase at
+// the same time and their MFMA and VALU time add up -- while 116 of the 256 CUs have no workgroup (140 workgroups); key halves
+// halve the work of a wave per round and 64-query workgroups use 252 CUs.
+template <bool USE_TR, int NW, int D, bool PACK = false, int KVS = 1, int KH = 1>
 __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                               const uint16_t* __restrict__ v,
                                                               const int32_t* __restrict__ cu, int hq, int hkv,
                                                               float scale_log2e, int causal, uint16_t* __restrict__ out,
                                                               int q_tiles, int n_seq, int slot, PagedKV pg,
                                                               float* __restrict__ lse) {
-  constexpr int GW = NW / KVS;                     // waves that share one K/V stream (and cover kBlockQ queries)
-  constexpr int kBlockQ = 32 * GW;
+  constexpr int GW = NW / KVS;                     // waves that share one K/V stream
+  constexpr int QW = GW / KH;                      // ... of which QW own distinct 32-query slices (KH waves per slice)
+  constexpr int kBlockQ = 32 * QW;
   constexpr int kLoadsPerWave = 16 / GW;           // 1-KiB wave-instructions per tile per tensor
+  constexpr int NKB = 2 / KH;                      // 32-key blocks of a tile that one wave computes
   static_assert(KVS == 1 || (KVS == 2 && NW == 8 && !PACK), "two KV streams need 8 waves");
+  static_assert(KH == 1 || (KH == 2 && KVS == 2 && USE_TR && D == 128), "key halves: only in the two-stream form");
   constexpr int kHeadDim = D;
   constexpr int kSteps = D / 16;                   // k-steps of S^T = K Q^T
   constexpr int kDTiles = (D + 31) / 32;           // 32-wide d-tiles of O^T
@@ -94,8 +102,11 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   const int64_t v_rs = pg.v_row_stride ? pg.v_row_stride : kv_rs;
   const int64_t v_hs = pg.v_row_stride ? pg.v_head_stride : kv_hs;
   const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
-  const int grp = KVS == 1 ? 0 : wave_all / GW;                // KV stream of this wave
-  const int wave = KVS == 1 ? wave_all : wave_all % GW;        // wave inside its group
+  const int grp = KVS == 1 ? 0 : __builtin_amdgcn_readfirstlane(wave_all / GW);      // KV stream of this wave (uniform)
+  const int wave = KVS == 1 ? wave_all : wave_all % GW;        // wave inside its group (its share of the tile loads)
+  const int qw = wave % QW;                                    // its 32-query slice
+  const int kh = KH == 1 ? 0 : __builtin_amdgcn_readfirstlane(wave / QW);   // its 32-key block of every tile (KH = 2)
+  const int pidx = grp * KH + kh;                              // which partial softmax state of the slice it carries
   const int j = lane & 31, hh = lane >> 5;
   char* const k_sm = smem + grp * kLds;
   char* const v_sm = k_sm + 2 * kBuf;
@@ -118,6 +129,13 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   for (int st = 0; st < kSteps; ++st) row_addr_u[st] = lds_u32(smem) + row_addr[st];
 #pragma unroll
   for (int dt = 0; dt < kDTiles; ++dt) { tr_addr_u[dt][0] = lds_u32(smem) + tr_addr[dt][0]; tr_addr_u[dt][1] = lds_u32(smem) + tr_addr[dt][1]; }
+  if constexpr (KH == 2) {                                     // key halves: the wave reads only tile rows 32 kh .. 32 kh + 31
+    const uint32_t blk = (uint32_t)(wave / QW) * 32u * kRowBytes;
+#pragma unroll
+    for (int st = 0; st < kSteps; ++st) row_addr_u[st] += blk;
+#pragma unroll
+    for (int dt = 0; dt < kDTiles; ++dt) { tr_addr_u[dt][0] += blk; tr_addr_u[dt][1] += blk; }
+  }
   // direct-to-LDS loads: wave w issues wave-instructions w, w + NW, ...; instruction i covers tile rows 4i .. 4i+3, lane l
   // lands at (row 4i + (l >> 4), position l & 15) and therefore fetches global part (l & 15) ^ swz(row)
   // (a source part past the row's data, head_dim < 128, is redirected to part 0: its LDS position is never read for S and only
@@ -140,7 +158,9 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
     item = s_item;
     __syncthreads();
   }
+  item = __builtin_amdgcn_readfirstlane(item);      // (uniform by construction; lets the address arithmetic run on the scalar ALU)
   if (item >= n_items) return;
+  VSEL_STAMP(0, 0);
   int qtile, head, seq, kvh;
   if constexpr (PACK) {
     qtile = 0;
@@ -163,11 +183,11 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   const int len = pg.seqlens_k ? pg.seqlens_k[seq] : qlen;
   const int shift = len - qlen;
   const int ks = pg.cu_k ? pg.cu_k[seq] : qs;
-  const int vq = PACK ? j / rep : q0 + wave * 32 + j;         // this lane's query
+  const int vq = PACK ? j / rep : q0 + qw * 32 + j;           // this lane's query
   const int my_q = min(vq, qlen - 1);                         // clamped: padding lanes replay the last query
   const bool q_valid = vq < qlen;
-  const int wave_qmax = PACK ? qlen - 1 : min(q0 + wave * 32 + 31, qlen - 1);
-  const int wave_qmin = PACK ? 0 : q0 + wave * 32;
+  const int wave_qmax = PACK ? qlen - 1 : min(q0 + qw * 32 + 31, qlen - 1);
+  const int wave_qmin = PACK ? 0 : q0 + qw * 32;
 
   // Q^T fragments (B operand of S^T = K Q^T): lane (j, hh) holds q[my_q][16*step + 8*hh .. +7]
   u32x4 qf[kSteps];
@@ -198,30 +218,49 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
 
   const int64_t kv_base = (int64_t)ks * hkv * kHeadDim + kvh * kv_hs;            // contiguous keys: row r adds r * kv_rs
   const int64_t v_base = (int64_t)ks * hkv * kHeadDim + kvh * v_hs;
+  // Fast path (contiguous keys, full tile): the address of a slice is a wave-uniform 64-bit row base (scalar ALU) plus a
+  // per-lane 32-bit byte offset that is computed ONCE per item -- tools/trace_attn.py measured 0.9-1.3 us per tile spent
+  // ISSUING the 16 direct-to-LDS loads of a 2-wave group when every load carried its own 64-bit multiplies and the branches
+  // of the paged / tail form.
+  constexpr int NP = GW >= 4 ? 1 : 4 / GW;                     // distinct swizzle keys (i & 3) among a wave's slices
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  uint32_t lane_off_k[NP], lane_off_v[NP];
+#pragma unroll
+  for (int pp = 0; pp < NP; ++pp) {
+    const int part8 = src_part8(wave + GW * pp);
+    lane_off_k[pp] = (uint32_t)(((int64_t)(lane >> 4) * kv_rs + part8) * 2);
+    lane_off_v[pp] = (uint32_t)(((int64_t)(lane >> 4) * v_rs + part8) * 2);
+  }
   auto load_tile = [&](int t, int buf) {
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     const bool tail = __builtin_amdgcn_readfirstlane((int)(t * kTileK + kTileK > len)) != 0;
+    if (!pg.block_table && !tail) {
+#pragma unroll
+      for (int u = 0; u < kLoadsPerWave; ++u) {
+        const int i = wave_u + GW * u;
+        const int64_t row = (int64_t)(t * kTileK + 4 * i);
+        const char* kp = reinterpret_cast<const char*>(k + kv_base + row * kv_rs);
+        const char* vp = reinterpret_cast<const char*>(v + v_base + row * v_rs);
+        __builtin_amdgcn_global_load_lds((gptr_t)(kp + lane_off_k[u % NP]), (lptr_t)(k_sm + buf * kBuf + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vp + lane_off_v[u % NP]), (lptr_t)(v_sm + buf * kBuf + i * 1024), 16, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < kLoadsPerWave; ++u) {
       const int i = wave + GW * u;
       const int key = 4 * i + (lane >> 4);
-      int64_t off, off_v;
-      if (!pg.block_table && !tail) {
-        off = kv_base + (int64_t)(t * kTileK + key) * kv_rs + src_part8(i);
-        off_v = v_base + (int64_t)(t * kTileK + key) * v_rs + src_part8(i);
+      const int kpos = min(t * kTileK + key, len - 1);
+      int64_t row;
+      if (pg.block_table) {
+        const int page = kpos / pg.page_size;
+        row = (int64_t)pg.block_table[(int64_t)seq * pg.max_pages + page] * pg.page_size + (kpos - page * pg.page_size);
       } else {
-        const int kpos = min(t * kTileK + key, len - 1);
-        int64_t row;
-        if (pg.block_table) {
-          const int page = kpos / pg.page_size;
-          row = (int64_t)pg.block_table[(int64_t)seq * pg.max_pages + page] * pg.page_size + (kpos - page * pg.page_size);
-        } else {
-          row = kpos;
-        }
-        off = (pg.block_table ? (row * hkv + kvh) * kHeadDim : kv_base + row * kv_rs) + src_part8(i);
-        off_v = (pg.block_table ? (row * hkv + kvh) * kHeadDim : v_base + row * v_rs) + src_part8(i);
+        row = kpos;
       }
+      const int64_t off = (pg.block_table ? (row * hkv + kvh) * kHeadDim : kv_base + row * kv_rs) + src_part8(i);
+      const int64_t off_v = (pg.block_table ? (row * hkv + kvh) * kHeadDim : v_base + row * v_rs) + src_part8(i);
       __builtin_amdgcn_global_load_lds((gptr_t)(k + off), (lptr_t)(k_sm + buf * kBuf + i * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(v + off_v), (lptr_t)(v_sm + buf * kBuf + i * 1024), 16, 0, 0);
     }
@@ -230,19 +269,22 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
   const int n_rounds = (n_tiles + KVS - 1) / KVS;
   if (grp < n_tiles) load_tile(grp, 0);
   __syncthreads();
+  VSEL_STAMP(0, 1);
 
   // one 64-key tile from LDS buffer CUR (compile-time, so that every LDS address is a per-lane base + an immediate)
   auto tile_body = [&](auto cur_c, int t) {
     constexpr int CUR = decltype(cur_c)::value;
     // a wave whose 32 query slots are all padding (short q-tiles: decode, ragged tails) only helps with the loads
-    const bool wave_active = (wave_qmin < qlen) && (!causal || (t * kTileK <= wave_qmax + shift));
+    // (KH = 2: the wave's own 32-key block must hold a visible key)
+    const int kblk0 = t * kTileK + 32 * kh;
+    const bool wave_active = (wave_qmin < qlen) && (!causal || (kblk0 <= wave_qmax + shift)) && (KH == 1 || kblk0 < len);
     if (wave_active) {
       const char* kt = smem + CUR * kBuf;
       const char* vt = smem + (2 + CUR) * kBuf;
       // ---- S^T = K Q^T ----------------------------------------------------------------------------------------
-      f32x16 s[2];
+      f32x16 s[NKB];                    // s[b]: key block b (KH = 1) / the wave's own key block kh (KH = 2)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
       if constexpr (USE_TR && kSteps == 8 && !PACK) {
@@ -250,6 +292,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
         // of one per MFMA; a second batch in flight would need 32 more registers and spills)
         auto s_block = [&](auto kb_c) {
           constexpr int KB = decltype(kb_c)::value;
+          constexpr int SI = KH == 1 ? KB : 0;
           if constexpr (NW >= 8) {
             u32x4 ka[8];
 #pragma unroll
@@ -257,7 +300,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
             lds_wait8<0>(ka);
 #pragma unroll
             for (int st = 0; st < 8; ++st)
-              s[KB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(ka[st]), to_bf16x8(qf[st]), s[KB], 0, 0, 0);
+              s[SI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(ka[st]), to_bf16x8(qf[st]), s[SI], 0, 0, 0);
           } else {
             // 4-wave workgroups stage twice the tile rows per wave (more address state): batches of 4 keep the kernel spill-free
 #pragma unroll
@@ -268,12 +311,12 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
               lds_wait4<0>(ka);
 #pragma unroll
               for (int st = 0; st < 4; ++st)
-                s[KB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(ka[st]), to_bf16x8(qf[4 * h4 + st]), s[KB], 0, 0, 0);
+                s[SI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(ka[st]), to_bf16x8(qf[4 * h4 + st]), s[SI], 0, 0, 0);
             }
           }
         };
-        s_block(std::integral_constant<int, 0>{});
-        s_block(std::integral_constant<int, 1>{});
+        s_block(std::integral_constant<int, 0>{});          // (KH = 2: the per-lane bases already point at the wave's own key block)
+        if constexpr (KH == 1) s_block(std::integral_constant<int, 1>{});
       } else {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -300,9 +343,9 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
       float mx = -INFINITY;
       if (need_mask) {
         const int kmax = causal ? min(len - 1, my_q + shift) : len - 1;     // last visible key of this lane's query
-        const int kbase0 = t * kTileK + 8 * hh;
+        const int kbase0 = t * kTileK + 8 * hh + (KH == 1 ? 0 : 32 * kh);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = kbase0 + 32 * kb + 16 * (r >> 3) + (r & 7);
@@ -312,7 +355,7 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
           }
       } else {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
       }
@@ -328,9 +371,9 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
           for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
       }
       float psum = 0.f;
-      bf16x8_t pf[2][2];
+      bf16x8_t pf[NKB][2];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], scale_log2e, -m_run));
@@ -356,12 +399,19 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
             const u32x4 w = {src[2 * dt][0], src[2 * dt][1], src[2 * dt + 1][0], src[2 * dt + 1][1]};
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(w), pf[G >> 1][G & 1], o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(w), pf[KH == 1 ? (G >> 1) : 0][G & 1], o[dt], 0, 0, 0);
           }
         };
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-        if constexpr (NW >= 8) {
+        if constexpr (KH == 2) {
+          // the wave's own key block = two 16-key groups (the first was issued before the softmax)
+          issue(I1{}, vr1);
+          lds_wait8<8>(vr0);
+          pv(I0{}, vr0);
+          lds_wait8<0>(vr1);
+          pv(I1{}, vr1);
+        } else if constexpr (NW >= 8) {
           issue(I1{}, vr1);                    // (group 0 was issued before the softmax)
           lds_wait8<8>(vr0);
           pv(I0{}, vr0);
@@ -421,56 +471,95 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
     for (int r = 0; r < n_rounds; r += 2) {
       const int t0 = KVS * r + grp, t1 = t0 + KVS, t2 = t1 + KVS;
       if (t1 < n_tiles) load_tile(t1, 1);
+      VSEL_STAMP(3, min(r, 7));
       if (t0 < n_tiles) tile_body(std::integral_constant<int, 0>{}, t0);
+      VSEL_STAMP(2, min(r, 7));
       __syncthreads();
+      VSEL_STAMP(1, min(r, 7));
       if (r + 1 >= n_rounds) break;
       if (t2 < n_tiles) load_tile(t2, 0);
+      VSEL_STAMP(3, min(r + 1, 7));
       if (t1 < n_tiles) tile_body(std::integral_constant<int, 1>{}, t1);
+      VSEL_STAMP(2, min(r + 1, 7));
       __syncthreads();
+      VSEL_STAMP(1, min(r + 1, 7));
     }
   }
+  VSEL_STAMP(0, 2);
 
+  constexpr int P = KVS * KH;              // partial online-softmax states per 32-query slice
   if constexpr (KVS == 2) {
-    // merge the two groups' online-softmax states: group 1 publishes (m, l, O) through LDS (the tile buffers are free now),
-    // group 0 rescales both to the common maximum and adds
+    // merge the P partial states of a slice (one per KV stream and key half), all P waves at once: partial p OWNS the d-tiles
+    // dt with dt % P == p.  Every wave publishes (m, l) and the O rows of the d-tiles it does not own through LDS (the tile
+    // buffers are free now), then rescales its own d-tiles to the common maximum, adds the others' in index order and stores
+    // those columns.  (One wave merging everything serially and storing whole rows cost 3.1 us of the 15 at L' = 524.)
+    static_assert(kDTiles % P == 0, "d-tiles are dealt out evenly to the partials");
     float* ex = reinterpret_cast<float*>(smem);
-    constexpr int kState = kDTiles * 16 + 2;
+    constexpr int kPub = 2 + 16 * (kDTiles - kDTiles / P);      // floats a wave publishes per lane
+    static_assert((size_t)P * QW * kPub * 64 * sizeof(float) <= (size_t)KVS * kLds, "merge area exceeds the tile buffers");
+    auto pub_pos = [&](int p, int dt) {      // index of d-tile dt (not owned by p) among p's published d-tiles
+      return (dt / P) * (P - 1) + (dt % P) - ((dt % P) > p ? 1 : 0);
+    };
     __syncthreads();
-    if (grp == 1) {
-      float* mine = ex + (size_t)wave * kState * 64 + lane;
+    {
+      float* mine = ex + ((size_t)(pidx * QW + qw) * kPub) * 64 + lane;
       mine[0] = m_run;
       mine[64] = l_run;
 #pragma unroll
-      for (int dt = 0; dt < kDTiles; ++dt)
+      for (int dt = 0; dt < kDTiles; ++dt) {
+        if (dt % P == pidx) continue;        // uniform
+        const int pos = pub_pos(pidx, dt);
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) mine[(2 + dt * 16 + rr) * 64] = o[dt][rr];
+        for (int rr = 0; rr < 16; ++rr) mine[(2 + pos * 16 + rr) * 64] = o[dt][rr];
+      }
     }
     __syncthreads();
-    if (grp == 1) continue;                  // (both groups took the same path up to here; group 0 stores the result)
-    const float* other = ex + (size_t)wave * kState * 64 + lane;
-    const float m1 = other[0], l1 = other[64];
-    const float m_new = fmaxf(m_run, m1);
-    const float a0 = __builtin_amdgcn_exp2f(m_run - m_new), a1 = __builtin_amdgcn_exp2f(m1 - m_new);
-    m_run = m_new;
-    l_run = l_run * a0 + l1 * a1;
+    float a[P];
+    float m_max = m_run;
 #pragma unroll
-    for (int dt = 0; dt < kDTiles; ++dt)
+    for (int pp = 0; pp < P; ++pp) {
+      a[pp] = ex[((size_t)(pp * QW + qw) * kPub) * 64 + lane];                  // m of partial pp
+      m_max = fmaxf(m_max, a[pp]);
+    }
+    float l_sum = 0.f;
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) o[dt][rr] = o[dt][rr] * a0 + other[(2 + dt * 16 + rr) * 64] * a1;
+    for (int pp = 0; pp < P; ++pp) {
+      a[pp] = __builtin_amdgcn_exp2f(a[pp] - m_max);
+      l_sum += ex[((size_t)(pp * QW + qw) * kPub + 1) * 64 + lane] * a[pp];
+    }
+    m_run = m_max;
+    l_run = l_sum;
+#pragma unroll
+    for (int dt = 0; dt < kDTiles; ++dt) {
+      if (dt % P != pidx) continue;          // uniform
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        float acc = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+          const float v = (pp == pidx) ? o[dt][rr]
+                                       : ex[((size_t)(pp * QW + qw) * kPub + 2 + pub_pos(pp, dt) * 16 + rr) * 64 + lane];
+          acc += v * a[pp];
+        }
+        o[dt][rr] = acc;
+      }
+    }
   }
 
+  VSEL_STAMP(0, 3);
   // ---- epilogue: O^T[d][query] / l, 4 consecutive d per store ------------------------------------------------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;      // a row that sees no key (klen < qlen) outputs zeros
   if (q_valid) {
     // log-sum-exp of the scaled scores (natural log), saved for the backward pass; -inf for a row without a visible key
-    if (lse && hh == 0)
+    if (lse && hh == 0 && pidx == 0)
       lse[(int64_t)(qs + my_q) * hq + head] = l_tot > 0.f ? (m_run + log2f(l_tot)) * 0.6931471805599453f : -INFINITY;
     uint16_t* op = out + ((int64_t)(qs + my_q) * hq + head) * kHeadDim;
 #pragma unroll
     for (int dt = 0; dt < kDTiles; ++dt)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
+        if (P > 1 && dt % P != pidx) continue;        // (two-stream form: every partial stores the d-tiles it owns)
         const int d0 = 32 * dt + 8 * g4 + 4 * hh;
         if (d0 >= kHeadDim) continue;                 // head_dim 80: the last d-tile is half padding
         const uint32_t w0 = f32_to_bf16_bits(o[dt][4 * g4] * inv) | (f32_to_bf16_bits(o[dt][4 * g4 + 1] * inv) << 16);
@@ -481,12 +570,25 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
         *reinterpret_cast<uint2*>(op + d0) = pk;
       }
   }
+  VSEL_STAMP_DRAIN(0, 4);
   }  // persistent item loop
 }
 
 }  // namespace vsel
 
 using namespace vsel;
+
+#ifdef VSEL_TRACE
+// copies the stamps of the last forward launch: out[kTraceKernels][kTraceBlocks][kTraceSlots] (tools/trace_attn.py)
+extern "C" int vsel_debug_read_attn_trace(unsigned long long* out, int clear) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(g_trace)) != hipSuccess) return VSEL_ERR_HIP;
+  if (clear) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_trace)) != hipSuccess || hipMemset(p, 0, sizeof(g_trace)) != hipSuccess) return VSEL_ERR_HIP;
+  }
+  return VSEL_OK;
+}
+#endif
 
 static bool g_attn_use_tr = true;
 static int g_attn_nw = 0;      // 0 = choose by grid size, 4 / 8 = force the workgroup size
@@ -496,6 +598,8 @@ static int g_attn_pack = 2;    // 0 = never, 1 = whenever qlen * rep <= 32, 2 (d
 extern "C" void vsel_debug_attn_pack(int mode) { g_attn_pack = mode; }
 static int g_attn_split = 2;   // 0 = never, 1 = whenever the 4-wave grid has <= 256 items, 2 (default) = ... and the sequences are not tiny
 extern "C" void vsel_debug_attn_split(int mode) { g_attn_split = mode; }
+static bool g_attn_split_q64 = true;   // 64-query workgroups for the two-stream form when they fit one per CU
+extern "C" void vsel_debug_attn_split_q64(int on) { g_attn_split_q64 = on != 0; }
 
 static int attn_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
                        int64_t max_seqlen_q, int64_t hq, int64_t hkv, int64_t d, float scale, int causal, void* out,
@@ -516,7 +620,9 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   // results do not depend on what it is packed with" bit for bit)
   const bool split2 = g_attn_split != 0 && d == 128 && !pack && !big && g_attn_nw == 0 && g_attn_use_tr && items4 <= 256 &&
                       (g_attn_split == 1 || (lse == nullptr && (pg.seqlens_k != nullptr || max_seqlen_q >= 256)));
-  const int block_q = big ? 256 : 128;
+  // ... and 64-query workgroups whose wave pairs split every tile's keys (KH = 2) while those still fit one per CU
+  const bool split2_q64 = split2 && g_attn_split_q64 && cdiv(max_seqlen_q, 64) * hq * n_seq <= 256;
+  const int block_q = big ? 256 : (split2_q64 ? 64 : 128);
   const int q_tiles = (int)cdiv(max_seqlen_q, block_q);
   const int64_t n_items = pack ? hkv * n_seq : (int64_t)q_tiles * hq * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
@@ -534,7 +640,11 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
 #define VSEL_ATTN_LAUNCH(TR, NWV, DV)                                                                                          \
   hipLaunchKernelGGL((varlen_attn_fwd_kernel<TR, NWV, DV>), grid, dim3(64 * NWV), 0, st, (const uint16_t*)q, (const uint16_t*)k, \
                      (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg, lse)
-  if (split2) {
+  if (split2_q64) {
+    hipLaunchKernelGGL((varlen_attn_fwd_kernel<true, 8, 128, false, 2, 2>), grid, dim3(512), 0, st, (const uint16_t*)q,
+                       (const uint16_t*)k, (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles,
+                       (int)n_seq, slot, pg, lse);
+  } else if (split2) {
     hipLaunchKernelGGL((varlen_attn_fwd_kernel<true, 8, 128, false, 2>), grid, dim3(512), 0, st, (const uint16_t*)q,
                        (const uint16_t*)k, (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles,
                        (int)n_seq, slot, pg, lse);

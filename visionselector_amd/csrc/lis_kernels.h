@@ -19,30 +19,6 @@
 
 namespace vsel {
 
-// -DVSEL_TRACE (tools/trace_small.py builds with it; never in the shipped library): thread 0 of every workgroup leaves
-// s_memrealtime stamps (100 MHz, one clock for the whole device) at the phase edges of the small-batch kernels.
-#ifdef VSEL_TRACE
-constexpr int kTraceKernels = 8, kTraceBlocks = 1024, kTraceSlots = 8;
-static __device__ unsigned long long g_trace[kTraceKernels][kTraceBlocks][kTraceSlots];
-#define VSEL_STAMP(kern, slot)                                                                                         \
-  do {                                                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    if (threadIdx.x == 0) {                                                                                            \
-      const unsigned b_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                              \
-      if (b_ < (unsigned)kTraceBlocks) g_trace[kern][b_][slot] = __builtin_amdgcn_s_memrealtime();                     \
-    }                                                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                                 \
-  } while (0)
-#define VSEL_STAMP_DRAIN(kern, slot)                                                                                   \
-  do {                                                                                                                 \
-    __builtin_amdgcn_s_waitcnt(0);                                                                                     \
-    VSEL_STAMP(kern, slot);                                                                                            \
-  } while (0)
-#else
-#define VSEL_STAMP(kern, slot) do {} while (0)
-#define VSEL_STAMP_DRAIN(kern, slot) do {} while (0)
-#endif
-
 // =================================================================================================
 constexpr int kRowsPerChunk = 128;   // sweep-1 row chunk (batch-invariant summation order)
 constexpr int kSliceNT = 256;        // split-K slice of the kbar projection (fixed => batch-invariant)

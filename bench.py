@@ -372,7 +372,7 @@ def bench_train_step(ops, dist, world, rank, iters=20):
     return out
 
 
-def bench_attention(ops, k, text=64, hq=28, hkv=4, dh=128, layers=28, iters=20):
+def bench_attention(ops, k, text=64, hq=28, hkv=4, dh=128, layers=28, iters=200):
     """Var-len causal GQA attention (Qwen2.5-VL-7B geometry) at L' = k + 64 vs L = N + 64, one sequence."""
     out = {}
     for tag, L in (("retain20", k + text), ("full", N_VIS + text)):
@@ -381,8 +381,9 @@ def bench_attention(ops, k, text=64, hq=28, hkv=4, dh=128, layers=28, iters=20):
         kk = torch.randn(L, hkv, dh, device="cuda", generator=gen).bfloat16()
         v = torch.randn(L, hkv, dh, device="cuda", generator=gen).bfloat16()
         cu = torch.tensor([0, L], dtype=torch.int32, device="cuda")
-        for _ in range(3):
+        for _ in range(20):            # (a ~15 us kernel: enough launches queued that the Python call rate is not what is timed)
             ops.varlen_attn(q, kk, v, cu, L)
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):

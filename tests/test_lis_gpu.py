@@ -365,3 +365,31 @@ def test_small_batch_path_ragged_permuted_presummed(ops):
     out_p, idx_p, _ = outs[True][3:6]
     out_r, idx_r, _ = ops.lis_select(h2[l2p].contiguous(), wq, bq, wk, bk, 128)
     assert torch.equal(idx_p, idx_r) and torch.equal(out_p, out_r)
+
+
+def test_fused_select_gather_is_bit_identical(ops):
+    """Mid-size batches run the radix select inside the gather workgroups (one launch less): same indices / rows / scores as the
+    two-launch form, uniform and ragged."""
+    import ctypes
+    from visionselector_amd import _native
+    lib = _native.lib()
+    d, hd, n, k, b = 2048, 1024, 1100, 220, 9
+    c = oin.make_case(d, hd, n, 31, batch=b)
+    h, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    lens = [700, 33, 1500, 64, 9, 412, 800]
+    ks = [max(1, m // 4) for m in lens]
+    c2 = oin.make_case(d, hd, sum(lens), 32)
+    h2 = dev(c2["h"], torch.bfloat16)
+    outs = {}
+    try:
+        for limit in (0, 64):
+            lib.vsel_debug_set_fused_select(ctypes.c_int(limit))
+            _native.profile_start()
+            a = ops.lis_select(h, wq, bq, wk, bk, k)
+            prof = _native.profile_stop()
+            assert ("select_gather_small_kernel" in prof) == (limit > 0), prof
+            outs[limit] = a + ops.lis_select_varlen(h2, lens, ks, wq, bq, wk, bk)
+    finally:
+        lib.vsel_debug_set_fused_select(ctypes.c_int(32))
+    for x, y in zip(outs[0], outs[64]):
+        assert torch.equal(x, y)

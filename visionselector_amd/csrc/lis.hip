@@ -84,6 +84,15 @@ extern "C" int vsel_debug_read_trace(unsigned long long* out, int clear) {
 }
 #endif
 
+// select fused into the gather (select_gather_small_kernel) for mid-size batches of the nine-launch form.  Measured (7B geometry,
+// us per call, fused vs two launches): 8 images 82.0 vs 83.3, 16 135.3 vs 137.0, 32 233.4 vs 238.8, 48 350.9 vs 347.1, 128 900.8 vs
+// 877.0 -> up to 32 segments.  VSEL_FUSED_SELECT=<n> / vsel_debug_set_fused_select(n).
+static int g_fused_select_max_seg = [] {
+  const char* e = getenv("VSEL_FUSED_SELECT");
+  return e ? atoi(e) : 32;
+}();
+extern "C" void vsel_debug_set_fused_select(int max_seg) { g_fused_select_max_seg = max_seg; }
+
 static bool use_small_path(const vsel_segments* seg, const vsel_scorer* sc, const LisPlan& p) {
   return seg->n_seg <= g_small_path_max_seg && small_path_ok(seg, sc, p);
 }
@@ -105,6 +114,8 @@ static int select_whole(hipStream_t st, const T* h, const vsel_segments* seg, co
   if (rc) return rc;
   rc = run_score<T>(st, h, seg, sc, ws, p, scores, p2l);
   if (rc) return rc;
+  // up to g_fused_select_max_seg segments: the radix select runs inside every gather workgroup (one launch less; same indices)
+  if (seg->n_seg <= g_fused_select_max_seg) return launch_select_gather_small<T>(st, h, (int)sc->d, seg, scores, idx, out, l2p);
   rc = launch_select(st, scores, seg, idx, nullptr);
   if (rc) return rc;
   return launch_gather<T>(st, h, (int)sc->d, seg, idx, out, l2p);

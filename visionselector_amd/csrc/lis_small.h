@@ -27,9 +27,11 @@ constexpr int kSmallSelectThreads = 256;
 //     kernel's arithmetic floor, so tiles are spread over as many SIMDs as there are (784 waves at the 7B geometry).
 //     partial: sweep-1 partials [S][row_splits][K] (or the producer's column sums, row_splits 1)
 // -------------------------------------------------------------------------------------------------------------------------
+//     split_stride: floats between consecutive row splits of one segment (K for the sweep-1 partials); mean = 0: the sums are
+//     used as they are instead of being divided by the segment's row count (training backward: Wq (sum_i g_i x_i))
 static __global__ __launch_bounds__(64) void proj_nt_small_kernel(const float* __restrict__ partial, SegView sv, int S, int row_splits,
                                                                   const uint16_t* __restrict__ w, int N, int K, int kslice,
-                                                                  float* __restrict__ part) {
+                                                                  float* __restrict__ part, int64_t split_stride, int mean) {
   __shared__ __attribute__((aligned(16))) uint16_t xs[3][kSmallMaxSeg][kSliceNT];
   const int lane = threadIdx.x;
   const int i = lane & 31, kg = lane >> 5;
@@ -55,14 +57,14 @@ static __global__ __launch_bounds__(64) void proj_nt_small_kernel(const float* _
   const bool kq_ok = kq < k_end;                     // K % 16 == 0: a 4-group is inside the slice or outside it
   for (int m = 0; m < S; ++m) {
     const float nf = (float)sv.n_rows(m);
-    const float* pc = partial + (int64_t)m * row_splits * K + (kq_ok ? kq : k_begin);     // lanes past the slice read a valid dummy
+    const float* pc = partial + (int64_t)m * row_splits * split_stride + (kq_ok ? kq : k_begin);   // lanes past the slice read a valid dummy
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int r0 = 0; r0 < row_splits; r0 += 24) {
       f32x4 v[24];
 #pragma unroll
       for (int q = 0; q < 24; ++q)       // UNCONDITIONAL loads (clamped index): a per-element "load or zero" on a runtime bound makes
                                          // hipcc branch around every load and wait for each one (cdna_hip_programming.md, trap (c))
-        v[q] = *reinterpret_cast<const f32x4*>(pc + (int64_t)min(r0 + q, row_splits - 1) * K);
+        v[q] = *reinterpret_cast<const f32x4*>(pc + (int64_t)min(r0 + q, row_splits - 1) * split_stride);
 #pragma unroll
       for (int q = 0; q < 24; ++q)
         if (r0 + q < row_splits) acc += v[q];
@@ -71,7 +73,7 @@ static __global__ __launch_bounds__(64) void proj_nt_small_kernel(const float* _
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       b[0][e] = b[1][e] = b[2][e] = 0u;
-      if (kq_ok) split3(acc[e] / nf, b[0][e], b[1][e], b[2][e]);
+      if (kq_ok) split3(mean ? acc[e] / nf : acc[e], b[0][e], b[1][e], b[2][e]);
     }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
@@ -582,7 +584,7 @@ inline int run_proj_small(hipStream_t st, const vsel_segments* seg, const vsel_s
   float* part2 = (float*)(ws + p.off_part2);
   float* cpart = (float*)(ws + p.off_cpart);
   hipLaunchKernelGGL(proj_nt_small_kernel, dim3((unsigned)cdiv(hd, 32), p.ks1), dim3(64), 0, st, partial, make_view(seg), S,
-                     row_splits, (const uint16_t*)sc->wk, hd, d, p.kslice1, part1);
+                     row_splits, (const uint16_t*)sc->wk, hd, d, p.kslice1, part1, (int64_t)d, 1);
   VSEL_AFTER_LAUNCH(st, "proj_nt_small_kernel");
   hipLaunchKernelGGL(proj_nn_small_kernel, dim3((unsigned)cdiv(d, 128), p.ks2), dim3(64), 0, st, part1, p.ks1, S,
                      (const uint16_t*)sc->bk, (const uint16_t*)sc->bq, (const uint16_t*)sc->wq, d, hd, p.kslice2, part2, cpart,

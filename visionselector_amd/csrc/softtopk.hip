@@ -12,6 +12,11 @@
 namespace vsel {
 
 __device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+// 4 instructions instead of ~25 (v_exp_f32 / v_rcp_f32: about 1 ulp each); relative error < 1e-6.  Only used to DECIDE a bisection
+// step whose sum is further from k than that error allows (below); every value that is returned comes from sigmoidf_ref.
+__device__ __forceinline__ float sigmoidf_fast(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 // Sum over the block, identical value in every thread, fixed order.  `slot` alternates so one barrier
 // per call is enough.
@@ -35,7 +40,7 @@ __global__ __launch_bounds__(NT) void soft_topk_fwd_kernel(const float* __restri
                                                            float* __restrict__ ps, float* __restrict__ ts) {
   constexpr int NW = NT / 64;
   constexpr int E = EPT > 0 ? EPT : 1;
-  __shared__ float red[4][NW];
+  __shared__ float red[6][NW];
   const int row = blockIdx.x;
   const float* x = xs + (int64_t)row * n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -60,25 +65,40 @@ __global__ __launch_bounds__(NT) void soft_topk_fwd_kernel(const float* __restri
   }
   mx = wave_max(mx);
   mn = wave_min(mn);
-  if (lane == 0) { red[2][wave] = mx; red[3][wave] = mn; }
+  if (lane == 0) { red[4][wave] = mx; red[5][wave] = mn; }
   __syncthreads();
-  mx = red[2][0]; mn = red[3][0];
+  mx = red[4][0]; mn = red[5][0];
 #pragma unroll
-  for (int w = 1; w < NW; ++w) { mx = fmaxf(mx, red[2][w]); mn = fminf(mn, red[3][w]); }
+  for (int w = 1; w < NW; ++w) { mx = fmaxf(mx, red[4][w]); mn = fminf(mn, red[5][w]); }
 
   float lo = -mx - 10.0f;   // :78
   float hi = -mn + 10.0f;   // :79
   const float kf = (float)k;
+  // A step only needs the SIGN of (sum - k).  While the bracket is wide that sign is decided by a sum of 4-instruction sigmoids
+  // (error bound: 2e-6 per element incl. the summation, + 1e-3); the step is redone with the reference-accurate sigmoid when
+  // the cheap sum is within the bound of k -- the sequence of (lo, hi) is the all-accurate one, step for step, at a third of the
+  // arithmetic (the row sits on ONE CU: 26 steps x N accurate sigmoids were 31 us at N = 2304).
+  const float decisive = 2e-6f * (float)n + 1e-3f;
   for (int it = 0; it < 64; ++it) {             // :80
     const float mid = (hi + lo) / 2.0f;         // :81
     float acc = 0.f;
     if constexpr (EPT > 0) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) acc += sigmoidf_ref(xr[e] + mid);
+      for (int e = 0; e < E; ++e) acc += sigmoidf_fast(xr[e] + mid);
     } else {
-      for (int i = tid; i < n; i += NT) acc += sigmoidf_ref(x[i] + mid);
+      for (int i = tid; i < n; i += NT) acc += sigmoidf_fast(x[i] + mid);
     }
-    const float sum = block_sum<NW>(acc, red, it & 1);
+    float sum = block_sum<NW>(acc, red, (2 * it) & 3);
+    if (fabsf(sum - kf) <= decisive) {          // uniform
+      acc = 0.f;
+      if constexpr (EPT > 0) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc += sigmoidf_ref(xr[e] + mid);
+      } else {
+        for (int i = tid; i < n; i += NT) acc += sigmoidf_ref(x[i] + mid);
+      }
+      sum = block_sum<NW>(acc, red, (2 * it + 1) & 3);
+    }
     const bool fixed_point = (mid == lo) || (mid == hi);
     if (sum < kf) lo = mid; else hi = mid;      // :82-84
     if (fixed_point) break;
@@ -128,8 +148,8 @@ __global__ __launch_bounds__(NT) void soft_topk_bwd_kernel(const float* __restri
 int launch_soft_topk_fwd(hipStream_t st, const float* xs, int64_t b, int64_t n, int64_t k, float* ps, float* ts) {
   if (n <= 1024)
     hipLaunchKernelGGL((soft_topk_fwd_kernel<256, 4>), dim3((unsigned)b), dim3(256), 0, st, xs, (int)n, (int)k, ps, ts);
-  else if (n <= 4096)
-    hipLaunchKernelGGL((soft_topk_fwd_kernel<1024, 4>), dim3((unsigned)b), dim3(1024), 0, st, xs, (int)n, (int)k, ps, ts);
+  else if (n <= 4096)      // one wave per SIMD: a step is issue-bound (16 waves: 0.8 us per step at N = 2304, 4 waves: see bench_train)
+    hipLaunchKernelGGL((soft_topk_fwd_kernel<256, 16>), dim3((unsigned)b), dim3(256), 0, st, xs, (int)n, (int)k, ps, ts);
   else if (n <= 16384)
     hipLaunchKernelGGL((soft_topk_fwd_kernel<1024, 16>), dim3((unsigned)b), dim3(1024), 0, st, xs, (int)n, (int)k, ps, ts);
   else

@@ -10,6 +10,7 @@
 //             dx_i = ps_i dh'_i + g_i rs Wq^T kbar + Wk^T dk
 //           i.e. two more sweeps over the token tensor (row dots, weighted column sums) + GEMVs + rank-1 writes.
 #include "lis_kernels.h"
+#include "lis_small.h"
 
 namespace vsel {
 
@@ -26,12 +27,20 @@ __global__ __launch_bounds__(256) void mask_apply_kernel(const T* __restrict__ h
     const float p = ps[r];
     const T* src = h + (int64_t)r * d;
     T* dst = out + (int64_t)r * d;
-    for (int c = lane * V; c < d; c += 64 * V) {
-      float v[V];
-      load_vec(src + c, v);
+    // the row's column groups are loaded 8 at a time (clamped, unconditional): a plain loop waits for every load in turn
+    for (int c0 = lane * V; c0 < d; c0 += 8 * 64 * V) {
+      float v[8][V];
 #pragma unroll
-      for (int q = 0; q < V; ++q) v[q] *= p;
-      store_vec(dst + c, v);
+      for (int u = 0; u < 8; ++u) load_vec(src + min(c0 + u * 64 * V, d - V), v[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + u * 64 * V;
+        if (c < d) {
+#pragma unroll
+          for (int q = 0; q < V; ++q) v[u][q] *= p;
+          store_vec(dst + c, v[u]);
+        }
+      }
     }
   }
 }
@@ -67,12 +76,20 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ dhn, 
     const T* a = dhn + (int64_t)r * d;
     const T* b = h + (int64_t)r * d;
     float acc = 0.f;
-    for (int c = lane * V; c < d; c += 64 * V) {
-      float va[V], vb[V];
-      load_vec(a + c, va);
-      load_vec(b + c, vb);
+    for (int c0 = lane * V; c0 < d; c0 += 4 * 64 * V) {      // 2 x 4 loads in flight (clamped); same order of the FMAs
+      float va[4][V], vb[4][V];
 #pragma unroll
-      for (int q = 0; q < V; ++q) acc = fmaf(va[q], vb[q], acc);
+      for (int u = 0; u < 4; ++u) {
+        const int cc = min(c0 + u * 64 * V, d - V);
+        load_vec(a + cc, va[u]);
+        load_vec(b + cc, vb[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c0 + u * 64 * V < d) {
+#pragma unroll
+          for (int q = 0; q < V; ++q) acc = fmaf(va[u][q], vb[u][q], acc);
+        }
     }
     acc = wave_sum(acc);
     if (lane == 0) {
@@ -99,12 +116,20 @@ __global__ __launch_bounds__(256) void wcolsum_partial_kernel(const T* __restric
 #pragma unroll
   for (int i = 0; i < V; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
   if (col < d) {
-    for (int r = rb + wave; r < re; r += 4) {
-      float v[V];
-      load_vec(h + (int64_t)r * d + col, v);
-      const float gr = g[r];
+    for (int r0 = rb + wave; r0 < re; r0 += 32) {          // 8 rows in flight per wave (clamped); rows are added in order
+      float v[8][V], gr[8];
 #pragma unroll
-      for (int i = 0; i < V; ++i) { a0[i] += v[i]; a1[i] = fmaf(gr, v[i], a1[i]); }
+      for (int u = 0; u < 8; ++u) {
+        const int r = min(r0 + 4 * u, re - 1);
+        load_vec(h + (int64_t)r * d + col, v[u]);
+        gr[u] = g[r];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r0 + 4 * u < re) {
+#pragma unroll
+          for (int i = 0; i < V; ++i) { a0[i] += v[u][i]; a1[i] = fmaf(gr[u], v[u][i], a1[i]); }
+        }
     }
   }
   __shared__ float red[4][64][2 * V + 1];
@@ -129,9 +154,17 @@ __global__ __launch_bounds__(256) void wcolsum_finish_kernel(const float* __rest
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c < d) {
     float a = 0.f, b = 0.f;
-    for (int rs = 0; rs < row_splits; ++rs) {
-      a += partial[(int64_t)rs * 2 * d + c];
-      b += partial[(int64_t)rs * 2 * d + d + c];
+    for (int r0 = 0; r0 < row_splits; r0 += 16) {            // 2 x 16 loads in flight (clamped), added in rs order
+      float ta[16], tb[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int64_t rs = min(r0 + u, row_splits - 1);
+        ta[u] = partial[rs * 2 * d + c];
+        tb[u] = partial[rs * 2 * d + d + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (r0 + u < row_splits) { a += ta[u]; b += tb[u]; }
     }
     xsum[c] = a;
     gx[c] = b;
@@ -157,8 +190,7 @@ __global__ __launch_bounds__(256) void dk_finish_kernel(const float* __restrict_
                                                         float* __restrict__ dbq, float* __restrict__ dbk) {
   const int h = blockIdx.x * 256 + threadIdx.x;
   if (h >= hd) return;
-  float v = 0.f;
-  for (int ks = 0; ks < KS; ++ks) v += part[(int64_t)ks * hd + h];
+  const float v = strided_sum(part + h, KS, hd);             // (ks order, all slab loads in flight)
   const float s = sg[0];
   const float dkv = (v + load_elem(bq + h) * s) * rs / (float)n;
   dk[h] = dkv;
@@ -235,7 +267,15 @@ template <typename T, typename TW>
 static int train_fwd_impl(hipStream_t st, const T* h, int64_t n, int64_t k, const vsel_scorer* sc, char* ws,
                           const TrainPlan& tp, T* h_new, float* ps, float* y, float* scores, float* ts, float* bce) {
   vsel_segments seg{1, n, n, k, k, nullptr, nullptr};
-  int rc = run_scores<T, TW>(st, h, &seg, sc, ws, tp.lis, scores);
+  int rc;
+  if (small_path_ok(&seg, sc, tp.lis)) {
+    // one segment: the four-launch small-batch form of the scores (lis_small.h; bit-identical to run_scores)
+    if ((rc = run_colsum<T>(st, h, &seg, (int)sc->d, ws, tp.lis))) return rc;
+    if ((rc = run_proj_small(st, &seg, sc, ws, tp.lis, nullptr))) return rc;
+    rc = run_score_small<T>(st, h, &seg, sc, ws, tp.lis, scores, nullptr);
+  } else {
+    rc = run_scores<T, TW>(st, h, &seg, sc, ws, tp.lis, scores);
+  }
   if (rc) return rc;
   rc = launch_soft_topk_fwd(st, scores, 1, n, k, ps, ts);
   if (rc) return rc;
@@ -281,17 +321,32 @@ static int scores_bwd_impl(hipStream_t st, const float* g, const T* h, int64_t n
   hipLaunchKernelGGL(wcolsum_finish_kernel, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st, wpart, g, (int)n, d, tp.wsplits,
                      xsum, gx, xbar, sg);
   VSEL_AFTER_LAUNCH(st, "wcolsum_finish_kernel");
-  // kbar = Wk xbar + bk
-  hipLaunchKernelGGL((gemm_nt_kernel<TW>), dim3((unsigned)cdiv(hd, 32), 1, p.ks1), dim3(64), 0, st, xbar, (const TW*)sc->wk, 1,
-                     hd, d, p.kslice1, part1);
-  VSEL_AFTER_LAUNCH(st, "gemm_nt_kernel");
+  // kbar = Wk xbar + bk.  bf16 weights: the forward's single-wave-per-tile bf16x3 kernel, its prologue summing the row splits
+  // of wpart itself (same bits as the forward's kbar); else the fp32-input MFMA form
+  vsel_segments seg1{1, n, n, 1, 1, nullptr, nullptr};
+  const bool small = small_path_ok(&seg1, sc, p);
+  if (small) {
+    hipLaunchKernelGGL(proj_nt_small_kernel, dim3((unsigned)cdiv(hd, 32), p.ks1), dim3(64), 0, st, wpart, make_view(&seg1), 1,
+                       tp.wsplits, (const uint16_t*)sc->wk, hd, d, p.kslice1, part1, (int64_t)2 * d, 1);
+    VSEL_AFTER_LAUNCH(st, "proj_nt_small_kernel");
+  } else {
+    hipLaunchKernelGGL((gemm_nt_kernel<TW>), dim3((unsigned)cdiv(hd, 32), 1, p.ks1), dim3(64), 0, st, xbar, (const TW*)sc->wk, 1,
+                       hd, d, p.kslice1, part1);
+    VSEL_AFTER_LAUNCH(st, "gemm_nt_kernel");
+  }
   hipLaunchKernelGGL((kbar_finish_kernel<TW>), dim3(1), dim3(256), 0, st, part1, p.ks1, 1, hd, (const TW*)sc->bk,
                      (const TW*)sc->bq, kbar, c);
   VSEL_AFTER_LAUNCH(st, "kbar_finish_kernel");
   // dk = (Wq gx + bq sg) rs / N
-  hipLaunchKernelGGL((gemm_nt_kernel<TW>), dim3((unsigned)cdiv(hd, 32), 1, p.ks1), dim3(64), 0, st, gx, (const TW*)sc->wq, 1,
-                     hd, d, p.kslice1, dkraw);
-  VSEL_AFTER_LAUNCH(st, "gemm_nt_kernel");
+  if (small) {
+    hipLaunchKernelGGL(proj_nt_small_kernel, dim3((unsigned)cdiv(hd, 32), p.ks1), dim3(64), 0, st, wpart + d, make_view(&seg1), 1,
+                       tp.wsplits, (const uint16_t*)sc->wq, hd, d, p.kslice1, dkraw, (int64_t)2 * d, 0);
+    VSEL_AFTER_LAUNCH(st, "proj_nt_small_kernel");
+  } else {
+    hipLaunchKernelGGL((gemm_nt_kernel<TW>), dim3((unsigned)cdiv(hd, 32), 1, p.ks1), dim3(64), 0, st, gx, (const TW*)sc->wq, 1,
+                       hd, d, p.kslice1, dkraw);
+    VSEL_AFTER_LAUNCH(st, "gemm_nt_kernel");
+  }
   hipLaunchKernelGGL((dk_finish_kernel<TW>), dim3((unsigned)cdiv(hd, 256)), dim3(256), 0, st, dkraw, p.ks1, hd,
                      (const TW*)sc->bq, kbar, sg, rs, (int)n, dk, a, dbq, dbk);
   VSEL_AFTER_LAUNCH(st, "dk_finish_kernel");

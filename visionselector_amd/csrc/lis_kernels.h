@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 }
 
 // K1b  xbar[s][c] = sum_rs partial[s][rs][c] / N_s   (fixed order)
-static __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, SegView sv, int d,
+static __attribute__((unused)) __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, SegView sv, int d,
                                                             int row_splits, float* __restrict__ xbar) {
   const int s = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64) void gemm_nn_kernel(const float* __restrict__ x
 }
 
 // K3b  out[e] = sum_ks part[ks][e]
-static __global__ __launch_bounds__(256) void slice_sum_kernel(const float* __restrict__ part, int KS, int64_t count,
+static __attribute__((unused)) __global__ __launch_bounds__(256) void slice_sum_kernel(const float* __restrict__ part, int KS, int64_t count,
                                                         float* __restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= count) return;
@@ -465,7 +465,7 @@ __device__ __forceinline__ uint32_t order_key(float x) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-static __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restrict__ scores, SegView sv,
+static __attribute__((unused)) __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restrict__ scores, SegView sv,
                                                            int64_t* __restrict__ idx, float* __restrict__ mask) {
   const int s = blockIdx.x;
   const int n = sv.n_rows(s);

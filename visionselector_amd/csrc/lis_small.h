@@ -29,7 +29,7 @@ constexpr int kSmallSelectThreads = 256;
 // -------------------------------------------------------------------------------------------------------------------------
 //     split_stride: floats between consecutive row splits of one segment (K for the sweep-1 partials); mean = 0: the sums are
 //     used as they are instead of being divided by the segment's row count (training backward: Wq (sum_i g_i x_i))
-static __global__ __launch_bounds__(64) void proj_nt_small_kernel(const float* __restrict__ partial, SegView sv, int S, int row_splits,
+static __attribute__((unused)) __global__ __launch_bounds__(64) void proj_nt_small_kernel(const float* __restrict__ partial, SegView sv, int S, int row_splits,
                                                                   const uint16_t* __restrict__ w, int N, int K, int kslice,
                                                                   float* __restrict__ part, int64_t split_stride, int mean) {
   __shared__ __attribute__((aligned(16))) uint16_t xs[3][kSmallMaxSeg][kSliceNT];
@@ -135,7 +135,7 @@ static __global__ __launch_bounds__(64) void proj_nt_small_kernel(const float* _
 //     lane (i, kg) loads 8 bytes = Wq[h][n0 + 4 i .. + 3] per k-row, MFMA tile t takes column 4 i + t (four tiles, 96 MFMAs per
 //     wave; the 256-column / eight-tile form of the batched kernel spends 3.9 us in its 192 MFMAs at one image).
 // -------------------------------------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(64) void proj_nn_small_kernel(const float* __restrict__ part1, int KS1, int S,
+static __attribute__((unused)) __global__ __launch_bounds__(64) void proj_nn_small_kernel(const float* __restrict__ part1, int KS1, int S,
                                                                   const uint16_t* __restrict__ bk, const uint16_t* __restrict__ bq,
                                                                   const uint16_t* __restrict__ w, int N, int K, int kslice,
                                                                   float* __restrict__ part2, float* __restrict__ cpart, int n_cpart) {

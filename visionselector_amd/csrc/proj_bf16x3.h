@@ -57,7 +57,7 @@ __device__ __forceinline__ int64_t frag_off(int p, int m, int k, int m_tiles, in
 }
 
 // xs (fragment-major bf16x3 planes) = split3( sum_rs partial[m][rs][c] / N_m )
-static __global__ __launch_bounds__(256) void colsum_finish_split_kernel(const float* __restrict__ partial, SegView sv,
+static __attribute__((unused)) __global__ __launch_bounds__(256) void colsum_finish_split_kernel(const float* __restrict__ partial, SegView sv,
                                                                          int d, int row_splits, int M,
                                                                          uint16_t* __restrict__ xs) {
   const int s = blockIdx.y;
@@ -75,8 +75,8 @@ static __global__ __launch_bounds__(256) void colsum_finish_split_kernel(const f
 
 // NT: part[ks][n][m_pad] = sum_{k in slice} x[m][k] w[n][k].  grid (ceil(N/64), m_tiles, KS), one wave per block:
 // two 32-row weight tiles x one 32-column activation tile.  Requires K % 16 == 0.  m_pad = 32 * m_tiles.
-static __global__ __launch_bounds__(64) void gemm_nt_bf16x3_kernel(const uint16_t* __restrict__ xs,
-                                                                   const uint16_t* __restrict__ w, int M, int N, int K,
+static __attribute__((unused)) __global__ __launch_bounds__(64) void gemm_nt_bf16x3_kernel(const uint16_t* __restrict__ xs,
+                                                                   const uint16_t* __restrict__ w, int /*M*/, int N, int K,
                                                                    int kslice, float* __restrict__ part) {
   const int lane = threadIdx.x;
   const int i = lane & 31, kg = lane >> 5;
@@ -146,7 +146,7 @@ static __global__ __launch_bounds__(64) void gemm_nt_bf16x3_kernel(const uint16_
 
 // kbar[m][h] = sum_ks part[ks][h][m] + bk[h]  -> fp32 copy + fragment-major bf16x3 planes;
 // cpart[m][by] = sum_{h in block} bq[h] kbar[m][h].  grid (ceil(m_pad/32), ceil(N/8)), block 256 = 32 m x 8 h.
-static __global__ __launch_bounds__(256) void kbar_finish_split_kernel(const float* __restrict__ part, int KS, int M, int N,
+static __attribute__((unused)) __global__ __launch_bounds__(256) void kbar_finish_split_kernel(const float* __restrict__ part, int KS, int M, int N,
                                                                        int m_pad, const uint16_t* __restrict__ bk,
                                                                        const uint16_t* __restrict__ bq,
                                                                        float* __restrict__ kbar, uint16_t* __restrict__ ksp,
@@ -182,8 +182,8 @@ static __global__ __launch_bounds__(256) void kbar_finish_split_kernel(const flo
 // Lane (i, kg) owns 8 consecutive n (n0 + 8i .. +7) and k rows k0 + 8kg .. +7: eight 16-byte row loads, then a
 // register transpose (v_perm_b32) builds, for each t in 0..7, the A fragment {w[k0+8kg+e][n0+8i+t]}_e of the
 // 32x32 tile "n = n0 + 8*i' + t".  Requires K % 16 == 0 and N % 8 == 0.
-static __global__ __launch_bounds__(64) void gemm_nn_bf16x3_kernel(const uint16_t* __restrict__ xs,
-                                                                   const uint16_t* __restrict__ w, int M, int N, int K,
+static __attribute__((unused)) __global__ __launch_bounds__(64) void gemm_nn_bf16x3_kernel(const uint16_t* __restrict__ xs,
+                                                                   const uint16_t* __restrict__ w, int /*M*/, int N, int K,
                                                                    int kslice, float* __restrict__ part) {
   const int lane = threadIdx.x;
   const int i = lane & 31, kg = lane >> 5;
@@ -254,7 +254,7 @@ static __global__ __launch_bounds__(64) void gemm_nn_bf16x3_kernel(const uint16_
 }
 
 // w[m][n] = sum_ks part[ks][n][m];  c[m] = sum_j cpart[m][j].  grid (ceil(m_pad/32), ceil(N/8)), block 256 = 32 m x 8 n.
-static __global__ __launch_bounds__(256) void w_finish_kernel(const float* __restrict__ part, int KS, int M, int N, int m_pad,
+static __attribute__((unused)) __global__ __launch_bounds__(256) void w_finish_kernel(const float* __restrict__ part, int KS, int M, int N, int m_pad,
                                                               const float* __restrict__ cpart, int n_cpart,
                                                               float* __restrict__ w, float* __restrict__ c) {
   const int m = blockIdx.x * 32 + (threadIdx.x & 31);

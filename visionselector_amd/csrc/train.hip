@@ -11,6 +11,7 @@
 //           i.e. two more sweeps over the token tensor (row dots, weighted column sums) + GEMVs + rank-1 writes.
 #include "lis_kernels.h"
 #include "lis_small.h"
+#include "softtopk.h"
 
 namespace vsel {
 
@@ -62,6 +63,133 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ ps,
     for (int w = 0; w < 16; ++w) t += red[w];
     out[0] = t / (float)n;
   }
+}
+
+// The forward's tail for one row of N <= 256 KPT scores in ONE launch (three before: soft top-k, hard top-k mask, BCE):
+//   ts, ps = _find_ts(scores, k)                 (soft_topk_fwd_kernel's bisection, step for step)
+//   y      = hard top-k mask of the scores       (topk_select_reg_kernel's integer select: larger key first, then lower index)
+//   bce    = mean_i BCE(ps_i, y_i)               (ATen's -100 clamp; fixed summation order: wave, then waves 0..3)
+// Wave w owns the contiguous elements [w span, (w + 1) span), element j of a lane = e0 + 64 j.
+template <int KPT>
+__global__ __launch_bounds__(256) void train_tail_kernel(const float* __restrict__ xs, int n, int k, float* __restrict__ ps,
+                                                         float* __restrict__ ts, float* __restrict__ y,
+                                                         float* __restrict__ bce) {
+  constexpr int NT = 256, NW = 4;
+  __shared__ float red[6][NW];
+  __shared__ uint32_t hist[4][256];
+  __shared__ uint32_t wtot[NW][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kpw = (n + NT - 1) / NT;                  // 64-element groups per wave (<= KPT)
+  const int e0 = wave * kpw * 64 + lane;
+  float xr[KPT];
+  float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) xr[j] = xs[min(e0 + 64 * j, n - 1)];      // unconditional (clamped) loads
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const bool ok = j < kpw && e0 + 64 * j < n;
+    if (ok) { mx = fmaxf(mx, xr[j]); mn = fminf(mn, xr[j]); }
+    else xr[j] = -INFINITY;                           // sigmoid(-inf + t) = 0: padding never contributes
+  }
+#pragma unroll
+  for (int p4 = 0; p4 < 4; ++p4) hist[p4][tid] = 0;
+  mx = wave_max(mx);
+  mn = wave_min(mn);
+  if (lane == 0) { red[4][wave] = mx; red[5][wave] = mn; }
+  __syncthreads();
+  mx = red[4][0]; mn = red[5][0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) { mx = fmaxf(mx, red[4][w]); mn = fminf(mn, red[5][w]); }
+  // ---- _find_ts (selector_model.py:72-86), see soft_topk_fwd_kernel for the decisive / accurate step rule --------------
+  float lo = -mx - 10.0f, hi = -mn + 10.0f;
+  const float kf = (float)k;
+  const float decisive = 2e-6f * (float)n + 1e-3f;
+  for (int it = 0; it < 64; ++it) {
+    const float mid = (hi + lo) / 2.0f;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) acc += sigmoidf_fast(xr[j] + mid);
+    float sum = block_sum<NW>(acc, red, (2 * it) & 3);
+    if (fabsf(sum - kf) <= decisive) {
+      acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) acc += sigmoidf_ref(xr[j] + mid);
+      sum = block_sum<NW>(acc, red, (2 * it + 1) & 3);
+    }
+    const bool fixed_point = (mid == lo) || (mid == hi);
+    if (sum < kf) lo = mid; else hi = mid;
+    if (fixed_point) break;
+  }
+  const float t = (lo + hi) / 2.0f;
+  if (tid == 0) ts[0] = t;
+  // ---- hard top-k mask: 4-pass radix select on the ordered keys, then the ordered tie rule ------------------------------
+  uint32_t key[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) key[j] = (j < kpw && e0 + 64 * j < n) ? order_key(xr[j]) : 0u;
+  uint32_t prefix = 0, maskbits = 0, kk = (uint32_t)k;
+#pragma unroll 1
+  for (int pass = 3; pass >= 0; --pass) {
+    const int shift = 8 * pass;
+    uint32_t* hp = hist[pass];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j)
+      if (j < kpw && e0 + 64 * j < n && (key[j] & maskbits) == prefix) atomicAdd(&hp[(key[j] >> shift) & 255u], 1u);
+    __syncthreads();
+    const u32x4 cv = *reinterpret_cast<const u32x4*>(&hp[252 - 4 * lane]);
+    const uint32_t cs[4] = {cv[3], cv[2], cv[1], cv[0]};
+    const uint32_t tot = cs[0] + cs[1] + cs[2] + cs[3];
+    uint32_t run = wave_prefix_sum_u32(tot) - tot;
+    uint32_t found = 0xffffffffu, found_kk = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (run < kk && run + cs[b] >= kk) {
+        found = 255 - 4 * lane - b;
+        found_kk = kk - run;
+      }
+      run += cs[b];
+    }
+    const unsigned long long who = __ballot(found != 0xffffffffu);
+    const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)who) - 1);
+    const uint32_t bin = (uint32_t)__builtin_amdgcn_readlane((int)found, src);
+    kk = (uint32_t)__builtin_amdgcn_readlane((int)found_kk, src);
+    prefix |= bin << shift;
+    maskbits |= 0xffu << shift;
+  }
+  const uint32_t thr = prefix, need = kk;
+  uint32_t my_eq = 0;
+  unsigned long long beq[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    beq[j] = __ballot(j < kpw && e0 + 64 * j < n && key[j] == thr);
+    my_eq += __popcll(beq[j]);
+  }
+  if (lane == 0) wtot[wave][1] = my_eq;
+  __syncthreads();
+  uint32_t run_eq = 0;
+#pragma unroll
+  for (int wv = 0; wv < NW; ++wv)
+    if (wv < wave) run_eq += wtot[wv][1];
+  const unsigned long long below = (1ull << lane) - 1ull;
+  // ---- ps, y, BCE ---------------------------------------------------------------------------------------------------
+  float bacc = 0.f;
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const int e = e0 + 64 * j;
+    const bool valid = j < kpw && e < n;
+    const bool eq = (beq[j] >> lane) & 1ull;
+    const uint32_t eq_before = run_eq + __popcll(beq[j] & below);
+    const bool sel = valid && (key[j] > thr || (eq && eq_before < need));
+    if (valid) {
+      const float p = sigmoidf_ref(xr[j] + t);          // :86
+      const float yv = sel ? 1.0f : 0.0f;
+      ps[e] = p;
+      y[e] = yv;
+      bacc += (yv - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - yv * fmaxf(logf(p), -100.0f);
+    }
+    run_eq += __popcll(beq[j]);
+  }
+  const float btot = block_sum<NW>(bacc, red, 0);
+  if (tid == 0) bce[0] = btot / (float)n;
 }
 
 // dps[i] = <d_hnew[i,:], h[i,:]> + d_ps_ext[i] + dl_dbce * (p - y) / max((1 - p) p, 1e-12) / N     wave per row
@@ -277,11 +405,21 @@ static int train_fwd_impl(hipStream_t st, const T* h, int64_t n, int64_t k, cons
     rc = run_scores<T, TW>(st, h, &seg, sc, ws, tp.lis, scores);
   }
   if (rc) return rc;
+  const int d = (int)sc->d;
+  if (n <= 4096) {
+    // soft top-k + hard top-k mask + BCE of the one row in one launch
+    if (n <= 1024) hipLaunchKernelGGL(train_tail_kernel<4>, dim3(1), dim3(256), 0, st, scores, (int)n, (int)k, ps, ts, y, bce);
+    else hipLaunchKernelGGL(train_tail_kernel<16>, dim3(1), dim3(256), 0, st, scores, (int)n, (int)k, ps, ts, y, bce);
+    VSEL_AFTER_LAUNCH(st, "train_tail_kernel");
+    hipLaunchKernelGGL((mask_apply_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv(n, 4), 4096)), dim3(256), 0, st, h, ps,
+                       (int)n, d, h_new);
+    VSEL_AFTER_LAUNCH(st, "mask_apply_kernel");
+    return VSEL_OK;
+  }
   rc = launch_soft_topk_fwd(st, scores, 1, n, k, ps, ts);
   if (rc) return rc;
   rc = launch_select(st, scores, &seg, nullptr, y);
   if (rc) return rc;
-  const int d = (int)sc->d;
   hipLaunchKernelGGL((mask_apply_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv(n, 4), 4096)), dim3(256), 0, st, h, ps,
                      (int)n, d, h_new);
   VSEL_AFTER_LAUNCH(st, "mask_apply_kernel");

@@ -21,12 +21,13 @@ def main():
     from visionselector_amd import ops
 
     L = int(sys.argv[1]) if len(sys.argv) > 1 else 524
+    n_seq = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     hq, hkv, d = 28, 4, 128
     g = torch.Generator(device="cuda").manual_seed(0)
-    q = torch.randn(L, hq, d, device="cuda", generator=g).bfloat16()
-    k = torch.randn(L, hkv, d, device="cuda", generator=g).bfloat16()
-    v = torch.randn(L, hkv, d, device="cuda", generator=g).bfloat16()
-    cu = torch.tensor([0, L], device="cuda", dtype=torch.int32)
+    q = torch.randn(n_seq * L, hq, d, device="cuda", generator=g).bfloat16()
+    k = torch.randn(n_seq * L, hkv, d, device="cuda", generator=g).bfloat16()
+    v = torch.randn(n_seq * L, hkv, d, device="cuda", generator=g).bfloat16()
+    cu = torch.arange(0, n_seq * L + 1, L, device="cuda", dtype=torch.int32)
     lib = _native.lib()
     if len(sys.argv) > 2 and sys.argv[2] == "q128":
         lib.vsel_debug_attn_split_q64(C.c_int(0))         # two 4-wave groups, 128 queries per workgroup
@@ -49,7 +50,18 @@ def main():
     for _ in range(2000):
         f()
     torch.cuda.synchronize()
-    print(f"L = {L}: {(time.perf_counter() - t0) / 2000 * 1e6:.2f} us per launch (traced build, back to back)")
+    print(f"{n_seq} x L = {L}: {(time.perf_counter() - t0) / 2000 * 1e6:.2f} us per launch (traced build, back to back)")
+    if n_seq > 1:
+        # persistent grid: the stamps are those of the LAST item each workgroup processed
+        r = runs[-1]
+        live = r[0][:, 0] > 0
+        st = r[0][live].astype(np.int64)
+        t_first = (st[:, 1] - st[:, 0]) / 100.0
+        t_loop = (st[:, 2] - st[:, 1]) / 100.0
+        t_end = (st[:, 4] - st[:, 2]) / 100.0
+        print(f"  last item of each of the {int(live.sum())} workgroups: start -> first tile landed median {np.median(t_first):.2f} us, "
+              f"tile loop {np.median(t_loop):.2f}, merge + store {np.median(t_end):.2f}")
+        return
     names = ["start", "Q in registers, first tile landed", "tile loop done", "states merged", "end (stores drained)"]
     live = runs[0][0][:, 0] > 0
     nwg = int(live.sum())

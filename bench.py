@@ -369,6 +369,40 @@ def bench_train_step(ops, dist, world, rank, iters=20):
         out[name] = {"n_tokens_per_rank": n, "k": k, "step_us": step_us, "fwd_bwd_us": comp_us, "grad_allreduce_us": exch_us,
                      "tokens_per_s": world * n / (step_us * 1e-6),
                      "allreduce_busbw_GBps": (2 * (world - 1) / world * bucket.numel() * 4 / (exch_us * 1e-6) / 1e9) if dist else None}
+
+        # the same step with the weight gradients exchanged as rank-1 factors (ddp.LisFactorSync): the backward
+        # writes one 57 KB payload row instead of two dense [Hd, D] gradients, the exchange is an all-gather of the rows and
+        # every rank rebuilds the mean gradient with two [Hd, R] x [R, D] GEMMs
+        from visionselector_amd.ddp import LisFactorSync
+        params = [torch.nn.Parameter(t.float(), requires_grad=True) for t in (wq, bq, wk, bk)]
+        fsync = LisFactorSync(params)
+
+        def compute_f(step_no):
+            w = curriculum_weight(step_no, 1000, 0.1, 2.0)
+            h_new, ps, y, scores, ts, bce = ops.lis_train_fwd(h, wq, bq, wk, bk, k)
+            ops.lis_train_bwd_factors(dhn, h, wq, bq, wk, bk, ps, y, scores, ts, None, w, need_dh=False,
+                                      out=fsync.new_row(h.device))
+
+        for i in range(3):
+            compute_f(i)
+            fsync.sync()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for i in range(iters):
+            compute_f(i)
+            fsync.sync()
+        ev[1].record()
+        torch.cuda.synchronize()
+        tf_ = torch.tensor([ev[0].elapsed_time(ev[1])], dtype=torch.float64, device="cuda") / iters * 1e3
+        if dist:
+            dist.all_reduce(tf_, op=dist.ReduceOp.MAX)
+        out[name]["rank1_factors"] = {"step_us": float(tf_[0]), "payload_bytes_per_rank": fsync.row * 4,
+                                      "tokens_per_s": world * n / (float(tf_[0]) * 1e-6),
+                                      "note": "fwd + factor backward + all-gather of the payload rows + dense rebuild on every rank"}
     return out
 
 

@@ -149,6 +149,23 @@ int vsel_lis_train_bwd(void* stream, const void* d_hnew, const void* h, vsel_dty
                        const float* ts, const float* d_ps_ext, float dl_dbce, void* workspace,
                        size_t workspace_bytes, float* dwq, float* dbq, float* dwk, float* dbk, void* dh);
 
+/* The same backward with the two weight gradients as their rank-1 FACTORS ("rank-1-factor all-gather",
+ * the data-parallel exchange of qwen-vl-finetune/scripts/sft_7b.sh:9-12,71-74 with 2 (Hd + D) + 2 Hd floats per micro-batch
+ * instead of 2 Hd D + 2 Hd):   dWq = a (x) gx,   dWk = dk (x) xsum.
+ *   out: factors float32 [2 (Hd + D)] = a [Hd] | gx [D] | dk [Hd] | xsum [D]; dbq, dbk float32 [Hd]; dh [N, D] or NULL.
+ * Nothing of size Hd x D is written (vsel_lis_train_bwd writes 2 Hd D floats per call).                              */
+int vsel_lis_train_bwd_factors(void* stream, const void* d_hnew, const void* h, vsel_dtype hdtype, int64_t n,
+                               const vsel_scorer* scorer, const float* ps, const float* y, const float* scores,
+                               const float* ts, const float* d_ps_ext, float dl_dbce, void* workspace,
+                               size_t workspace_bytes, float* factors, float* dbq, float* dbk, void* dh);
+
+/* Dense gradients from R payload rows of vsel_lis_train_bwd_factors (row = a | gx | dk | xsum | dbq | dbk, 2 (Hd + D) + 2 Hd
+ * floats each; own micro-batches and / or the rows all-gathered from the other ranks):
+ *   dwq = scale sum_i a_i (x) gx_i,  dwk = scale sum_i dk_i (x) xsum_i,  dbq = scale sum_i dbq_i,  dbk likewise  (i in order).
+ * scale = 1 / world gives the mean over ranks that the reference's DDP / ZeRO all-reduce leaves in .grad.                 */
+int vsel_lis_factors_to_grads(void* stream, const float* payload, int64_t n_rows, int64_t hd, int64_t d, float scale,
+                              float* dwq, float* dbq, float* dwk, float* dbk);
+
 /* Backward of TransformerScorer.forward alone (autograd through FT/compression_method/selector_scorer.py:47-53)
  * for one segment: g = dL/dscores [N] float32 -> dwq, dbq, dwk, dbk float32 (overwritten), dh [N, D] or NULL.
  * Workspace: vsel_lis_train_workspace_bytes(n, d, hd).                                             */

@@ -164,6 +164,51 @@ def _ddp_view_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _factor_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from visionselector_amd.ddp import LisFactorSync
+        from visionselector_amd.selector import TransformerScorer
+        torch.manual_seed(0)
+        m = TransformerScorer(48, 24, init_scale=0.02)
+        params = (m.q_proj.weight, m.q_proj.bias, m.k_proj.weight, m.k_proj.bias)
+        sync = LisFactorSync(params)
+        assert sync.row == 2 * (24 + 48) + 2 * 24
+        g = torch.Generator().manual_seed(50 + rank)
+        for _ in range(3):                                 # three micro-batches per rank
+            sync.add(torch.randn(sync.row, generator=g))
+        sync.sync()
+        torch.save([p.grad.clone() for p in params], os.path.join(out_dir, f"f{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_lis_factor_sync_gloo_world2(tmp_path):
+    """Rank-1-factor exchange: all-gather of the per-micro-batch payload rows, dense mean gradient rebuilt on every rank ==
+    the mean over ranks of the summed dense gradients (what LisGradSync's all-reduce leaves)."""
+    world, hd, d = 2, 24, 48
+    mp.spawn(_factor_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "f0.pt")
+    r1 = torch.load(tmp_path / "f1.pt")
+    for a, b in zip(r0, r1):
+        assert torch.equal(a, b)
+    exp = [torch.zeros(hd, d, dtype=torch.float64), torch.zeros(hd, dtype=torch.float64),
+           torch.zeros(hd, d, dtype=torch.float64), torch.zeros(hd, dtype=torch.float64)]
+    for rank in range(world):
+        g = torch.Generator().manual_seed(50 + rank)
+        for _ in range(3):
+            row = torch.randn(2 * (hd + d) + 2 * hd, generator=g).double()
+            a, gx, dk, xs, dbq, dbk = torch.split(row, [hd, d, hd, d, hd, hd])
+            exp[0] += torch.outer(a, gx)
+            exp[1] += dbq
+            exp[2] += torch.outer(dk, xs)
+            exp[3] += dbk
+    for got, e in zip(r0, exp):
+        assert torch.allclose(got.double(), e / world, rtol=1e-5, atol=1e-5)
+
+
 def test_lis_grad_sync_bucket_view_gloo_world2(tmp_path):
     """bucket_view: p.grad are views of the flat bucket; the data-parallel mean is one all-reduce with no pack / unpack."""
     world = 2

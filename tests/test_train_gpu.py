@@ -179,3 +179,27 @@ def test_train_bf16_end_to_end_tolerance(ops):
     assert np.array_equal(y.cpu().numpy(), y_ref)
     assert abs(float(bce[0]) - float(olis.bce_mean(ps_ref, y_ref))) <= 1e-4
     assert np.abs(h_new.float().cpu().numpy() - hn_ref).max() <= 1e-3 * max(1.0, np.abs(hn_ref).max()) * 8
+
+
+def test_train_bwd_factors_rebuild_the_dense_gradients(ops):
+    """vsel_lis_train_bwd_factors: dWq = a (x) gx, dWk = dk (x) xsum, same dbq / dbk / dh as the dense backward; through
+    ddp.LisFactorSync (world 1) the rebuilt gradients equal the dense ones to fp32 rounding."""
+    from visionselector_amd.ddp import LisFactorSync
+    d, hd, n, k = 2048, 1024, 600, 120
+    c = oin.make_case(d, hd, n, 91)
+    h, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    dhn = (torch.randn(n, d, device="cuda", generator=g) / d ** 0.5).bfloat16()
+    h_new, ps, y, scores, ts, bce = ops.lis_train_fwd(h, wq, bq, wk, bk, k)
+    dwq, dbq, dwk, dbk, dh = ops.lis_train_bwd(dhn, h, wq, bq, wk, bk, ps, y, scores, ts, None, 0.7, need_dh=True)
+    payload, dh2 = ops.lis_train_bwd_factors(dhn, h, wq, bq, wk, bk, ps, y, scores, ts, None, 0.7, need_dh=True)
+    a, gx, dk, xs, dbq2, dbk2 = ops.factor_payload_split(payload, hd, d)
+    assert torch.equal(dbq2, dbq) and torch.equal(dbk2, dbk) and torch.equal(dh2, dh)
+    assert torch.equal(torch.outer(a, gx), dwq) and torch.equal(torch.outer(dk, xs), dwk)       # the dense kernel writes a_r * b_c
+    params = [torch.nn.Parameter(t.float()) for t in (wq, bq, wk, bk)]
+    sync = LisFactorSync(params)
+    for _ in range(2):                                      # two identical micro-batches: the gradients add
+        ops.lis_train_bwd_factors(dhn, h, wq, bq, wk, bk, ps, y, scores, ts, None, 0.7, out=sync.new_row(h.device))
+    sync.sync()
+    for p, ref in zip(params, (dwq, dbq, dwk, dbk)):
+        assert float((p.grad - 2 * ref).abs().max()) <= 2e-6 * max(1e-30, float(ref.abs().max())) + 1e-12

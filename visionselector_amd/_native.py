@@ -46,6 +46,8 @@ SIGNATURES = {
     "vsel_lis_train_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "vsel_lis_train_fwd": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _SC, _P, _SZ, _P, _P, _P, _P, _P, _P]),
     "vsel_lis_train_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _SC, _P, _P, _P, _P, _P, _F, _P, _SZ, _P, _P, _P, _P, _P]),
+    "vsel_lis_factors_to_grads": (C.c_int, [_P, _P, _I64, _I64, _I64, _F, _P, _P, _P, _P]),
+    "vsel_lis_train_bwd_factors": (C.c_int, [_P, _P, _P, C.c_int, _I64, _SC, _P, _P, _P, _P, _P, _F, _P, _SZ, _P, _P, _P, _P]),
     "vsel_lis_scores_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _SC, _P, _SZ, _P, _P, _P, _P, _P]),
     "vsel_gelu_colsum_workspace_bytes": (_SZ, [_SEG, _I64]),
     "vsel_gelu_colsum": (C.c_int, [_P, _P, C.c_int, _SEG, _I64, _P, _P, _P, _SZ]),

@@ -341,6 +341,52 @@ __global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ a,
   }
 }
 
+// Rank-1-factor exchange (vsel_lis_factors_to_grads): R payload rows a_i | gx_i | dk_i | xsum_i | dbq_i | dbk_i ->
+//   dwq[r][c] = scale sum_i a_i[r] gx_i[c],  dwk[r][c] = scale sum_i dk_i[r] xsum_i[c]   (i in order; fp32)
+// grid (ceil(cols / 1024), row blocks, 2 = {dwq, dwk}); a block stages its <= 64 x R left factors through LDS.
+__global__ __launch_bounds__(256) void outer_sum_kernel(const float* __restrict__ payload, int R, int64_t row_stride, int hd, int d,
+                                                        float scale, float* __restrict__ dwq, float* __restrict__ dwk) {
+  const int which = blockIdx.z;
+  const float* left = payload + (which ? hd + d : 0);              // a / dk   [hd]
+  const float* right = payload + (which ? 2 * hd + d : hd);         // gx / xsum [d]
+  float* out = which ? dwk : dwq;
+  const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool c_ok = c4 < d;
+  f32x4 bv[8];
+  for (int r = blockIdx.y; r < hd; r += gridDim.y) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 < R; i0 += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bv[u] = *reinterpret_cast<const f32x4*>(right + (int64_t)min(i0 + u, R - 1) * row_stride + (c_ok ? c4 : 0));
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u < R) {
+          const float av = left[(int64_t)(i0 + u) * row_stride + r];
+          acc[0] = fmaf(av, bv[u][0], acc[0]);
+          acc[1] = fmaf(av, bv[u][1], acc[1]);
+          acc[2] = fmaf(av, bv[u][2], acc[2]);
+          acc[3] = fmaf(av, bv[u][3], acc[3]);
+        }
+    }
+    if (c_ok) *reinterpret_cast<f32x4*>(out + (int64_t)r * d + c4) = acc * scale;
+  }
+}
+
+// dbq[h] = scale sum_i dbq_i[h], dbk likewise (i in order)
+__global__ __launch_bounds__(256) void bias_sum_kernel(const float* __restrict__ payload, int R, int64_t row_stride, int hd, int d,
+                                                       float scale, float* __restrict__ dbq, float* __restrict__ dbk) {
+  const int h = blockIdx.x * 256 + threadIdx.x;
+  if (h >= hd) return;
+  const float* p = payload + 2 * (hd + d) + h;
+  float s0 = 0.f, s1 = 0.f;
+  for (int i = 0; i < R; ++i) {
+    s0 += p[(int64_t)i * row_stride];
+    s1 += p[(int64_t)i * row_stride + hd];
+  }
+  dbq[h] = s0 * scale;
+  dbk[h] = s1 * scale;
+}
+
 // dh[i,:] = ps[i] d_hnew[i,:] + (g[i] rs) w[:] + u[:]      (first term dropped when dhn == NULL)
 template <typename T>
 __global__ __launch_bounds__(256) void dh_kernel(const T* __restrict__ dhn, const float* __restrict__ ps,
@@ -432,17 +478,19 @@ static int train_fwd_impl(hipStream_t st, const T* h, int64_t n, int64_t k, cons
 template <typename T, typename TW>
 static int scores_bwd_impl(hipStream_t st, const float* g, const T* h, int64_t n, const vsel_scorer* sc, char* ws,
                            const TrainPlan& tp, float* dwq, float* dbq, float* dwk, float* dbk, T* dh, const T* dhn,
-                           const float* ps) {
+                           const float* ps, float* factors = nullptr) {
   constexpr int V = Elem<T>::kVec;
   const int d = (int)sc->d, hd = (int)sc->hd;
   const LisPlan& p = tp.lis;
   float* wpart = (float*)(ws + tp.off_wpart);
-  float* xsum = (float*)(ws + tp.off_xsum);
-  float* gx = (float*)(ws + tp.off_gx);
+  // factors != NULL: the rank-1 factors of the weight gradients go to the caller (a | gx | dk | xsum) and the two dense
+  // [Hd, D] writes are skipped (vsel_lis_train_bwd_factors)
+  float* xsum = factors ? factors + 2 * hd + d : (float*)(ws + tp.off_xsum);
+  float* gx = factors ? factors + hd : (float*)(ws + tp.off_gx);
   float* sg = (float*)(ws + tp.off_sg);
   float* dkraw = (float*)(ws + tp.off_dkraw);
-  float* dk = (float*)(ws + tp.off_dk);
-  float* a = (float*)(ws + tp.off_a);
+  float* dk = factors ? factors + hd + d : (float*)(ws + tp.off_dk);
+  float* a = factors ? factors : (float*)(ws + tp.off_a);
   float* u = (float*)(ws + tp.off_u);
   float* xbar = (float*)(ws + p.off_xbar);
   float* part1 = (float*)(ws + p.off_part1);
@@ -488,11 +536,13 @@ static int scores_bwd_impl(hipStream_t st, const float* g, const T* h, int64_t n
   hipLaunchKernelGGL((dk_finish_kernel<TW>), dim3((unsigned)cdiv(hd, 256)), dim3(256), 0, st, dkraw, p.ks1, hd,
                      (const TW*)sc->bq, kbar, sg, rs, (int)n, dk, a, dbq, dbk);
   VSEL_AFTER_LAUNCH(st, "dk_finish_kernel");
-  const dim3 og((unsigned)cdiv(d, 1024), (unsigned)std::min<int>(hd, 512));
-  hipLaunchKernelGGL(outer_kernel, og, dim3(256), 0, st, a, gx, hd, d, dwq);
-  VSEL_AFTER_LAUNCH(st, "outer_kernel");
-  hipLaunchKernelGGL(outer_kernel, og, dim3(256), 0, st, dk, xsum, hd, d, dwk);
-  VSEL_AFTER_LAUNCH(st, "outer_kernel");
+  if (!factors) {
+    const dim3 og((unsigned)cdiv(d, 1024), (unsigned)std::min<int>(hd, 512));
+    hipLaunchKernelGGL(outer_kernel, og, dim3(256), 0, st, a, gx, hd, d, dwq);
+    VSEL_AFTER_LAUNCH(st, "outer_kernel");
+    hipLaunchKernelGGL(outer_kernel, og, dim3(256), 0, st, dk, xsum, hd, d, dwk);
+    VSEL_AFTER_LAUNCH(st, "outer_kernel");
+  }
   if (dh) {
     hipLaunchKernelGGL((gemm_nn_kernel<TW>), dim3((unsigned)cdiv(d, 256), 1, p.ks2), dim3(64), 0, st, kbar, (const TW*)sc->wq, 1,
                        d, hd, p.kslice2, part2);
@@ -513,7 +563,8 @@ static int scores_bwd_impl(hipStream_t st, const float* g, const T* h, int64_t n
 template <typename T, typename TW>
 static int train_bwd_impl(hipStream_t st, const T* dhn, const T* h, int64_t n, const vsel_scorer* sc, const float* ps,
                           const float* y, const float* scores, const float* ts, const float* d_ps_ext, float dl_dbce,
-                          char* ws, const TrainPlan& tp, float* dwq, float* dbq, float* dwk, float* dbk, T* dh) {
+                          char* ws, const TrainPlan& tp, float* dwq, float* dbq, float* dwk, float* dbk, T* dh,
+                          float* factors = nullptr) {
   const int d = (int)sc->d;
   float* dps = (float*)(ws + tp.off_dps);
   float* g = (float*)(ws + tp.off_g);
@@ -522,7 +573,7 @@ static int train_bwd_impl(hipStream_t st, const T* dhn, const T* h, int64_t n, c
   VSEL_AFTER_LAUNCH(st, "rowdot_kernel");
   int rc = launch_soft_topk_bwd(st, dps, scores, ts, 1, n, g);
   if (rc) return rc;
-  return scores_bwd_impl<T, TW>(st, g, h, n, sc, ws, tp, dwq, dbq, dwk, dbk, dh, dhn, ps);
+  return scores_bwd_impl<T, TW>(st, g, h, n, sc, ws, tp, dwq, dbq, dwk, dbk, dh, dhn, ps, factors);
 }
 
 }  // namespace vsel
@@ -584,6 +635,39 @@ extern "C" int vsel_lis_train_bwd(void* stream, const void* d_hnew, const void* 
   VSEL_DISPATCH2(hdtype, sc->wdtype,
                  (train_bwd_impl<T, TW>(s, (const T*)d_hnew, (const T*)h, n, sc, ps, y, scores, ts, d_ps_ext, dl_dbce,
                                         (char*)ws, tp, dwq, dbq, dwk, dbk, (T*)dh)));
+}
+
+extern "C" int vsel_lis_train_bwd_factors(void* stream, const void* d_hnew, const void* h, vsel_dtype hdtype, int64_t n,
+                                          const vsel_scorer* sc, const float* ps, const float* y, const float* scores,
+                                          const float* ts, const float* d_ps_ext, float dl_dbce, void* ws, size_t ws_bytes,
+                                          float* factors, float* dbq, float* dbk, void* dh) {
+  TrainPlan tp;
+  int st = train_checks(h, hdtype, n, sc, ws, ws_bytes, &tp);
+  if (st) return st;
+  if (!d_hnew || !ps || !y || !scores || !ts || !factors || !dbq || !dbk) return fail(VSEL_ERR_INVALID, "NULL pointer");
+  if (sc->d % 4 || sc->hd % 4) return fail(VSEL_ERR_UNSUPPORTED, "D and Hd must be multiples of 4");
+  hipStream_t s = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(s);
+  VSEL_DISPATCH2(hdtype, sc->wdtype,
+                 (train_bwd_impl<T, TW>(s, (const T*)d_hnew, (const T*)h, n, sc, ps, y, scores, ts, d_ps_ext, dl_dbce,
+                                        (char*)ws, tp, nullptr, dbq, nullptr, dbk, (T*)dh, factors)));
+}
+
+extern "C" int vsel_lis_factors_to_grads(void* stream, const float* payload, int64_t n_rows, int64_t hd, int64_t d, float scale,
+                                        float* dwq, float* dbq, float* dwk, float* dbk) {
+  if (!payload || !dwq || !dbq || !dwk || !dbk) return fail(VSEL_ERR_INVALID, "NULL pointer");
+  if (n_rows < 1 || hd < 1 || d < 1 || n_rows > (1 << 20)) return fail(VSEL_ERR_INVALID, "bad shape");
+  if (d % 4 || hd % 4) return fail(VSEL_ERR_UNSUPPORTED, "D and Hd must be multiples of 4");
+  hipStream_t st = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(st);
+  const int64_t row = 2 * (hd + d) + 2 * hd;
+  const dim3 og((unsigned)cdiv(d, 1024), (unsigned)std::min<int64_t>(hd, 512), 2);
+  hipLaunchKernelGGL(outer_sum_kernel, og, dim3(256), 0, st, payload, (int)n_rows, row, (int)hd, (int)d, scale, dwq, dwk);
+  VSEL_AFTER_LAUNCH(st, "outer_sum_kernel");
+  hipLaunchKernelGGL(bias_sum_kernel, dim3((unsigned)cdiv(hd, 256)), dim3(256), 0, st, payload, (int)n_rows, row, (int)hd, (int)d,
+                     scale, dbq, dbk);
+  VSEL_AFTER_LAUNCH(st, "bias_sum_kernel");
+  return VSEL_OK;
 }
 
 extern "C" int vsel_lis_scores_bwd(void* stream, const float* g, const void* h, vsel_dtype hdtype, int64_t n,

@@ -114,6 +114,88 @@ class LisGradSync:
             dist.broadcast(p.data, src=src, group=self.group)
 
 
+class LisFactorSync:
+    """The same exchange with the scorer's weight gradients as rank-1 FACTORS ("rank-1-factor all-gather").
+
+    Each micro-batch's LIS backward yields dWq = a (x) gx and dWk = dk (x) xsum (ops.lis_train_bwd_factors: one payload row of
+    2 (Hd + D) + 2 Hd floats = 57 KB at 7B instead of two dense [Hd, D] gradients = 51.4 MB).  A rank collects the payload rows
+    of its micro-batches; sync() all-gathers them (world x micro-batches rows -- on xGMI a 57 KB-per-rank all-gather instead of
+    a 51 MB all-reduce) and every rank rebuilds the mean gradient itself:
+        dWq = A^T GX / world,  dWk = DK^T XS / world        (two [Hd, R] x [R, D] GEMMs, R = world x micro-batches)
+        dbq, dbk = column sums of the gathered bias rows / world
+    which is what LisGradSync.sync() leaves in p.grad (sum over a rank's micro-batches, mean over ranks), up to fp32 rounding.
+    params = (q_proj.weight, q_proj.bias, k_proj.weight, k_proj.bias) in that order."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None):
+        self.params: List[torch.nn.Parameter] = list(params)
+        if len(self.params) != 4:
+            raise ValueError("LisFactorSync takes (q_proj.weight, q_proj.bias, k_proj.weight, k_proj.bias)")
+        wq, bq, wk, bk = self.params
+        if wq.dim() != 2 or wq.shape != wk.shape or bq.shape != (wq.shape[0],) or bk.shape != (wq.shape[0],):
+            raise ValueError("unexpected scorer parameter shapes")
+        self.hd, self.d = int(wq.shape[0]), int(wq.shape[1])
+        self.row = 2 * (self.hd + self.d) + 2 * self.hd
+        self.group = group
+        self._buf: Optional[torch.Tensor] = None       # [capacity, row] payload rows of this step's micro-batches
+        self._n = 0
+        self._gathered: Optional[torch.Tensor] = None
+        self._grads: Optional[List[torch.Tensor]] = None
+
+    def new_row(self, device) -> torch.Tensor:
+        """A payload row for the next micro-batch (pass it as ops.lis_train_bwd_factors(out=...))."""
+        if self._buf is None or self._buf.device != torch.device(device) or self._n == self._buf.shape[0]:
+            cap = 4 if self._buf is None else 2 * self._buf.shape[0]
+            buf = torch.empty(cap, self.row, dtype=torch.float32, device=device)
+            if self._buf is not None and self._n:
+                buf[:self._n].copy_(self._buf[:self._n])
+            self._buf = buf
+        self._n += 1
+        return self._buf[self._n - 1]
+
+    def add(self, payload: torch.Tensor) -> None:
+        if payload.numel() != self.row or payload.dtype != torch.float32:
+            raise ValueError(f"payload must be float32 [{self.row}]")
+        self.new_row(payload.device).copy_(payload.reshape(-1))
+
+    def zero_grads(self) -> None:
+        self._n = 0
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def sync(self) -> None:
+        """p.grad <- mean over ranks of the sum over this step's micro-batches (every rank must have added the same number of rows)."""
+        if not self._n:
+            raise RuntimeError("LisFactorSync.sync(): no micro-batch payload was added")
+        local = self._buf[:self._n]                                      # [M, row], contiguous
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world > 1:
+            if self._gathered is None or self._gathered.shape[0] != world * self._n or self._gathered.device != local.device:
+                self._gathered = torch.empty(world * self._n, self.row, dtype=torch.float32, device=local.device)
+            dist.all_gather_into_tensor(self._gathered, local, group=self.group)
+            gathered = self._gathered
+        else:
+            gathered = local
+        hd, d = self.hd, self.d
+        inv = 1.0 / world
+        if gathered.is_cuda:
+            # one launch writes both dense gradients (sums over the rows in order, fp32), one the two bias gradients
+            from . import ops
+            if self._grads is None or self._grads[0].device != gathered.device:
+                self._grads = [torch.empty(hd, d, dtype=torch.float32, device=gathered.device),
+                               torch.empty(hd, dtype=torch.float32, device=gathered.device),
+                               torch.empty(hd, d, dtype=torch.float32, device=gathered.device),
+                               torch.empty(hd, dtype=torch.float32, device=gathered.device)]
+            ops.factors_to_grads(gathered, hd, d, inv, out=self._grads)
+            grads = self._grads
+        else:                                                            # host tensors (the gloo tests of the exchange logic)
+            a, gx, dk, xs, dbq, dbk = torch.split(gathered, [hd, d, hd, d, hd, hd], dim=1)
+            grads = [(a.t() @ gx) * inv, dbq.sum(0) * inv, (dk.t() @ xs) * inv, dbk.sum(0) * inv]
+        for p, g in zip(self.params, grads):
+            p.grad = g if g.dtype == p.dtype else g.to(p.dtype)
+        self._n = 0
+
+
 def shard_units(n_units: int, rank: int, world: int) -> range:
     """Round-robin sharding of independent units (images / samples) over ranks -- the eval harness's accelerate DDP
     split (qwen-evaluation/run_selector.sh:11-18), no data-path collective."""

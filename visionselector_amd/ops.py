@@ -338,6 +338,50 @@ def lis_train_bwd(d_hnew, h, wq, bq, wk, bk, ps, y, scores, ts, d_ps_ext=None, d
     return dwq, dbq, dwk, dbk, dh
 
 
+def lis_train_bwd_factors(d_hnew, h, wq, bq, wk, bk, ps, y, scores, ts, d_ps_ext=None, dl_dbce: float = 0.0,
+                          need_dh: bool = False, out=None):
+    """The same backward with the weight gradients as rank-1 factors: -> (payload fp32 [2 (Hd + D) + 2 Hd], dh or None),
+    payload = a [Hd] | gx [D] | dk [Hd] | xsum [D] | dbq [Hd] | dbk [Hd]  with  dWq = a (x) gx,  dWk = dk (x) xsum
+    (factor_payload_split / ddp.LisFactorSync turn payloads into dense gradients).  out = a contiguous fp32 row to overwrite."""
+    dev = _dev(d_hnew, h, wq, bq, wk, bk, ps, y, scores, ts, d_ps_ext)
+    n, d = h.shape
+    sc = _scorer(wq, bq, wk, bk)
+    lib = N.lib()
+    ws = _workspace(lib.vsel_lis_train_workspace_bytes(n, d, sc.hd), dev)
+    numel = 2 * (sc.hd + d) + 2 * sc.hd
+    if out is None:
+        out = torch.empty(numel, dtype=torch.float32, device=dev)
+    elif out.dtype != torch.float32 or out.numel() != numel or not out.is_contiguous() or out.device != dev:
+        raise ValueError(f"lis_train_bwd_factors(out=...): need a contiguous float32 buffer of {numel} elements on the same device")
+    dh = torch.empty_like(h) if need_dh else None
+    base = out.data_ptr()
+    fac_bytes = 2 * (sc.hd + d) * 4
+    N.check(lib.vsel_lis_train_bwd_factors(_stream(), d_hnew.data_ptr(), h.data_ptr(), _code(h), n, C.byref(sc), ps.data_ptr(),
+                                           y.data_ptr(), scores.data_ptr(), ts.data_ptr(), _p(d_ps_ext), float(dl_dbce),
+                                           ws.data_ptr(), ws.numel(), base, base + fac_bytes, base + fac_bytes + 4 * sc.hd,
+                                           _p(dh)))
+    return out, dh
+
+
+def factors_to_grads(payload: torch.Tensor, hd: int, d: int, scale: float = 1.0, out=None):
+    """payload fp32 [R, 2 (Hd + D) + 2 Hd] (rows of lis_train_bwd_factors, own and / or all-gathered) ->
+    (dwq [Hd, D], dbq [Hd], dwk [Hd, D], dbk [Hd]) = scale x the sums over the rows, in row order."""
+    dev = _dev(payload)
+    row = 2 * (hd + d) + 2 * hd
+    if payload.dtype != torch.float32 or payload.dim() != 2 or payload.shape[1] != row or not payload.is_contiguous():
+        raise ValueError(f"payload must be contiguous float32 [R, {row}]")
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    dwq, dbq, dwk, dbk = out if out is not None else (f(hd, d), f(hd), f(hd, d), f(hd))
+    N.check(N.lib().vsel_lis_factors_to_grads(_stream(), payload.data_ptr(), payload.shape[0], hd, d, float(scale), dwq.data_ptr(),
+                                              dbq.data_ptr(), dwk.data_ptr(), dbk.data_ptr()))
+    return dwq, dbq, dwk, dbk
+
+
+def factor_payload_split(payload: torch.Tensor, hd: int, d: int):
+    """payload [..., 2 (Hd + D) + 2 Hd] -> (a [..., Hd], gx [..., D], dk [..., Hd], xsum [..., D], dbq [..., Hd], dbk [..., Hd])."""
+    return torch.split(payload, [hd, d, hd, d, hd, hd], dim=-1)
+
+
 def lis_scores_bwd(g, h, wq, bq, wk, bk, need_dh: bool = False):
     """Backward of lis_scores for one segment: g fp32 [N], h [N,D] -> (dwq, dbq, dwk, dbk fp32, dh or None)."""
     dev = _dev(g, h, wq, bq, wk, bk)
@@ -616,7 +660,7 @@ def paged_attn(q, k_cache, v_cache, cu_seqlens_q: torch.Tensor, seqlens_k: torch
 
 # every op that reaches libvsel switches to its tensors' device first
 for _name in ("lis_scores", "lis_select", "lis_select_permuted", "gelu_colsum", "lis_select_presummed", "lis_select_varlen",
-              "hard_topk", "gather_rows", "soft_topk_fwd", "soft_topk_bwd", "lis_train_fwd", "lis_train_bwd", "lis_scores_bwd",
+              "hard_topk", "gather_rows", "soft_topk_fwd", "soft_topk_bwd", "lis_train_fwd", "lis_train_bwd", "lis_train_bwd_factors", "factors_to_grads", "lis_scores_bwd",
               "splice", "splice_batched", "varlen_attn", "varlen_attn_fwd_lse", "varlen_attn_bwd", "varlen_attn_kv",
               "attn_head_major", "paged_attn"):
     globals()[_name] = _device_guard(globals()[_name])

@@ -58,6 +58,21 @@ def _rccl_worker(rank, world, port, out):
     torch.cuda.synchronize()
     want = sum(range(1, world + 1)) / world
     ok = all(bool(torch.allclose(p.grad, torch.full_like(p.grad, want))) for p in ps)
+    # the rank-1-factor exchange: all-gather of payload rows over RCCL, dense rebuild by vsel_lis_factors_to_grads
+    from visionselector_amd.ddp import LisFactorSync
+    hd, d = 8, 16
+    fp = [torch.nn.Parameter(torch.zeros(hd, d, device="cuda")), torch.nn.Parameter(torch.zeros(hd, device="cuda")),
+          torch.nn.Parameter(torch.zeros(hd, d, device="cuda")), torch.nn.Parameter(torch.zeros(hd, device="cuda"))]
+    fs = LisFactorSync(fp)
+    g = torch.Generator().manual_seed(1000 + rank)
+    fs.add(torch.randn(fs.row, generator=g).cuda())
+    fs.sync()
+    torch.cuda.synchronize()
+    exp = torch.zeros(hd, d, dtype=torch.float64)
+    for r in range(world):
+        row = torch.randn(fs.row, generator=torch.Generator().manual_seed(1000 + r)).double()
+        exp += torch.outer(row[:hd], row[hd:hd + d])
+    ok = ok and bool(torch.allclose(fp[0].grad.double().cpu(), exp / world, rtol=1e-5, atol=1e-6))
     if rank == 0:
         out.put(ok)
     dist.barrier()

@@ -236,14 +236,17 @@ __global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint1
     typedef __attribute__((address_space(3))) void* lptr_t;
     const bool tail = __builtin_amdgcn_readfirstlane((int)(t * kTileK + kTileK > len)) != 0;
     if (!pg.block_table && !tail) {
+      // one 64-bit multiply per tensor and tile (the tile's first row of this wave), then a constant stride between slices
+      const char* kp = reinterpret_cast<const char*>(k + kv_base + (int64_t)(t * kTileK + 4 * wave_u) * kv_rs);
+      const char* vp = reinterpret_cast<const char*>(v + v_base + (int64_t)(t * kTileK + 4 * wave_u) * v_rs);
+      const int64_t k_step = 2 * 4 * GW * kv_rs, v_step = 2 * 4 * GW * v_rs;          // bytes from slice i to slice i + GW
 #pragma unroll
       for (int u = 0; u < kLoadsPerWave; ++u) {
         const int i = wave_u + GW * u;
-        const int64_t row = (int64_t)(t * kTileK + 4 * i);
-        const char* kp = reinterpret_cast<const char*>(k + kv_base + row * kv_rs);
-        const char* vp = reinterpret_cast<const char*>(v + v_base + row * v_rs);
         __builtin_amdgcn_global_load_lds((gptr_t)(kp + lane_off_k[u % NP]), (lptr_t)(k_sm + buf * kBuf + i * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(vp + lane_off_v[u % NP]), (lptr_t)(v_sm + buf * kBuf + i * 1024), 16, 0, 0);
+        kp += k_step;
+        vp += v_step;
       }
       return;
     }

@@ -115,7 +115,10 @@ static int select_whole(hipStream_t st, const T* h, const vsel_segments* seg, co
   rc = run_score<T>(st, h, seg, sc, ws, p, scores, p2l);
   if (rc) return rc;
   // up to g_fused_select_max_seg segments: the radix select runs inside every gather workgroup (one launch less; same indices)
-  if (seg->n_seg <= g_fused_select_max_seg) return launch_select_gather_small<T>(st, h, (int)sc->d, seg, scores, idx, out, l2p);
+  // (every gather workgroup repeats its segment's select: not when there are thousands of them -- 32 images at 50 % retain:
+  // 308.0 vs 305.7 us)
+  if (seg->n_seg <= g_fused_select_max_seg && seg->n_seg * cdiv(seg->k, 16) <= 1536)
+    return launch_select_gather_small<T>(st, h, (int)sc->d, seg, scores, idx, out, l2p);
   rc = launch_select(st, scores, seg, idx, nullptr);
   if (rc) return rc;
   return launch_gather<T>(st, h, (int)sc->d, seg, idx, out, l2p);

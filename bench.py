@@ -314,11 +314,12 @@ def bench_train_step(ops, dist, world, rank, iters=20):
     train_qwen_selector.py:60-92.  Max over ranks; tokens/s is the whole-job aggregate."""
     from visionselector_amd.selector import curriculum_weight
     d, hd = D, HD
-    gen = torch.Generator(device="cuda").manual_seed(4321 + rank)
-    wq = (0.02 * torch.randn(hd, d, device="cuda", generator=gen)).bfloat16()
-    wk = (0.02 * torch.randn(hd, d, device="cuda", generator=gen)).bfloat16()
-    bq = (0.02 * torch.randn(hd, device="cuda", generator=gen)).bfloat16()
-    bk = (0.02 * torch.randn(hd, device="cuda", generator=gen)).bfloat16()
+    wgen = torch.Generator(device="cuda").manual_seed(4321)          # ONE scorer, replicated on every rank (data parallel:
+    wq = (0.02 * torch.randn(hd, d, device="cuda", generator=wgen)).bfloat16()   # the mean of the gradients is a gradient of
+    wk = (0.02 * torch.randn(hd, d, device="cuda", generator=wgen)).bfloat16()   # these weights only if they are the same)
+    bq = (0.02 * torch.randn(hd, device="cuda", generator=wgen)).bfloat16()
+    bk = (0.02 * torch.randn(hd, device="cuda", generator=wgen)).bfloat16()
+    gen = torch.Generator(device="cuda").manual_seed(8765 + rank)    # each rank its own micro-batches
     bucket = torch.zeros(2 * (hd * d + hd), dtype=torch.float32, device="cuda")
     views, off = [], 0
     for shape in ((hd, d), (hd,), (hd, d), (hd,)):

@@ -23,7 +23,8 @@ What is executed from the reference (paths under /root/reference):
         merger), and LLaVAOneVision1_5_Model_Selector.forward (splice :259-276, 1-D position_ids / cache_position /
         attention_mask selection :308-314) on a recording language model
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--ov-only | --bf16-only]
+        (--bf16-only: the same LIS cases with the reference modules and tokens in bfloat16 -> lisbf16_*.npz)
 """
 import importlib.machinery
 import os
@@ -190,6 +191,60 @@ def gen_lis_case(name, d, hd, n, seed, ft, ev, TransformerScorer):
         out["train_hnew"] = h_new.detach().numpy().astype(np.float32)
     np.savez_compressed(os.path.join(HERE, f"lis_{name}.npz"), **out)
     print(f"{name}: N={n} gaps/std={out['gaps'] / out['score_std']} bce={out['train_bce']:.6f} ts={out['topk_ts']:.6f}")
+
+
+def gen_lis_bf16_case(name, d, hd, n, seed, ft, ev, TransformerScorer):
+    """The reference as its users run it: scorer module and tokens in bfloat16 (FT/qwenvl/train/train_qwen_selector.py:175-180
+    loads and trains in bf16; `_find_ts` runs in the dtype of its input, FT/compression_method/selector_model.py:72-86).
+    Same seeded inputs as lis_<name>.npz (bf16-representable), every module op rounding to bf16 as torch CPU does.
+    Stored: bf16 scores, EV selection (indices, soft mask `last_combined_scores`) for the three budgets, `_find_ts` in bf16,
+    the training forward (soft mask, constraint mask, BCE), and the tie census at each k boundary."""
+    case = oin.make_case(d, hd, n, seed)
+    scorer = build_scorer(TransformerScorer, case).bfloat16()
+    h = torch.from_numpy(case["h"]).bfloat16()
+    grid = torch.tensor([[1, 1, n]])
+    out = {"d": d, "hd": hd, "n": n, "seed": seed}
+    with torch.no_grad():
+        scores = scorer(h[None])[0]
+    assert scores.dtype == torch.bfloat16
+    out["scores_bf16"] = scores.float().numpy()
+    sf = out["scores_bf16"]
+    for r in oin.BUDGETS:
+        stub = StubTower(scorer, r, n, training=False)
+        with torch.no_grad():
+            h_new, idx, total = ev.Qwen2_5_VisionTransformerPretrainedModel_Selector.forward(stub, h, grid)
+        tag = str(r).replace(".", "p")
+        k = max(1, int(n * r))
+        assert idx.numel() == k and torch.equal(h_new, h[idx])
+        out[f"idx_bf16_{tag}"] = idx.numpy().astype(np.int64)
+        ps = stub.last_combined_scores
+        assert ps.dtype == torch.bfloat16
+        out[f"ps_bf16_{tag}"] = ps.float().numpy()
+        out[f"sum_ps_bf16_{tag}"] = np.float64(ps.double().sum().item())
+        kth = np.sort(sf)[::-1][k - 1]
+        out[f"ties_at_kth_{tag}"] = np.int64((sf == kth).sum())          # candidates tied at the k-th value (torch.topk
+        out[f"above_kth_{tag}"] = np.int64((sf > kth).sum())              # breaks them in an unspecified order)
+    k = int(n * 0.2)
+    with torch.no_grad():
+        ts, ps = ft._find_ts(scores[None], k)
+    out["topk_k"] = k
+    out["ts_bf16"] = np.float32(ts.float().item())
+    out["ps_bf16"] = ps[0].float().numpy()
+    out["sum_ps_bf16"] = np.float64(ps.double().sum().item())
+    stub = StubTower(scorer, 0.2, n, training=True)
+    with torch.no_grad():
+        h_new, img_mask, cmask = ft.qwen25vl_vision_tower_forward_selector(stub, h, grid)
+        bce = F.binary_cross_entropy(img_mask.float(), cmask.float())
+    out["train_ps_bf16"] = img_mask.float().numpy()
+    out["train_y_bf16"] = cmask.float().numpy()
+    out["train_bce_bf16"] = np.float32(bce.item())
+    out["train_hnew_rowsum_bf16"] = h_new.double().sum(1).numpy()
+    g32 = np.load(os.path.join(HERE, f"lis_{name}.npz"))
+    d32 = np.abs(sf - g32["scores"]).max()
+    sym = {t: len(set(out[f"idx_bf16_{t}"]) ^ set(g32[f"idx_{t}"])) for t in ("0p1", "0p2", "0p5")}
+    np.savez_compressed(os.path.join(HERE, f"lisbf16_{name}.npz"), **out)
+    print(f"bf16 {name}: N={n} max|s_bf16 - s_fp32|={d32:.3e} (max|s|={np.abs(g32['scores']).max():.3f}) "
+          f"sym.diff vs fp32 idx={sym} sum(ps)={out['sum_ps_bf16']:.3f} (k={k}) ts={out['ts_bf16']:.5f}")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -429,6 +484,10 @@ def main():
     ft, TransformerScorer = load_ft()
     ev = load_ev()
     torch.manual_seed(0)
+    if "--bf16-only" in sys.argv:
+        for name, d, hd, n, seed in oin.GOLDEN_CASES:
+            gen_lis_bf16_case(name, d, hd, n, seed, ft, ev, TransformerScorer)
+        return
     for name, d, hd, n, seed in oin.GOLDEN_CASES:
         gen_lis_case(name, d, hd, n, seed, ft, ev, TransformerScorer)
     gen_splice_case("image_a", ev, "image", 64, (1, 16, 16), 7, 12, 12, 21)

@@ -17,10 +17,21 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LOG = os.path.join(ROOT, "gpurun_out", "parity", "r02_parity.jsonl")
+ROUND = "r03"
+LOG = os.path.join(ROOT, "gpurun_out", "parity", f"{ROUND}_parity.jsonl")
 
-MAX_ULP_FWD = 2.0        # gate: every element within 2 bf16 ulps (ulp at its row's scale) of the bf16-rounded oracle
+MAX_ULP_FWD = 1.0        # gate: every element within 1 bf16 ulp (ulp at its row's scale) of the bf16-rounded oracle
+MAX_ULP_ROW8_FWD = 8.0   # gate: the same error counted with the ulp floor at rowmax / 8 (an element 8x below its row's
+                         # largest may be off by 1 row-scale ulp = 8 of its own; beyond that the error model is violated)
+MIN_FRAC_1ULP_ROW8 = 0.93  # gate: share of elements within ONE ulp at that finer scale (observed minimum 0.954, round 2)
 MEAN_ABS_FWD = 1e-3      # gate: mean |err| vs the un-rounded fp64 oracle
+
+# The reference's own bf16 run (tests/golden/lisbf16_*.npz: modules and tokens in bfloat16, every op rounding to bf16)
+# against the build's bf16-storage / fp32-accumulate path.  north_star: "soft scores ... within 1e-3 bf16".
+BF16_SCORE_TOL = 1e-3    # |score - reference bf16 score| <= 1e-3 * max(1, max|score|)
+BF16_IDX_FRAC = 0.01     # |idx (sym.diff) reference bf16 idx| <= max(2 * ties at the k-th value, 1 % of k)
+BF16_PS_TOL = 6e-3       # soft mask: the reference's bf16 bisection stalls at bf16 spacing of t (|dt| <= 2^-7 -> |dp| <= 2e-3)
+                         # and its p is rounded to bf16 (<= 2^-9 relative = 2e-3 near 1); observed worst logged
 
 
 def bf16_round(x: np.ndarray) -> np.ndarray:
@@ -77,5 +88,36 @@ def check_fwd(case: str, got: np.ndarray, ref64: np.ndarray, max_ulp: float = MA
     m = fwd_metrics(got, ref64)
     record(case, "attn_fwd", m)
     assert m["max_ulp_row"] <= max_ulp, (case, m)
+    assert m["max_ulp_row8"] <= MAX_ULP_ROW8_FWD * max_ulp, (case, m)
+    assert m["frac_within_1ulp"] >= MIN_FRAC_1ULP_ROW8 or m["n"] < 4096, (case, m)
     assert m["mean_abs_err"] <= MEAN_ABS_FWD * max(1.0, m["max_abs_ref"]), (case, m)
+    return m
+
+
+def lis_bf16_metrics(scores, idx_by_budget: dict, g) -> dict:
+    """scores fp32 [N] and {tag: idx} of the build against one lisbf16_*.npz (the reference's bf16 run)."""
+    ref = np.asarray(g["scores_bf16"], dtype=np.float64)
+    scores = np.asarray(scores, dtype=np.float64)
+    out = {"n": int(ref.size), "max_abs_dscore": float(np.abs(scores - ref).max()), "max_abs_ref": float(np.abs(ref).max())}
+    for tag, idx in idx_by_budget.items():
+        ridx = g[f"idx_bf16_{tag}"]
+        sym = sorted(set(idx.tolist()) ^ set(ridx.tolist()))
+        kth = np.sort(ref)[::-1][len(ridx) - 1]
+        out[f"k_{tag}"] = int(len(ridx))
+        out[f"symdiff_{tag}"] = len(sym)
+        out[f"ties_at_kth_{tag}"] = int(g[f"ties_at_kth_{tag}"])
+        out[f"symdiff_max_dist_to_kth_{tag}"] = float(max((abs(ref[i] - kth) for i in sym), default=0.0))
+    return out
+
+
+def check_lis_bf16(case: str, scores, idx_by_budget: dict, g) -> dict:
+    m = lis_bf16_metrics(scores, idx_by_budget, g)
+    record(case, "lis_bf16", m)
+    scale = max(1.0, m["max_abs_ref"])
+    assert m["max_abs_dscore"] <= BF16_SCORE_TOL * scale, (case, m)
+    for tag in idx_by_budget:
+        k = m[f"k_{tag}"]
+        assert m[f"symdiff_{tag}"] <= max(2 * m[f"ties_at_kth_{tag}"], 2, int(BF16_IDX_FRAC * k)), (case, tag, m)
+        # every disagreement sits at the k boundary: within the score tolerance of the reference's k-th bf16 score
+        assert m[f"symdiff_max_dist_to_kth_{tag}"] <= 2 * BF16_SCORE_TOL * scale, (case, tag, m)
     return m

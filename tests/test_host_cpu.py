@@ -3,6 +3,7 @@ monkeypatch call shapes, and the data-parallel gradient exchange over a world_si
 import os
 import socket
 import sys
+import types
 
 import numpy as np
 import pytest
@@ -227,6 +228,147 @@ def test_lis_grad_sync_bucket_view_gloo_world2(tmp_path):
         LisGradSync(torch.nn.Linear(2, 2).bfloat16().parameters(), bucket_view=True)
 
 
+# ---- LisTrainer(exchange="factors") vs the dense bucket, world 2 ------------------------------------------------------
+class _CpuLisFunction(torch.autograd.Function):
+    """TEST stand-in for selector._LisTrainFunction on the host (the product's forward needs the GPU library): collapsed scores
+    and the closed-form backward of SURVEY.md section 7 hard part 4, leaving either dense gradients or -- when
+    selector.factor_sink is active -- one payload row a | gx | dk | xsum | dbq | dbk, exactly as the HIP backward does."""
+
+    @staticmethod
+    def forward(ctx, h, wq, bq, wk, bk):
+        hd = wq.shape[0]
+        kbar = wk @ h.mean(0) + bk
+        ctx.save_for_backward(h, wq, bq, kbar)
+        return (h @ (wq.t() @ kbar) + bq @ kbar) / hd ** 0.5
+
+    @staticmethod
+    def backward(ctx, g):
+        from visionselector_amd import selector
+        h, wq, bq, kbar = ctx.saved_tensors
+        n, hd = h.shape[0], wq.shape[0]
+        a = kbar / hd ** 0.5
+        gx = g @ h
+        dk = (wq @ gx + bq * g.sum()) / (n * hd ** 0.5)
+        xsum = h.sum(0)
+        dbq, dbk = a * g.sum(), n * dk
+        sink = selector.active_factor_sink()
+        if sink is not None:
+            sink.add(torch.cat([a, gx, dk, xsum, dbq, dbk]))
+            return None, None, None, None, None
+        return None, torch.outer(a, gx), dbq, torch.outer(dk, xsum), dbk
+
+
+class _CpuLisModel(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        from visionselector_amd.selector import TransformerScorer
+        self.visual = torch.nn.Module()
+        self.visual.importance_scorer = TransformerScorer(48, 24, init_scale=0.05)
+        self.frozen = torch.nn.Linear(4, 4)
+        self.regularization_weight = 0.0
+
+    def forward(self, h, c):
+        sc = self.visual.importance_scorer
+        s = _CpuLisFunction.apply(h, sc.q_proj.weight, sc.q_proj.bias, sc.k_proj.weight, sc.k_proj.bias)
+        loss = (c * s).sum() + self.regularization_weight * (s ** 2).mean()
+        return types.SimpleNamespace(loss=loss)
+
+
+def _trainer_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from visionselector_amd.trainer import LisTrainer
+        res = {}
+        for mode in ("dense", "factors"):
+            torch.manual_seed(11 + rank)                   # different init per rank: the trainer broadcasts rank 0's scorer
+            model = _CpuLisModel()
+            with torch.no_grad():
+                for p in model.visual.importance_scorer.parameters():
+                    if p.dim() == 1:
+                        p.normal_(std=0.05)
+            tr = LisTrainer(model, max_steps=4, lr=1e-2, exchange=mode, log=lambda *_: None)
+            g = torch.Generator().manual_seed(900 + rank)  # each rank its own micro-batches
+            grads = []
+            for step in range(3):
+                batches = [dict(h=torch.randn(30 + 5 * mb, 48, generator=g), c=torch.randn(30 + 5 * mb, generator=g))
+                           for mb in range(2)]
+                tr.train_step(batches)
+                grads.append([p.grad.detach().clone().float() for p in tr.params])
+            res[mode] = {"grads": grads, "params": {n: p.detach().clone() for n, p in model.named_parameters() if "scorer" in n}}
+        torch.save(res, os.path.join(out_dir, f"t{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_lis_trainer_factor_exchange_matches_dense_gloo_world2(tmp_path):
+    """LisTrainer(exchange="factors") (57 KB payload rows, all-gather, local rebuild) takes the same optimizer steps as the
+    dense bucket all-reduce, to fp32 rounding, over three steps of two micro-batches on two ranks; ranks stay identical."""
+    world = 2
+    mp.spawn(_trainer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"t{i}.pt") for i in range(world)]
+    for mode in ("dense", "factors"):
+        for n in r[0][mode]["params"]:
+            assert torch.equal(r[0][mode]["params"][n], r[1][mode]["params"][n]), (mode, n)
+    for step in range(3):
+        for gd, gf in zip(r[0]["dense"]["grads"][step], r[0]["factors"]["grads"][step]):
+            assert torch.allclose(gd, gf, rtol=1e-4, atol=1e-6 * float(gd.abs().max()) + 1e-9)   # post-clip gradients
+    for n, pd in r[0]["dense"]["params"].items():
+        pf = r[0]["factors"]["params"][n]
+        assert torch.allclose(pd, pf, rtol=1e-4, atol=1e-5), n
+        assert not torch.equal(pd, torch.zeros_like(pd))
+
+
+def test_lis_factor_sync_buffer_growth_and_device_spelling():
+    """new_row: grows only when full ('cuda' vs 'cuda:0' used to double the buffer on every call)."""
+    from visionselector_amd.ddp import LisFactorSync
+    from visionselector_amd.selector import TransformerScorer
+    m = TransformerScorer(16, 8)
+    sync = LisFactorSync((m.q_proj.weight, m.q_proj.bias, m.k_proj.weight, m.k_proj.bias))
+    caps = []
+    for step in range(5):
+        for _ in range(3):
+            sync.new_row("cpu").zero_()
+            caps.append(sync._buf.shape[0])
+        sync.sync()
+        sync.zero_grads()
+    assert max(caps) == 4                                   # three rows per step never outgrow the initial four
+    rows = [sync.new_row(torch.device("cpu")) for _ in range(9)]
+    for i, r_ in enumerate(rows[:4]):
+        r_.fill_(float(i))
+    assert sync._buf.shape[0] == 16 and sync._n == 9
+    assert LisFactorSync._same_device(torch.device("cpu"), torch.device("cpu"))
+    assert not LisFactorSync._same_device(torch.device("cpu"), torch.device("cuda", 0))
+
+
+def _count_mismatch_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from visionselector_amd.ddp import LisFactorSync
+        from visionselector_amd.selector import TransformerScorer
+        m = TransformerScorer(16, 8)
+        sync = LisFactorSync((m.q_proj.weight, m.q_proj.bias, m.k_proj.weight, m.k_proj.bias))
+        for _ in range(2 + rank):                            # rank 1 adds one row more
+            sync.add(torch.zeros(sync.row))
+        try:
+            sync.sync()
+            msg = "no error"
+        except RuntimeError as e:
+            msg = str(e)
+        open(os.path.join(out_dir, f"c{rank}.txt"), "w").write(msg)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_lis_factor_sync_row_count_mismatch_raises(tmp_path):
+    mp.spawn(_count_mismatch_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r_ in range(2):
+        assert "different numbers of micro-batch rows: [2, 3]" in (tmp_path / f"c{r_}.txt").read_text()
+
+
 def test_eval_time_log_reader(tmp_path):
     """The EVAL_TIME lines our *_Selector.forward / timed_generate print are averaged like qwen-evaluation/extract_time.py."""
     from visionselector_amd.evaltime import parse_log, summarize_log
@@ -304,3 +446,22 @@ def test_bench_gpus_without_enough_devices_exits_loudly():
     r = subprocess.run([_sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 2 and "only" in r.stderr and "GPU" in r.stderr
+
+
+def test_bench_spawn_ranks_propagates_rank_exit_code(tmp_path, monkeypatch):
+    """spawn_ranks returns the launcher's exit code: a rank that dies makes `python bench.py --gpus N` exit non-zero."""
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys\nsys.exit(7 if os.environ.get('RANK') == '1' else 0)\n")
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 2)
+    real = bench.spawn_command
+
+    def fake(n, argv, port=None):
+        cmd = real(n, argv, port)
+        cmd[cmd.index(os.path.join(ROOT, "bench.py"))] = str(script)
+        return cmd
+
+    monkeypatch.setattr(bench, "spawn_command", fake)
+    assert bench.spawn_ranks(2, []) != 0
+    script.write_text("import sys\nsys.exit(0)\n")
+    assert bench.spawn_ranks(2, []) == 0

@@ -191,6 +191,57 @@ def test_torch_cpu_restatement(golden_dir, cases, name):
         assert torch.equal(h_new, t["h"][idx])
 
 
+# ---------------------------------------------------------------------------------------------------
+# the reference's own bf16 run (lisbf16_*.npz; make_golden.py --bf16-only): what a user of the released bf16
+# checkpoints sees.  SURVEY.md section 7 hard parts 1(iii) and 5: "fixtures should pin both".
+# ---------------------------------------------------------------------------------------------------
+def load_bf16(golden_dir, name):
+    return np.load(os.path.join(golden_dir, f"lisbf16_{name}.npz"))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_fp32_oracle_vs_reference_bf16_run(golden_dir, name):
+    """How far the reference's bf16 run sits from its own fp32 run (= from the oracle): scores within 1e-3, selected sets
+    differ only inside the tie class / rounding band at the k boundary, <= 1 % of k."""
+    import parity
+    g32, g16 = load(golden_dir, name), load_bf16(golden_dir, name)
+    idx = {t: g32[f"idx_{t}"] for t in ("0p1", "0p2", "0p5")}
+    m = parity.lis_bf16_metrics(g32["scores"], idx, g16)
+    assert m["max_abs_dscore"] <= parity.BF16_SCORE_TOL * max(1.0, m["max_abs_ref"])
+    for t in idx:
+        assert m[f"symdiff_{t}"] <= max(2 * m[f"ties_at_kth_{t}"], 2, int(parity.BF16_IDX_FRAC * m[f"k_{t}"]))
+        assert m[f"symdiff_max_dist_to_kth_{t}"] <= 2 * parity.BF16_SCORE_TOL
+    # bisection in bf16 stalls (SURVEY 7.5): sum(ps) != k, ts off by up to the bf16 spacing at |t| ~ 1.4
+    k = int(g16["topk_k"])
+    assert abs(float(g16["sum_ps_bf16"]) - k) <= 0.01 * k + 0.1
+    assert abs(float(g16["ts_bf16"]) - float(g32["topk_ts"])) <= 2.0 ** -7
+    assert np.abs(g16["ps_bf16"] - g32["topk_ps"]).max() <= parity.BF16_PS_TOL
+    ts, ps = lis.find_ts(g16["scores_bf16"][None], k)            # fp32 oracle on the reference's bf16 scores
+    assert np.abs(ps[0] - g16["ps_bf16"]).max() <= parity.BF16_PS_TOL
+    assert int((g16["train_y_bf16"] != g32["train_y"]).sum()) <= max(2, int(0.01 * k))
+
+
+@pytest.mark.parametrize("name", ["tiny", "qwen3b_256", "qwen7b_2304"])
+def test_torch_cpu_restatement_bf16(golden_dir, cases, name):
+    """oracle/lis_torch.py run in bfloat16 (bench.py's `bf16_reference_formulation` CPU leg) is the reference's bf16 run: same
+    ATen ops in the same order.  bf16 GEMM blocking may differ between hosts, hence one bf16 ulp instead of bit equality."""
+    import torch
+    from oracle import lis_torch
+    g = load_bf16(golden_dir, name)
+    c = cases(name)
+    t = {k: torch.from_numpy(v).bfloat16() for k, v in c.items()}
+    h_new, idx, scores = lis_torch.select_forward(t["h"], t["wq"], t["bq"], t["wk"], t["bk"], 0.2)
+    assert scores.dtype == torch.bfloat16
+    s = scores.float().numpy()
+    ref = g["scores_bf16"]
+    assert np.abs(s - ref).max() <= 2.0 ** -7 * np.abs(ref).max()
+    assert (s == ref).mean() >= 0.9
+    assert len(set(idx.tolist()) ^ set(g["idx_bf16_0p2"].tolist())) <= max(2, 2 * int(g["ties_at_kth_0p2"]))
+    ts, ps = lis_torch.find_ts(torch.from_numpy(ref).bfloat16()[None], int(g["topk_k"]))
+    assert ts.dtype == torch.bfloat16 and float(ts) == float(g["ts_bf16"])
+    assert np.array_equal(ps[0].float().numpy(), g["ps_bf16"])
+
+
 def _eager_attention_torch(q, k, v, cu, causal):
     """torch restatement of the eager formula (modeling_qwen2_5_vl.py:777-797) in fp64, differentiable."""
     import torch

@@ -130,6 +130,81 @@ def test_gelu_colsum_matches_torch(rows, cols, n_seg, dt):
     assert torch.equal(sums, sums2)
 
 
+@pytest.mark.parametrize("storage", ["bf16", "f32"])
+@pytest.mark.parametrize("name", ["qwen7b_2304", "ov8b_5832", "qwen3b_576"])
+def test_presummed_select_matches_reference_goldens(golden_dir, name, storage):
+    """vsel_lis_select_presummed (single sweep, column sums supplied by the producer) against the REFERENCE's goldens:
+    indices bit-exact for the three budgets, scores to the same bar as the two-sweep path, natural and window order."""
+    import os
+    from oracle import inputs as oin
+    from visionselector_amd import ops
+    g = np.load(os.path.join(golden_dir, f"lis_{name}.npz"))
+    _, d, hd, n, seed = {c[0]: c for c in oin.GOLDEN_CASES}[name]
+    c = oin.make_case(d, hd, n, seed)
+    dt = torch.bfloat16 if storage == "bf16" else torch.float32
+    h, wq, bq, wk, bk = (torch.from_numpy(c[x]).cuda().to(dt) for x in ("h", "wq", "bq", "wk", "bk"))
+    sums = torch.from_numpy(c["h"].astype(np.float64).sum(0).astype(np.float32)).cuda()    # independent of any kernel of ours
+    scale = max(1.0, float(np.abs(g["scores"]).max()))
+    perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed))
+    h_phys = torch.empty_like(h)
+    h_phys[perm] = h
+    p2l = torch.empty_like(perm)
+    p2l[perm] = torch.arange(n, device="cuda")
+    for r in oin.BUDGETS:
+        k = olis.budget_k_eval(n, r)
+        want = g["idx_" + str(r).replace(".", "p")]
+        out, idx, sc = ops.lis_select_presummed(h, sums, wq, bq, wk, bk, k)
+        assert np.abs(sc.cpu().numpy() - g["scores"]).max() <= 4e-6 * scale
+        assert np.array_equal(idx.cpu().numpy(), want) and torch.equal(out, h[idx])
+        out, idx, sc = ops.lis_select_presummed(h_phys, sums, wq, bq, wk, bk, k, logical_to_physical=perm, physical_to_logical=p2l)
+        assert np.abs(sc.cpu().numpy() - g["scores"]).max() <= 4e-6 * scale
+        assert np.array_equal(idx.cpu().numpy(), want) and torch.equal(out, h[idx])
+
+
+@pytest.mark.parametrize("n,seed", [(2304, 5), (576, 6)])
+def test_merger_colsum_path_matches_oracle(n, seed):
+    """The whole N2 chain -- vsel_gelu_colsum in the merger, sum_rows(H) by linearity of the merger's last Linear
+    (hf_generic.merger_col_sums), vsel_lis_select_presummed -- against the numpy ORACLE evaluated on the tokens the merger
+    actually emitted (reference: Qwen2_5_VLPatchMerger, EV/qwen25vl/modeling_qwen2_5_vl.py:148-161, then the LIS block
+    EV/token_compression/selector_model.py:182-189).  The linearity form sums H BEFORE its bf16 rounding, so the mean differs
+    from the mean of the stored tokens by the averaged rounding noise (~2^-9 |h| / sqrt(N)): scores within 3e-4 * scale (not 4e-6;
+    observed 1.5e-4 at N = 576, 0.7e-4 at N = 2304), indices equal
+    wherever the oracle's k boundary gap exceeds twice the observed score difference (asserted, so a silent mismatch cannot
+    pass)."""
+    from visionselector_amd import hf_generic, ops
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    din, d, hd = 5120, 3584, 1792
+    x = (1.5 * torch.randn(n, din, device="cuda", generator=g)).bfloat16()
+    last = torch.nn.Linear(din, d).cuda().bfloat16()
+    with torch.no_grad():
+        last.weight.copy_(0.02 * torch.randn(d, din, device="cuda", generator=g))
+        last.bias.copy_(0.1 * torch.randn(d, device="cuda", generator=g))
+    wq, wk = [(0.02 * torch.randn(hd, d, device="cuda", generator=g)).bfloat16() for _ in range(2)]
+    bq, bk = [(0.02 * torch.randn(hd, device="cuda", generator=g)).bfloat16() for _ in range(2)]
+    y, gsum = ops.gelu_colsum(x, 1)
+    assert torch.equal(y, torch.nn.functional.gelu(x))
+    with torch.no_grad():
+        h = last(y)                                           # the merged tokens the LIS block is handed (bf16)
+        col_sums = hf_generic.merger_col_sums(gsum, last, n)
+    f = lambda t: t.float().cpu().numpy()  # noqa: E731
+    ref = olis.scorer_collapsed(f(h)[None], f(wq), f(bq), f(wk), f(bk))[0]
+    scale = max(1.0, float(np.abs(ref).max()))
+    srt = np.sort(ref)[::-1]
+    for r in (0.1, 0.2, 0.5):
+        k = olis.budget_k_eval(n, r)
+        out, idx, sc = ops.lis_select_presummed(h, col_sums, wq, bq, wk, bk, k)
+        dsc = float(np.abs(sc.cpu().numpy() - ref).max())
+        assert dsc <= 3e-4 * scale, dsc
+        want = olis.hard_topk_indices(ref.astype(np.float32), k)
+        got = idx.cpu().numpy()
+        if srt[k - 1] - srt[k] > 2 * dsc:
+            assert np.array_equal(got, want)
+        else:                                                 # boundary closer than the rounding noise of the mean
+            sym = set(got.tolist()) ^ set(want.tolist())
+            assert len(sym) <= 2 and all(abs(ref[i] - srt[k - 1]) <= 2 * dsc for i in sym)
+        assert torch.equal(out, h[idx])
+
+
 def test_presummed_select_equals_two_sweep_select():
     """vsel_lis_select_presummed with the true column sums selects the same rows as the two-sweep path (scores agree to
     fp32 rounding of the mean), with and without the row permutation."""

@@ -108,10 +108,14 @@ class LisGradSync:
     @torch.no_grad()
     def broadcast_parameters(self, src: int = 0) -> None:
         """Make every rank start from rank `src`'s scorer (DDP's initial broadcast)."""
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
-            return
-        for p in self.params:
-            dist.broadcast(p.data, src=src, group=self.group)
+        _broadcast(self.params, self.group, src)
+
+
+def _broadcast(params, group, src: int = 0) -> None:
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for p in params:
+        dist.broadcast(p.data, src=src, group=group)
 
 
 class LisFactorSync:
@@ -126,8 +130,12 @@ class LisFactorSync:
     which is what LisGradSync.sync() leaves in p.grad (sum over a rank's micro-batches, mean over ranks), up to fp32 rounding.
     params = (q_proj.weight, q_proj.bias, k_proj.weight, k_proj.bias) in that order."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None,
+                 check_counts: bool = True):
+        """check_counts: exchange the per-rank row counts (one 8-byte-per-rank all-gather, a host sync) before the payload
+        gather and raise on a mismatch; switch off once the data pipeline guarantees equal micro-batch counts."""
         self.params: List[torch.nn.Parameter] = list(params)
+        self.check_counts = bool(check_counts)
         if len(self.params) != 4:
             raise ValueError("LisFactorSync takes (q_proj.weight, q_proj.bias, k_proj.weight, k_proj.bias)")
         wq, bq, wk, bk = self.params
@@ -141,16 +149,36 @@ class LisFactorSync:
         self._gathered: Optional[torch.Tensor] = None
         self._grads: Optional[List[torch.Tensor]] = None
 
+    @staticmethod
+    def _same_device(a: torch.device, b: torch.device) -> bool:
+        """'cuda' and 'cuda:<current>' are the same device (torch.device('cuda') != torch.device('cuda:0') as objects)."""
+        if a.type != b.type:
+            return False
+        if a.type != "cuda":
+            return True
+        cur = torch.cuda.current_device()
+        return (cur if a.index is None else a.index) == (cur if b.index is None else b.index)
+
     def new_row(self, device) -> torch.Tensor:
-        """A payload row for the next micro-batch (pass it as ops.lis_train_bwd_factors(out=...))."""
-        if self._buf is None or self._buf.device != torch.device(device) or self._n == self._buf.shape[0]:
-            cap = 4 if self._buf is None else 2 * self._buf.shape[0]
-            buf = torch.empty(cap, self.row, dtype=torch.float32, device=device)
-            if self._buf is not None and self._n:
-                buf[:self._n].copy_(self._buf[:self._n])
+        """A payload row for the next micro-batch (pass it as ops.lis_train_bwd_factors(out=...)).  The buffer grows (x2)
+        only when it is full; rows already handed out this step are kept."""
+        device = torch.device(device)
+        if self._buf is not None and not self._same_device(self._buf.device, device):
+            if self._n:
+                raise RuntimeError(f"LisFactorSync: payload rows of one step on two devices ({self._buf.device}, {device})")
+            self._buf = None
+        if self._buf is None:
+            self._buf = torch.empty(4, self.row, dtype=torch.float32, device=device)
+        elif self._n == self._buf.shape[0]:
+            buf = torch.empty(2 * self._buf.shape[0], self.row, dtype=torch.float32, device=self._buf.device)
+            buf[:self._n].copy_(self._buf[:self._n])
             self._buf = buf
         self._n += 1
         return self._buf[self._n - 1]
+
+    @torch.no_grad()
+    def broadcast_parameters(self, src: int = 0) -> None:
+        _broadcast(self.params, self.group, src)
 
     def add(self, payload: torch.Tensor) -> None:
         if payload.numel() != self.row or payload.dtype != torch.float32:
@@ -170,6 +198,14 @@ class LisFactorSync:
         local = self._buf[:self._n]                                      # [M, row], contiguous
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world > 1:
+            if self.check_counts:
+                # all_gather_into_tensor needs the same row count everywhere: a mismatch would hang or corrupt the gather
+                counts = torch.full((world,), -1, dtype=torch.int64, device=local.device)
+                dist.all_gather_into_tensor(counts, torch.tensor([self._n], dtype=torch.int64, device=local.device),
+                                            group=self.group)
+                counts = counts.tolist()
+                if any(c != self._n for c in counts):
+                    raise RuntimeError(f"LisFactorSync.sync(): ranks added different numbers of micro-batch rows: {counts}")
             if self._gathered is None or self._gathered.shape[0] != world * self._n or self._gathered.device != local.device:
                 self._gathered = torch.empty(world * self._n, self.row, dtype=torch.float32, device=local.device)
             dist.all_gather_into_tensor(self._gathered, local, group=self.group)

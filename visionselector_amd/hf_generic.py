@@ -70,6 +70,13 @@ def _merger_gelu_slot(merger):
     return None
 
 
+def merger_col_sums(gelu_col_sums: torch.Tensor, last: torch.nn.Linear, n_rows: int) -> torch.Tensor:
+    """sum_rows(H) = sum_rows(G) W2^T + N b2 for H = Linear(G) (the merger's last Linear, EV/qwen25vl/modeling_qwen2_5_vl.py:
+    148-161): fp32 [n_seg, D_out] from the fp32 column sums of the GELU output."""
+    bias = last.bias.float() * n_rows if last.bias is not None else torch.zeros(last.out_features, device=gelu_col_sums.device)
+    return torch.addmm(bias, gelu_col_sums, last.weight.float().t()).contiguous()
+
+
 def _merged_tokens(out) -> torch.Tensor:
     """Accept either a plain tensor (transformers 4.5x towers) or a ModelOutput with pooler_output (5.x)."""
     if isinstance(out, torch.Tensor):
@@ -123,10 +130,7 @@ def make_vision_tower_forward_selector(base_forward: Callable, mode: str):
         col_sums = None
         if fused_gelu is not None and fused_gelu.col_sums is not None and perm is not None:
             # sum_rows(H) = sum_rows(G) W2^T + N b2 (one skinny fp32 GEMM; the merger's last Linear is linear)
-            last = slot[0][2]
-            col_sums = torch.addmm(last.bias.float() * merged.shape[0] if last.bias is not None
-                                   else torch.zeros(last.out_features, device=merged.device),
-                                   fused_gelu.col_sums, last.weight.float().t()).contiguous()
+            col_sums = merger_col_sums(fused_gelu.col_sums, slot[0][2], merged.shape[0])
         if perm is not None:
             out, idx, total, combined = _select_block_permuted(merged, perm, self.importance_scorer, self.budgets, col_sums)
         else:

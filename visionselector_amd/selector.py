@@ -124,6 +124,33 @@ class TransformerScorer(nn.Module):
 # --------------------------------------------------------------------------------------------------
 # training LIS block
 # --------------------------------------------------------------------------------------------------
+_FACTOR_SINK = None       # a ddp.LisFactorSync while LisTrainer(exchange="factors") runs a backward (one process per GPU,
+                          # no intra-process threading: SURVEY.md section 8b)
+
+
+class factor_sink:
+    """with factor_sink(sync): ...backward...  -- the LIS block's backward leaves its weight gradients as ONE rank-1-factor
+    payload row in `sync` (ddp.LisFactorSync.new_row) instead of two dense [Hd, D] tensors; autograd gets no .grad for the
+    scorer parameters.  Both are the closed form of SURVEY.md section 7 hard part 4."""
+
+    def __init__(self, sync):
+        self.sync = sync
+
+    def __enter__(self):
+        global _FACTOR_SINK
+        self._prev, _FACTOR_SINK = _FACTOR_SINK, self.sync
+        return self.sync
+
+    def __exit__(self, *exc):
+        global _FACTOR_SINK
+        _FACTOR_SINK = self._prev
+        return False
+
+
+def active_factor_sink():
+    return _FACTOR_SINK
+
+
 class _LisTrainFunction(Function):
     """(h_new, img_mask) = f(h, scorer params); constraint mask returned non-differentiable.
     FT/compression_method/selector_model.py:158-173."""
@@ -142,6 +169,10 @@ class _LisTrainFunction(Function):
     def backward(ctx, d_hnew, d_ps, _dy, _dscores):
         hc, wq, bq, wk, bk, ps, y, scores, ts = ctx.saved_tensors
         d_ps = None if d_ps is None else d_ps.float().contiguous()
+        if _FACTOR_SINK is not None:
+            _, dh = ops.lis_train_bwd_factors(d_hnew.contiguous(), hc, wq, bq, wk, bk, ps, y, scores, ts, d_ps_ext=d_ps,
+                                              dl_dbce=0.0, need_dh=ctx.need_dh, out=_FACTOR_SINK.new_row(hc.device))
+            return dh, None, None, None, None, None
         dwq, dbq, dwk, dbk, dh = ops.lis_train_bwd(d_hnew.contiguous(), hc, wq, bq, wk, bk, ps, y, scores, ts,
                                                    d_ps_ext=d_ps, dl_dbce=0.0, need_dh=ctx.need_dh)
         return dh, dwq.to(wq.dtype), dbq.to(bq.dtype), dwk.to(wk.dtype), dbk.to(bk.dtype), None

@@ -19,8 +19,8 @@ from typing import Callable, Dict, Iterable, Optional
 import torch
 import torch.distributed as dist
 
-from .ddp import LisGradSync
-from .selector import curriculum_weight
+from .ddp import LisFactorSync, LisGradSync
+from .selector import curriculum_weight, factor_sink
 
 SCORER_KEY = "importance_scorer"
 
@@ -63,13 +63,35 @@ def load_scorer_state_dict(model: torch.nn.Module, sd: Dict[str, torch.Tensor]) 
     model.load_state_dict(mapped, strict=False)
 
 
+def _scorer_params_in_payload_order(model: torch.nn.Module) -> list:
+    """(q_proj.weight, q_proj.bias, k_proj.weight, k_proj.bias) of the model's single importance_scorer."""
+    found = {}
+    for n, p in model.named_parameters():
+        if SCORER_KEY in n:
+            tail = n[n.index(SCORER_KEY) + len(SCORER_KEY) + 1:]
+            if tail in found:
+                raise ValueError(f"more than one importance_scorer in the model ({n})")
+            found[tail] = p
+    try:
+        return [found["q_proj.weight"], found["q_proj.bias"], found["k_proj.weight"], found["k_proj.bias"]]
+    except KeyError as e:
+        raise ValueError(f"importance_scorer lacks {e}") from None
+
+
 class LisTrainer:
     """Minimal trainer for the scorer: curriculum-annealed constraint weight, AdamW + cosine, clip, DP gradient mean."""
 
     def __init__(self, model: torch.nn.Module, max_steps: int, lr: float = 5e-5, weight_decay: float = 0.0,
                  reg_weight_start: float = 0.1, reg_weight_end: float = 2.0, max_grad_norm: float = 1.0,
                  warmup_ratio: float = 0.03, group: Optional[dist.ProcessGroup] = None, log: Callable[[str], None] = print,
-                 logging_steps: int = 1):
+                 logging_steps: int = 1, exchange: str = "dense"):
+        """exchange="dense": the scorer's fp32 gradients live in one flat bucket, ONE all-reduce per optimizer step
+        (51.4 MB at 7B).  exchange="factors": every micro-batch's LIS backward leaves a 57 KB rank-1-factor payload row
+        (selector.factor_sink), the step all-gathers the rows and every rank rebuilds the mean gradient itself
+        (ddp.LisFactorSync); same gradients to fp32 rounding, and no dense [Hd, D] write per micro-batch."""
+        if exchange not in ("dense", "factors"):
+            raise ValueError("exchange must be 'dense' or 'factors'")
+        self.exchange = exchange
         self.model = model
         self.params = freeze_all_but_scorer(model)
         self.max_steps = max_steps
@@ -89,7 +111,10 @@ class LisTrainer:
 
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lr_lambda)
         # fp32 scorer: gradients live in ONE flat bucket (views), so the data-parallel mean is a single all-reduce, no copies
-        self.sync = LisGradSync(self.params, group, bucket_view=all(p.dtype == torch.float32 for p in self.params))
+        if exchange == "factors":
+            self.sync = LisFactorSync(_scorer_params_in_payload_order(model), group)
+        else:
+            self.sync = LisGradSync(self.params, group, bucket_view=all(p.dtype == torch.float32 for p in self.params))
         self.sync.broadcast_parameters(0)
         self.global_step = 0
         self.log = log
@@ -104,10 +129,20 @@ class LisTrainer:
         self.sync.zero_grads()
         batches = list(batches)
         total = 0.0
-        for b in batches:
-            out = self.model(**b)
-            (out.loss / len(batches)).backward()
-            total += float(out.loss.detach())
+        if self.exchange == "factors":
+            with factor_sink(self.sync):
+                for b in batches:
+                    out = self.model(**b)
+                    (out.loss / len(batches)).backward()
+                    total += float(out.loss.detach())
+            if any(p.grad is not None for p in self.params):
+                raise RuntimeError("exchange='factors': a dense gradient reached the scorer outside the LIS training block "
+                                   "(only lis_train_block's backward produces factor payloads); use exchange='dense'")
+        else:
+            for b in batches:
+                out = self.model(**b)
+                (out.loss / len(batches)).backward()
+                total += float(out.loss.detach())
         self.sync.sync()                                                        # mean over the data-parallel ranks
         torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
         self.opt.step()

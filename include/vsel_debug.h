@@ -1,0 +1,58 @@
+/* vsel_debug.h -- diagnostic knobs of libvsel.so (NOT part of the drop-in boundary; include/vsel.h is).
+ *
+ * The library picks its kernel forms (small-batch LIS path, fused select, two-stream pipeline, attention workgroup shapes,
+ * backward split) from the problem size.  The -m gpu tests and the tools/ benchmarks need to FORCE a form to prove that the
+ * forms agree bit for bit and to measure them against each other; these knobs are how.  They replace nothing in the reference.
+ *
+ * Contract
+ *   - one table of process-global ints, read with relaxed atomics at launch time: setting a knob is thread-safe, but a call
+ *     running concurrently on another thread may see either value (one process per GPU, no intra-process threading is the
+ *     supported model);
+ *   - vsel_debug_set returns the PREVIOUS value through *previous so that a caller can restore it (the Python side wraps this
+ *     in a context manager: visionselector_amd._native.debug_knob); vsel_debug_reset puts every knob back to its default
+ *     (the default honours the environment variable named below, read once);
+ *   - results never depend on a knob beyond what the knob's line says (every form is parity-tested against the same oracle).
+ */
+#ifndef VSEL_DEBUG_H_
+#define VSEL_DEBUG_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vsel_debug_knob {
+  VSEL_KNOB_LIS_PIPELINE = 0,     /* 0 / 1: two-half aux-stream pipeline for >= 32 segments (env VSEL_PIPELINE, default 0); bit-identical */
+  VSEL_KNOB_LIS_SMALL_PATH = 1,   /* small-batch LIS form up to this many segments (env VSEL_SMALL_PATH, default 4, 0 = never); bit-identical */
+  VSEL_KNOB_LIS_FUSED_SELECT = 2, /* radix select fused into the gather up to this many segments (env VSEL_FUSED_SELECT, default 32); bit-identical */
+  VSEL_KNOB_ATTN_USE_TR = 3,      /* 0 / 1: V fragments by ds_read_b64_tr_b16 (default 1) or by plain LDS reads; bit-identical */
+  VSEL_KNOB_ATTN_WAVES = 4,       /* 0 = by grid size (default), 4 / 8 = force the forward workgroup size; bit-identical */
+  VSEL_KNOB_ATTN_PACK = 5,        /* GQA-packed decode form: 0 never, 1 whenever it applies, 2 (default) by grid size; bit-identical */
+  VSEL_KNOB_ATTN_SPLIT = 6,       /* two-KV-stream form for one short sequence: 0 never, 1 whenever <= 256 items, 2 (default) ... and
+                                     the sequences are not tiny; inference only, sums in a different order (bf16-rounding agreement) */
+  VSEL_KNOB_ATTN_SPLIT_Q64 = 7,   /* 0 / 1: 64-query workgroups in the two-stream form when they fit one per CU (default 1) */
+  VSEL_KNOB_ATTN_BWD_SPLIT = 8,   /* dK/dV per-q-head split: -1 by item count (default), 0 / 1 force; deterministic either way */
+  VSEL_KNOB_LIS_SPLICE_FUSED = 9, /* 0 / 1: vsel_lis_select_splice writes kept rows straight into inputs_embeds' (default 1) or runs
+                                     select then splice as two steps; bit-identical */
+  VSEL_KNOB_COUNT = 10
+} vsel_debug_knob;
+
+/* Set knob to value (clamped to the knob's range).  *previous (may be NULL) receives the value it had.
+ * Returns 0, or 1 (VSEL_ERR_INVALID) for an unknown knob. */
+int vsel_debug_set(int knob, int value, int* previous);
+/* Current value of knob through *value.  Returns 0 or 1 as above. */
+int vsel_debug_get(int knob, int* value);
+/* Every knob back to its default. */
+void vsel_debug_reset(void);
+
+#ifdef VSEL_TRACE
+/* Only in libraries built with -DVSEL_TRACE (tools/trace_small.py, tools/trace_attn.py; never the shipped one): copy the
+ * s_memrealtime stamps of the last small-batch LIS call / attention forward launch,
+ * out[kTraceKernels = 8][kTraceBlocks = 1024][kTraceSlots = 8] uint64; clear != 0 zeroes the device table afterwards. */
+int vsel_debug_read_trace(unsigned long long* out, int clear);
+int vsel_debug_read_attn_trace(unsigned long long* out, int clear);
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSEL_DEBUG_H_ */

@@ -129,18 +129,11 @@ def test_backward_linearity_and_full_size(ops):
 def test_split_and_grouped_dkdv_agree(ops):
     """The per-q-head split (fp32 partials + ordered group sum) and the in-kernel group loop compute the same sums in the
     same order per head; they may differ only by the fp32 association across heads -> compare within 1 bf16 ulp."""
-    import ctypes
-    from visionselector_amd import _native as N
-    lib = N.lib()
-    lib.vsel_debug_attn_bwd_split.argtypes = [ctypes.c_int]
-    lib.vsel_debug_attn_bwd_split.restype = None
-    try:
-        lib.vsel_debug_attn_bwd_split(0)
+    from visionselector_amd._native import debug_knob
+    with debug_knob("attn_bwd_split", 0):
         _, _, _, g0 = _run(ops, [300, 77, 513], 14, 2, True, seed=8)
-        lib.vsel_debug_attn_bwd_split(1)
+    with debug_knob("attn_bwd_split", 1):
         _, _, _, g1 = _run(ops, [300, 77, 513], 14, 2, True, seed=8)
-    finally:
-        lib.vsel_debug_attn_bwd_split(-1)
     assert torch.equal(g0[0], g1[0])                                   # dQ does not depend on the mode
     for a, b in zip(g0[1:], g1[1:]):
         assert float((a.float() - b.float()).abs().max()) <= 2 ** -7 * float(a.float().abs().max())

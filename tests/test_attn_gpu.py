@@ -1,6 +1,5 @@
 """GPU parity tests of the var-len causal GQA attention kernel against the eager-formula oracle (oracle/attention.py,
 fp64).  Parity is UNPINNED against flash_attn itself (third party, not in the reference tree) -- see the oracle header."""
-import ctypes
 
 import numpy as np
 import pytest
@@ -69,18 +68,13 @@ def test_attention_rescale_path(ops):
 
 def test_attention_transpose_read_equals_plain_reads(ops):
     """The ds_read_b64_tr_b16 V^T fragments and plain 16-bit column reads give bit-identical outputs."""
-    from visionselector_amd import _native
-    lib = _native.lib()
+    from visionselector_amd._native import debug_knob
     q, k, v = make_qkv(600, 8, 2, 11)
     cu = torch.tensor([0, 250, 600], dtype=torch.int32).cuda()
-    _set_split(0)                      # same single-stream schedule on both sides
-    try:
+    with debug_knob("attn_split", 0):                      # same single-stream schedule on both sides
         a = ops.varlen_attn(q.cuda(), k.cuda(), v.cuda(), cu, 350)
-        lib.vsel_debug_attn_use_tr(ctypes.c_int(0))
-        b = ops.varlen_attn(q.cuda(), k.cuda(), v.cuda(), cu, 350)
-    finally:
-        lib.vsel_debug_attn_use_tr(ctypes.c_int(1))
-        _set_split(2)
+        with debug_knob("attn_use_tr", 0):
+            b = ops.varlen_attn(q.cuda(), k.cuda(), v.cuda(), cu, 350)
     assert torch.equal(a, b)
 
 
@@ -104,11 +98,8 @@ def test_attention_full_size_properties(ops):
     # rounding; with the same schedule (split off) a sequence's output does not depend on what it is packed with, bit for bit
     o2 = ops.varlen_attn(*tail, cu1, lens[1])
     assert float((out[lens[0]:].float() - o2.float()).abs().max()) <= 2 ** -6 * float(o2.float().abs().max())
-    _set_split(0)
-    try:
+    with _split(0):
         assert torch.equal(out[lens[0]:], ops.varlen_attn(*tail, cu1, lens[1]))
-    finally:
-        _set_split(2)
     # spot-check a slice against the oracle (one kv group, last 64 queries of the long sequence)
     sl = slice(lens[0] - 64, lens[0])
     ref = oattn.varlen_attention(q[:lens[0], :7].float().numpy(), k[:lens[0], :1].float().numpy(),
@@ -166,19 +157,14 @@ def test_paged_equals_contiguous_when_pages_are_in_order(ops):
 
 def test_workgroup_shapes_agree(ops):
     """4-wave (128-query) and 8-wave (256-query) workgroups produce bit-identical outputs on a ragged batch."""
-    import ctypes
-    from visionselector_amd import _native
-    lib = _native.lib()
+    from visionselector_amd._native import debug_knob
     lens = [700, 33, 256, 257, 1500]
     q, k, v = make_qkv(sum(lens), 8, 2, 41)
     cu = torch.tensor(np.concatenate(([0], np.cumsum(lens))), dtype=torch.int32).cuda()
     outs = []
     for nw in (4, 8):
-        lib.vsel_debug_attn_waves(ctypes.c_int(nw))
-        try:
+        with debug_knob("attn_waves", nw):
             outs.append(ops.varlen_attn(q.cuda(), k.cuda(), v.cuda(), cu, max(lens)))
-        finally:
-            lib.vsel_debug_attn_waves(ctypes.c_int(0))
     assert torch.equal(outs[0], outs[1])
     ref = oattn.varlen_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu.cpu().numpy())
     check(outs[1].float().cpu().numpy(), ref)
@@ -206,7 +192,6 @@ def test_attention_rejects_unsupported_head_dim(ops):
 def test_gqa_packed_decode_matches_oracle_and_unpacked_kernel(ops, hq, hkv, qlens, klens, causal):
     """Decode / short chunks against a paged cache: one wave serves the whole GQA group (lane = (query, head) pair), K/V
     streamed once per kv head.  Against the oracle, and against the per-head kernel (pack mode 0)."""
-    lib = N_lib()
     page_size = 64
     rng = np.random.default_rng(hq + len(qlens))
     pages_per = [-(-kk // page_size) for kk in klens]
@@ -225,17 +210,12 @@ def test_gqa_packed_decode_matches_oracle_and_unpacked_kernel(ops, hq, hkv, qlen
             torch.from_numpy(bt).cuda(), max(qlens))
     from visionselector_amd import _native as N
     outs = {}
-    _set_split(0)                      # compare the packed form with the plain per-head form (not the two-stream one)
-    try:
-        for mode in (0, 1):
-            lib.vsel_debug_attn_pack(mode)
+    for mode in (0, 1):                # compare the packed form with the plain per-head form (not the two-stream one)
+        with N.debug_knob(attn_split=0, attn_pack=mode):
             N.profile_start()
             outs[mode] = ops.paged_attn(*args, causal=causal)
             prof = N.profile_stop()
             assert prof["varlen_attn_fwd_kernel"][1] == 1
-    finally:
-        lib.vsel_debug_attn_pack(2)
-        _set_split(2)
     ref = oattn.paged_attention(q.float().numpy(), kc.float().numpy(), vc.float().numpy(), cu_q, np.array(klens), bt, causal=causal)
     for mode in (0, 1):
         check(outs[mode].float().cpu().numpy().astype(np.float64), ref)
@@ -243,20 +223,10 @@ def test_gqa_packed_decode_matches_oracle_and_unpacked_kernel(ops, hq, hkv, qlen
     assert torch.equal(outs[0], outs[1])
 
 
-def N_lib():
-    from visionselector_amd import _native as N
-    lib = N.lib()
-    lib.vsel_debug_attn_pack.argtypes = [ctypes.c_int]
-    lib.vsel_debug_attn_pack.restype = None
-    return lib
-
-
-def _set_split(mode):
-    from visionselector_amd import _native as N
-    lib = N.lib()
-    lib.vsel_debug_attn_split.argtypes = [ctypes.c_int]
-    lib.vsel_debug_attn_split.restype = None
-    lib.vsel_debug_attn_split(mode)
+def _split(mode):
+    """with _split(0): ...  -- force / forbid the two-KV-stream form for the block (restored on exit)."""
+    from visionselector_amd._native import debug_knob
+    return debug_knob("attn_split", mode)
 
 
 @pytest.mark.parametrize("lens,hq,hkv", [([524], 28, 4), ([65], 4, 2), ([1], 2, 1), ([300, 129, 64], 4, 2), ([2368], 4, 4)])
@@ -267,12 +237,9 @@ def test_two_kv_stream_workgroups_match_oracle_and_single_stream(ops, lens, hq, 
     q, k, v = make_qkv(sum(lens), hq, hkv, seed=len(lens) + hq)
     cu = torch.from_numpy(np.concatenate(([0], np.cumsum(lens))).astype(np.int32)).cuda()
     outs = {}
-    try:
-        for mode in (0, 1):
-            _set_split(mode)
+    for mode in (0, 1):
+        with _split(mode):
             outs[mode] = ops.varlen_attn_fwd_lse(q.cuda(), k.cuda(), v.cuda(), cu, max(lens), causal=causal)
-    finally:
-        _set_split(2)
     ref = oattn.varlen_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu.cpu().numpy(), causal=causal)
     for mode in (0, 1):
         check(outs[mode][0].float().cpu().numpy().astype(np.float64), ref)

@@ -265,33 +265,29 @@ def test_full_size_properties(ops, budget):
 
 
 def test_two_half_pipeline_equals_single_stream(ops):
-    """The opt-in aux-stream software pipeline (>= 32 segments, vsel_debug_set_pipeline(1)) must give bit-identical results to
-    the single-stream, single-piece order."""
-    import ctypes
-    from visionselector_amd import _native
-    lib = _native.lib()
+    """The opt-in aux-stream software pipeline (>= 32 segments, knob lis_pipeline / VSEL_PIPELINE=1) must give bit-identical
+    results to the single-stream, single-piece order."""
+    from visionselector_amd._native import debug_get, debug_knob
     c = oin.make_case(2048, 1024, 300, 5, batch=35)
     h, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
-    lib.vsel_debug_set_pipeline(ctypes.c_int(1))
-    a = ops.lis_select(h, wq, bq, wk, bk, 77)
     lens = [300, 17, 1000, 64, 5, 700, 33, 900, 12] * 4
     ks = [max(1, n // 5) for n in lens]
     c2 = oin.make_case(2048, 1024, sum(lens), 6)
     h2 = dev(c2["h"], torch.bfloat16)
-    a2 = ops.lis_select_varlen(h2, lens, ks, wq, bq, wk, bk)
-    lib.vsel_debug_set_pipeline(ctypes.c_int(0))
-    try:
-        b = ops.lis_select(h, wq, bq, wk, bk, 77)
-        b2 = ops.lis_select_varlen(h2, lens, ks, wq, bq, wk, bk)
-    finally:
-        lib.vsel_debug_set_pipeline(ctypes.c_int(1))
-    torch.cuda.synchronize()
-    for x, y in zip(a + a2, b + b2):
-        assert torch.equal(x, y)
-    # back-to-back calls on the same stream reuse the aux stream / events correctly
-    outs = [ops.lis_select(h, wq, bq, wk, bk, 77) for _ in range(20)]
-    torch.cuda.synchronize()
-    lib.vsel_debug_set_pipeline(ctypes.c_int(0))
+    before = debug_get("lis_pipeline")
+    with debug_knob("lis_pipeline", 1):
+        a = ops.lis_select(h, wq, bq, wk, bk, 77)
+        a2 = ops.lis_select_varlen(h2, lens, ks, wq, bq, wk, bk)
+        with debug_knob("lis_pipeline", 0):
+            b = ops.lis_select(h, wq, bq, wk, bk, 77)
+            b2 = ops.lis_select_varlen(h2, lens, ks, wq, bq, wk, bk)
+        torch.cuda.synchronize()
+        for x, y in zip(a + a2, b + b2):
+            assert torch.equal(x, y)
+        # back-to-back calls on the same stream reuse the aux stream / events correctly
+        outs = [ops.lis_select(h, wq, bq, wk, bk, 77) for _ in range(20)]
+        torch.cuda.synchronize()
+    assert debug_get("lis_pipeline") == before             # restored whatever happened inside
     for o in outs:
         for x, y in zip(o, a):
             assert torch.equal(x, y)
@@ -337,10 +333,10 @@ def test_permuted_select_equals_unreorder_then_select(ops):
     assert float((got[2] - ref[2]).abs().max()) <= 4e-6 * max(1.0, float(ref[2].abs().max()))
 
 
-def _small_path(lib, on, default=4):
-    """on: the small-batch form for up to 8 segments (the library default is 4); off: never; restore with on=None."""
-    import ctypes
-    lib.vsel_debug_set_small_path(ctypes.c_int(default if on is None else (8 if on else 0)))
+def _small_path(on):
+    """with _small_path(True): the small-batch form for up to 8 segments (the library default is 4); False: never."""
+    from visionselector_amd._native import debug_knob
+    return debug_knob("lis_small_path", 8 if on else 0)
 
 
 @pytest.mark.parametrize("d,hd,n,k,batches", [(3584, 1792, 2304, 460, (1, 2, 4, 8)),      # Qwen2.5-VL-7B, the reference's eval call
@@ -352,23 +348,19 @@ def test_small_batch_path_is_bit_identical(ops, d, hd, n, k, batches, storage):
     """The five-launch small-batch form (csrc/lis_small.h, <= 8 segments) against the batched nine-launch form on the same
     inputs: scores, indices and kept rows bit for bit; also the scores-only entry."""
     from visionselector_amd import _native
-    lib = _native.lib()
     dt = torch.bfloat16 if storage == "bf16" else torch.float32
     for b in batches:
         c = oin.make_case(d, hd, n, 100 + b, batch=b)
         h = dev(c["h"], dt)
         wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("wq", "bq", "wk", "bk"))
-        try:
-            _small_path(lib, False)
+        with _small_path(False):
             ref = ops.lis_select(h, wq, bq, wk, bk, k)
             ref_s = ops.lis_scores(h, wq, bq, wk, bk)
-            _small_path(lib, True)
+        with _small_path(True):
             _native.profile_start()
             got = ops.lis_select(h, wq, bq, wk, bk, k)
             prof = _native.profile_stop()
             got_s = ops.lis_scores(h, wq, bq, wk, bk)
-        finally:
-            _small_path(lib, None)
         assert "proj_nt_small_kernel" in prof and "gemm_nt_bf16x3_kernel" not in prof, prof       # the small form really ran
         assert sum(c_ for _, c_ in prof.values()) == (5 if n <= 8192 else 6), prof
         for x, y in zip(got, ref):
@@ -378,8 +370,6 @@ def test_small_batch_path_is_bit_identical(ops, d, hd, n, k, batches, storage):
 
 def test_small_batch_path_ragged_permuted_presummed(ops):
     """Ragged segments, the un-reorder-fused form and the producer-supplied column sums through the small-batch kernels."""
-    from visionselector_amd import _native
-    lib = _native.lib()
     d, hd = 2048, 1024
     lens = [300, 17, 1000, 64, 5]
     ks = [max(1, n // 5) for n in lens]
@@ -394,13 +384,10 @@ def test_small_batch_path_ragged_permuted_presummed(ops):
     p2l[l2p] = torch.arange(n, device="cuda")
     sums = h2.float().sum(0, keepdim=True).contiguous()
     outs = {}
-    try:
-        for on in (False, True):
-            _small_path(lib, on)
+    for on in (False, True):
+        with _small_path(on):
             outs[on] = (ops.lis_select_varlen(h, lens, ks, wq, bq, wk, bk) + ops.lis_select_permuted(h2, l2p, p2l, wq, bq, wk, bk, 128)
                         + ops.lis_select_presummed(h2, sums, wq, bq, wk, bk, 128, logical_to_physical=l2p, physical_to_logical=p2l))
-    finally:
-        _small_path(lib, None)
     for x, y in zip(outs[True], outs[False]):
         assert torch.equal(x, y)
     # and the permuted form equals "un-reorder, then select" (kept rows / indices exact)
@@ -412,9 +399,7 @@ def test_small_batch_path_ragged_permuted_presummed(ops):
 def test_fused_select_gather_is_bit_identical(ops):
     """Mid-size batches run the radix select inside the gather workgroups (one launch less): same indices / rows / scores as the
     two-launch form, uniform and ragged."""
-    import ctypes
     from visionselector_amd import _native
-    lib = _native.lib()
     d, hd, n, k, b = 2048, 1024, 1100, 220, 9
     c = oin.make_case(d, hd, n, 31, batch=b)
     h, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
@@ -423,15 +408,12 @@ def test_fused_select_gather_is_bit_identical(ops):
     c2 = oin.make_case(d, hd, sum(lens), 32)
     h2 = dev(c2["h"], torch.bfloat16)
     outs = {}
-    try:
-        for limit in (0, 64):
-            lib.vsel_debug_set_fused_select(ctypes.c_int(limit))
+    for limit in (0, 64):
+        with _native.debug_knob("lis_fused_select", limit):
             _native.profile_start()
             a = ops.lis_select(h, wq, bq, wk, bk, k)
             prof = _native.profile_stop()
             assert ("select_gather_small_kernel" in prof) == (limit > 0), prof
             outs[limit] = a + ops.lis_select_varlen(h2, lens, ks, wq, bq, wk, bk)
-    finally:
-        lib.vsel_debug_set_fused_select(ctypes.c_int(32))
     for x, y in zip(outs[0], outs[64]):
         assert torch.equal(x, y)

@@ -220,18 +220,12 @@ def test_config5_real_geometry_select_splice_attend(ops):
     kk = torch.randn(t, hkv, 128, device="cuda", generator=g).bfloat16()
     vv = torch.randn(t, hkv, 128, device="cuda", generator=g).bfloat16()
     o = ops.varlen_attn(q, kk, vv, cu_c, max(seq_c))
-    _set = __import__("ctypes").c_int
-    from visionselector_amd import _native
-    lib = _native.lib()
-    lib.vsel_debug_attn_split.restype = None
-    lib.vsel_debug_attn_split(0)             # single-stream schedule on both sides: packing invariance is bit-exact
-    try:
+    from visionselector_amd._native import debug_knob
+    with debug_knob("attn_split", 0):        # single-stream schedule on both sides: packing invariance is bit-exact
         o_same = ops.varlen_attn(q, kk, vv, cu_c, max(seq_c))
         a = int(cu_c[3]); b = int(cu_c[4])
         alone = ops.varlen_attn(q[a:b].contiguous(), kk[a:b].contiguous(), vv[a:b].contiguous(),
                                 torch.tensor([0, b - a], dtype=torch.int32, device="cuda"), b - a)
-    finally:
-        lib.vsel_debug_attn_split(2)
     assert torch.equal(o_same[a:b], alone)
     ref = oattn.varlen_attention(q[a:b, :7].float().cpu().numpy(), kk[a:b, :1].float().cpu().numpy(), vv[a:b, :1].float().cpu().numpy(),
                                  np.array([0, b - a]))

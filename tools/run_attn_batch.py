@@ -1,14 +1,11 @@
-"""python tools/run_attn_batch.py N_SEQ L [pingpong 0/1] [iters]: the attention forward on a packed batch (profilers)."""
-import ctypes, os, sys, time
+"""python tools/run_attn_batch.py N_SEQ L [unused] [iters]: the attention forward on a packed batch (profilers)."""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from visionselector_amd import ops, _native
 nseq, L = int(sys.argv[1]), int(sys.argv[2])
 pp = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
-lib = _native.lib()
-if hasattr(lib, "vsel_debug_attn_pingpong"):
-    lib.vsel_debug_attn_pingpong(ctypes.c_int(pp))
 g = torch.Generator(device="cuda").manual_seed(7)
 T = nseq * L
 q = torch.randn(T, 28, 128, device="cuda", generator=g).bfloat16()
@@ -22,4 +19,4 @@ for _ in range(iters):
     ops.varlen_attn(q, k, v, cu, L)
 torch.cuda.synchronize()
 us = (time.perf_counter() - t0) / iters * 1e6
-print(f"{nseq}x{L} pingpong={pp}: {us:.1f} us, {4.0 * L * L * 28 * 128 / 2 * nseq / us / 1e6:.1f} TFLOP/s")
+print(f"{nseq}x{L}: {us:.1f} us, {4.0 * L * L * 28 * 128 / 2 * nseq / us / 1e6:.1f} TFLOP/s")

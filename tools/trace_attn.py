@@ -30,7 +30,7 @@ def main():
     cu = torch.arange(0, n_seq * L + 1, L, device="cuda", dtype=torch.int32)
     lib = _native.lib()
     if len(sys.argv) > 2 and sys.argv[2] == "q128":
-        lib.vsel_debug_attn_split_q64(C.c_int(0))         # two 4-wave groups, 128 queries per workgroup
+        lib.vsel_debug_set(_native.KNOBS["attn_split_q64"], 0, None)      # two 4-wave groups, 128 queries per workgroup
     lib.vsel_debug_read_attn_trace.argtypes = [C.c_void_p, C.c_int]
     lib.vsel_debug_read_attn_trace.restype = C.c_int
     buf = np.zeros((8, 1024, 8), dtype=np.uint64)

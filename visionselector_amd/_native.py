@@ -66,6 +66,15 @@ SIGNATURES = {
     "vsel_paged_attn_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, C.c_int, _P]),
 }
 
+# include/vsel_debug.h (diagnostic knobs; not part of the drop-in boundary)
+DEBUG_SIGNATURES = {
+    "vsel_debug_set": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "vsel_debug_get": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "vsel_debug_reset": (None, []),
+}
+KNOBS = {"lis_pipeline": 0, "lis_small_path": 1, "lis_fused_select": 2, "attn_use_tr": 3, "attn_waves": 4, "attn_pack": 5,
+         "attn_split": 6, "attn_split_q64": 7, "attn_bwd_split": 8, "lis_splice_fused": 9}
+
 _lib = None
 
 
@@ -81,7 +90,7 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: build it with `python -m visionselector_amd.build` "
                 "(hipcc --offload-arch=gfx950).  visionselector_amd has no CPU / eager fallback.")
         handle = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
@@ -92,6 +101,37 @@ def lib() -> C.CDLL:
 def check(status: int) -> None:
     if status != 0:
         raise VselError(status, lib().vsel_last_error().decode())
+
+
+class debug_knob:
+    """with debug_knob("attn_waves", 8): ...   -- force a kernel form for the duration of the block (include/vsel_debug.h);
+    the previous value is restored on exit, also when the block raises.  Several knobs: debug_knob(a=1, b=2)."""
+
+    def __init__(self, name: str = None, value: int = None, **more):
+        self.items = ([(name, value)] if name is not None else []) + list(more.items())
+        for n, _ in self.items:
+            if n not in KNOBS:
+                raise KeyError(f"unknown knob {n!r}; known: {sorted(KNOBS)}")
+        self.prev = []
+
+    def __enter__(self):
+        for n, v in self.items:
+            old = C.c_int(0)
+            check(lib().vsel_debug_set(KNOBS[n], int(v), C.byref(old)))
+            self.prev.append((n, old.value))
+        return self
+
+    def __exit__(self, *exc):
+        for n, v in reversed(self.prev):
+            lib().vsel_debug_set(KNOBS[n], v, None)
+        self.prev = []
+        return False
+
+
+def debug_get(name: str) -> int:
+    v = C.c_int(0)
+    check(lib().vsel_debug_get(KNOBS[name], C.byref(v)))
+    return v.value
 
 
 def profile_start() -> None:

@@ -110,7 +110,12 @@ def vsel_attention_forward(module, query, key, value, attention_mask, dropout: f
     if kwargs.get("sliding_window") is not None or kwargs.get("softcap") is not None:
         # the flash-attn call shapes raise for these too (_flash_attention_forward above): never run full attention silently
         raise NotImplementedError("vsel attention does not implement sliding_window / softcap")
-    pad = _padding_info(attention_mask, b, lk) if attention_mask is not None else None
+    # Batch-1 decode (Lq < Lk): generate() hands a NEW mask object every step, so the padding probe would cost one blocking
+    # host sync per generated token (and break stream capture) on the main batch-1 path, for a case the cache path cannot
+    # serve anyway -- a left-padded single prompt is not produced by generate() (padding exists to align a BATCH).  Skipped
+    # there; documented limit: decode against a padded cache is refused for B > 1 and not detected for B = 1.
+    probe = attention_mask is not None and not (b == 1 and lq < lk)
+    pad = _padding_info(attention_mask, b, lk) if probe else None
     needs_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
     if (pad is None and not needs_grad and kwargs.get("cu_seq_lens_q") is None and lq <= lk and query.dtype == torch.bfloat16
             and key.shape == value.shape and all(ops.head_major_ok(t) for t in (query, key, value))):

@@ -29,6 +29,43 @@ def _stale() -> bool:
     return any(os.path.getmtime(p) > t for p in deps)
 
 
+# Kernels that issue LDS reads from inline asm and wait for them later (csrc/attn_common.h): a register copy or spill between
+# issue and wait would read stale data, so these must compile without spilled VGPRs.  (source file, mangled-name fragment)
+ASM_READ_KERNELS = (("attn.hip", "varlen_attn_fwd_kernelILb1E"),)
+
+
+def extra_flags() -> list:
+    """VSEL_HIPCC_FLAGS (e.g. -DVSEL_TRACE, -save-temps).  Optimisation-level and debug-info flags are refused: the attention
+    kernels' asm-issued LDS reads rely on the -O3 register allocation (no spills, checked below)."""
+    flags = os.environ.get("VSEL_HIPCC_FLAGS", "").split()
+    bad = [f for f in flags if f.startswith("-O") or f.startswith("-g") or f in ("-fno-inline", "-fno-unroll-loops")]
+    if bad:
+        raise ValueError(f"VSEL_HIPCC_FLAGS: {bad} would change code generation of the hand-scheduled kernels; not accepted")
+    return flags
+
+
+def check_no_spills(src: str, remarks: str) -> None:
+    """Parse -Rpass-analysis=kernel-resource-usage remarks: every ASM_READ_KERNELS instantiation needs 0 spilled VGPRs."""
+    import re
+    frags = [f for s_, f in ASM_READ_KERNELS if os.path.basename(src) == s_]
+    if not frags:
+        return
+    seen = 0
+    for block in remarks.split("Function Name: ")[1:]:
+        name = block.split()[0]
+        if not any(f in name for f in frags):
+            continue
+        m = re.search(r"VGPRs Spill: (\d+)", block)
+        if m is None:
+            raise RuntimeError(f"no resource-usage remark for {name}")
+        seen += 1
+        if int(m.group(1)) != 0:
+            raise RuntimeError(f"{name}: {m.group(1)} spilled VGPRs -- its asm-issued LDS reads (attn_common.h) would read stale "
+                               "registers; reduce live registers before shipping this build")
+    if not seen:
+        raise RuntimeError(f"{src}: no kernel matched {frags}; update build.ASM_READ_KERNELS")
+
+
 def build_native(force: bool = False, verbose: bool = True) -> str:
     """Compile every csrc/*.hip into libvsel.so.  hipcc cross-compiles gfx950 without a GPU."""
     if not force and not _stale():
@@ -45,15 +82,25 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
                 os.path.getmtime(p) for p in [src] + glob.glob(os.path.join(CSRC, "*.h"))
                 + [os.path.join(os.path.dirname(PKG_DIR), "include", "vsel.h")]):
             continue
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("VSEL_HIPCC_FLAGS", "").split() + \
-            ["-c", src, "-o", obj]
+        checked = any(os.path.basename(src) == s_ for s_, _ in ASM_READ_KERNELS)
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + extra_flags() + \
+            (["-Rpass-analysis=kernel-resource-usage"] if checked else []) + ["-c", src, "-o", obj]
         if verbose:
             print("[vsel build]", " ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for cmd, p in procs:
+        procs.append((cmd, src, obj, checked, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for cmd, src, obj, checked, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed ({p.returncode}): {' '.join(cmd)}\n{out}")
+        if checked:
+            try:
+                check_no_spills(src, out)
+            except RuntimeError:
+                os.remove(obj)                      # never link an object that failed the check
+                raise
+            out = "\n".join(ln for ln in out.splitlines() if "kernel-resource-usage" not in ln and "remark:" not in ln)
+            if "warning:" not in out and "error:" not in out:
+                out = ""                            # only the source-context lines of the remarks were left
         if verbose and out.strip():
             print(out)
     link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs

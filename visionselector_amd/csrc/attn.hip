@@ -69,8 +69,10 @@ struct PagedKV {
 // tools/trace_attn.py on L' = 524: with 128-query workgroups a round costs 2.35 us -- two waves per SIMD run the same phase at
 // the same time and their MFMA and VALU time add up -- while 116 of the 256 CUs have no workgroup (140 workgroups); key halves
 // halve the work of a wave per round and 64-query workgroups use 252 CUs.
+// launch bounds: two waves per SIMD for the 4- / 8-wave workgroups; the single-wave GQA-packed decode workgroup owns 32 KiB of
+// LDS by itself, so waves-per-SIMD is LDS-bound there (5 workgroups per CU ~ 1 per SIMD) and asking for 2 only drew a warning
 template <bool USE_TR, int NW, int D, bool PACK = false, int KVS = 1, int KH = 1>
-__global__ __launch_bounds__(64 * NW, 2) void varlen_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+__global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                               const uint16_t* __restrict__ v,
                                                               const int32_t* __restrict__ cu, int hq, int hkv,
                                                               float scale_log2e, int causal, uint16_t* __restrict__ out,
@@ -593,20 +595,17 @@ extern "C" int vsel_debug_read_attn_trace(unsigned long long* out, int clear) {
 }
 #endif
 
-static bool g_attn_use_tr = true;
-static int g_attn_nw = 0;      // 0 = choose by grid size, 4 / 8 = force the workgroup size
-extern "C" void vsel_debug_attn_use_tr(int on) { g_attn_use_tr = on != 0; }
-extern "C" void vsel_debug_attn_waves(int nw) { g_attn_nw = nw; }
-static int g_attn_pack = 2;    // 0 = never, 1 = whenever qlen * rep <= 32, 2 (default) = against a cache when the per-head grid exceeds one round
-extern "C" void vsel_debug_attn_pack(int mode) { g_attn_pack = mode; }
-static int g_attn_split = 2;   // 0 = never, 1 = whenever the 4-wave grid has <= 256 items, 2 (default) = ... and the sequences are not tiny
-extern "C" void vsel_debug_attn_split(int mode) { g_attn_split = mode; }
-static bool g_attn_split_q64 = true;   // 64-query workgroups for the two-stream form when they fit one per CU
-extern "C" void vsel_debug_attn_split_q64(int on) { g_attn_split_q64 = on != 0; }
+// form selection knobs (include/vsel_debug.h; defaults in common.hip):
+//   ATTN_WAVES 0 = choose by grid size, 4 / 8 = force the workgroup size
+//   ATTN_PACK  0 = never, 1 = whenever qlen * rep <= 32, 2 (default) = against a cache when the per-head grid exceeds one round
+//   ATTN_SPLIT 0 = never, 1 = whenever the 4-wave grid has <= 256 items, 2 (default) = ... and the sequences are not tiny
+//   ATTN_SPLIT_Q64 64-query workgroups for the two-stream form when they fit one per CU
 
 static int attn_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
                        int64_t max_seqlen_q, int64_t hq, int64_t hkv, int64_t d, float scale, int causal, void* out,
                        const PagedKV& pg, float* lse = nullptr) {
+  const bool g_attn_use_tr = knob(VSEL_KNOB_ATTN_USE_TR) != 0, g_attn_split_q64 = knob(VSEL_KNOB_ATTN_SPLIT_Q64) != 0;
+  const int g_attn_nw = knob(VSEL_KNOB_ATTN_WAVES), g_attn_pack = knob(VSEL_KNOB_ATTN_PACK), g_attn_split = knob(VSEL_KNOB_ATTN_SPLIT);
   // 8-wave workgroups (256 queries) when there is enough work to fill the chip with them, else 4-wave (128 queries)
   const int64_t items8 = cdiv(max_seqlen_q, 256) * hq * n_seq;
   // measured on MI355X (tools/exp_attn_nw.py): 8 waves +12-16 % at L >= 4096, +4 % at 16 x 2368, -20 % at L = 524

@@ -480,12 +480,12 @@ using namespace vsel;
 // Items of the in-kernel-group dK/dV pass below which the per-q-head split (fp32 partials + group sum) is used instead:
 // measured (tools/bench_attn_bwd.py): the split wins up to ~300 items (4 x 2368: 635 vs 802 us) and loses at 576 (16 x 1100).
 static constexpr int64_t kSplitBelowItems = 512;
-static int g_bwd_split = -1;       // -1 = choose by item count, 0 / 1 = force (tests)
-extern "C" void vsel_debug_attn_bwd_split(int mode) { g_bwd_split = mode; }
+// knob VSEL_KNOB_ATTN_BWD_SPLIT (include/vsel_debug.h): -1 = choose by item count, 0 / 1 = force (tests)
 
 static bool bwd_use_split(int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv) {
   if (hq == hkv) return false;
-  if (g_bwd_split >= 0) return g_bwd_split != 0;
+  const int forced = knob(VSEL_KNOB_ATTN_BWD_SPLIT);
+  if (forced >= 0) return forced != 0;
   return cdiv(max_seqlen, 128) * hkv * n_seq < kSplitBelowItems;
 }
 

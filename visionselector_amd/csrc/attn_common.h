@@ -78,6 +78,11 @@ __device__ __forceinline__ int slice_src_part(int lane, int wave) { return (lane
 // direct-to-LDS prefetch of the next tile.  The reads are therefore issued from inline asm in BATCHES (8 per batch, the next
 // batch in flight behind the MFMAs of the current one) with counted lgkmcnt waits that name the batch's registers
 // (cdna_hip_programming.md 5.7, form (ii)) followed by sched_barrier(0) so that no MFMA is hoisted above its wait (rule 18).
+// The asm outputs are "ready" for the compiler at once although the data lands only at the lds_wait* that names them: a
+// compiler-inserted COPY or SPILL of such a register between issue and wait would read a stale value.  Guards: the outputs are
+// early-clobber (never share a register with the address), every user kernel must compile with 0 spilled VGPRs -- checked at
+// build time by visionselector_amd/build.py (-Rpass-analysis=kernel-resource-usage on attn.hip; the build fails otherwise) --
+// and VSEL_HIPCC_FLAGS refuses optimisation-level / debug flags that would change the register allocation wholesale.
 __device__ __forceinline__ uint32_t lds_u32(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -87,14 +92,14 @@ template <int OFF>
 __device__ __forceinline__ u32x4 lds_read_b128_asm(uint32_t addr) {
   static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
   u32x4 r;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(r) : "v"(addr), "n"(OFF));
   return r;
 }
 template <int OFF>
 __device__ __forceinline__ u32x2 lds_read_tr16_b64_asm(uint32_t addr) {
   static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
   u32x2 r;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(r) : "v"(addr), "n"(OFF));
   return r;
 }
 // wait until at most N LDS operations of this wave are outstanding; the 8 registers of the batch that must have landed are

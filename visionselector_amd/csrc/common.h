@@ -7,6 +7,7 @@
 #include <type_traits>
 
 #include "../../include/vsel.h"
+#include "../../include/vsel_debug.h"
 
 namespace vsel {
 
@@ -42,6 +43,9 @@ static __device__ unsigned long long g_trace[kTraceKernels][kTraceBlocks][kTrace
 #define VSEL_STAMP(kern, slot) do {} while (0)
 #define VSEL_STAMP_DRAIN(kern, slot) do {} while (0)
 #endif
+
+// ---- diagnostic knobs (include/vsel_debug.h): one process-global table, relaxed atomic reads -------------------------
+int knob(int id);
 
 // ---- error plumbing --------------------------------------------------------------------------
 void set_error(const std::string& msg);

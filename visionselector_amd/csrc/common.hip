@@ -2,6 +2,8 @@
 #include "common.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
+#include <atomic>
 #include <string.h>
 #include <utility>
 #include <vector>
@@ -22,6 +24,58 @@ int fail(vsel_status st, const char* fmt, ...) {
 }
 const std::string& last_error() { return g_last_error; }
 }  // namespace vsel
+
+namespace vsel {
+// ---- diagnostic knobs (include/vsel_debug.h) -----------------------------------------------------------------------
+namespace {
+struct KnobSpec { const char* env; int def, lo, hi; };
+constexpr KnobSpec kKnobs[VSEL_KNOB_COUNT] = {
+    {"VSEL_PIPELINE", 0, 0, 1},        // VSEL_KNOB_LIS_PIPELINE
+    {"VSEL_SMALL_PATH", 4, 0, 8},      // VSEL_KNOB_LIS_SMALL_PATH (8 = lis_small.h's kSmallMaxSeg)
+    {"VSEL_FUSED_SELECT", 32, 0, 1 << 30},
+    {nullptr, 1, 0, 1},                // VSEL_KNOB_ATTN_USE_TR
+    {nullptr, 0, 0, 8},                // VSEL_KNOB_ATTN_WAVES
+    {nullptr, 2, 0, 2},                // VSEL_KNOB_ATTN_PACK
+    {nullptr, 2, 0, 2},                // VSEL_KNOB_ATTN_SPLIT
+    {nullptr, 1, 0, 1},                // VSEL_KNOB_ATTN_SPLIT_Q64
+    {nullptr, -1, -1, 1},              // VSEL_KNOB_ATTN_BWD_SPLIT
+    {"VSEL_SPLICE_FUSED", 1, 0, 1},    // VSEL_KNOB_LIS_SPLICE_FUSED
+};
+int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+int knob_default(int id) {
+  const KnobSpec& k = kKnobs[id];
+  const char* e = k.env ? getenv(k.env) : nullptr;
+  return clampi(e ? atoi(e) : k.def, k.lo, k.hi);
+}
+struct KnobTable {
+  std::atomic<int> v[VSEL_KNOB_COUNT];
+  KnobTable() { for (int i = 0; i < VSEL_KNOB_COUNT; ++i) v[i].store(knob_default(i), std::memory_order_relaxed); }
+};
+KnobTable& knobs() {
+  static KnobTable t;          // constructed on first use (thread-safe), environment read once
+  return t;
+}
+}  // namespace
+int knob(int id) { return knobs().v[id].load(std::memory_order_relaxed); }
+}  // namespace vsel
+
+extern "C" int vsel_debug_set(int id, int value, int* previous) {
+  using namespace vsel;
+  if (id < 0 || id >= VSEL_KNOB_COUNT) return fail(VSEL_ERR_INVALID, "vsel_debug_set: unknown knob %d", id);
+  const int old = knobs().v[id].exchange(clampi(value, kKnobs[id].lo, kKnobs[id].hi), std::memory_order_relaxed);
+  if (previous) *previous = old;
+  return VSEL_OK;
+}
+extern "C" int vsel_debug_get(int id, int* value) {
+  using namespace vsel;
+  if (id < 0 || id >= VSEL_KNOB_COUNT || !value) return fail(VSEL_ERR_INVALID, "vsel_debug_get: unknown knob %d", id);
+  *value = knob(id);
+  return VSEL_OK;
+}
+extern "C" void vsel_debug_reset(void) {
+  using namespace vsel;
+  for (int i = 0; i < VSEL_KNOB_COUNT; ++i) knobs().v[i].store(knob_default(i), std::memory_order_relaxed);
+}
 
 namespace vsel {
 // Per-kernel timing with HIP events recorded on the launch stream between kernels.  Off by default;

@@ -119,7 +119,12 @@ using namespace vsel;
 
 extern "C" size_t vsel_gelu_colsum_workspace_bytes(const vsel_segments* seg, int64_t cols) {
   if (!seg || seg->n_seg < 1 || seg->rows_per_seg < 1 || cols < 1) return 0;
-  return (size_t)seg->n_seg * (size_t)cdiv(seg->rows_per_seg, 16) * (size_t)cols * sizeof(float);     // smallest chunk
+  // the partials of the chunking the launch will use: rows per workgroup depend on the vector width (dtype), which this query
+  // does not take, so the larger of the two (bf16: 8 elements per lane, fp32: 4) -- not the 16-row worst case, which was 8x too
+  // large exactly where the fusion is on (147 456 x 5120: 23.6 MB instead of 188 MB)
+  const int rows = gelu_rows_per_wg(seg, cols, 8) < gelu_rows_per_wg(seg, cols, 4) ? gelu_rows_per_wg(seg, cols, 8)
+                                                                                  : gelu_rows_per_wg(seg, cols, 4);
+  return (size_t)seg->n_seg * (size_t)cdiv(seg->rows_per_seg, rows) * (size_t)cols * sizeof(float);
 }
 
 extern "C" int vsel_gelu_colsum(void* stream, const void* x, vsel_dtype dtype, const vsel_segments* seg, int64_t cols, void* y,

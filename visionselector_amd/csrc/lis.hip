@@ -50,27 +50,17 @@ static AuxStream* aux_for_current_device() {
   return &a;
 }
 
-// OFF by default (VSEL_PIPELINE=1 or vsel_debug_set_pipeline(1) turns it on): measured on MI355X at B = 32 / 64 / 128 images it is
+// OFF by default (VSEL_PIPELINE=1 or the knob VSEL_KNOB_LIS_PIPELINE, include/vsel_debug.h, turns it on): measured on MI355X at B = 32 / 64 / 128 images it is
 // 264.7 / 454.3 / 884.6 us per call against 240.9 / 449.2 / 878.6 us for the single-piece, single-stream order -- the halves pay
 // the latency-bound small kernels twice and the two hand-offs, which eats what the overlap wins.
-static int g_pipeline_enabled = [] {
-  const char* e = getenv("VSEL_PIPELINE");
-  return (e && e[0] == '1') ? 1 : 0;
-}();
-extern "C" void vsel_debug_set_pipeline(int on) { g_pipeline_enabled = on; }
+static inline int pipeline_enabled() { return knob(VSEL_KNOB_LIS_PIPELINE); }
 
-// small-batch form (lis_small.h): used up to g_small_path_max_seg segments per call.  Measured on MI355X (Qwen2.5-VL-7B geometry,
+// small-batch form (lis_small.h): used up to small_path_max_seg() segments per call.  Measured on MI355X (Qwen2.5-VL-7B geometry,
 // us per call, small form vs batched form): 1 image 36.2 vs 51.7, 2 images 43.8 vs 55.8, 3 images 52.2 vs 60.8, 4 images 60.4 vs
 // 65.3, 8 images 102.3 vs 86.2 -- the redundant prologues grow with the segment count, so the default limit is 4.
-// VSEL_SMALL_PATH=<n> / vsel_debug_set_small_path(n) set the limit (0 = never; at most kSmallMaxSeg).
-static int g_small_path_max_seg = [] {
-  const char* e = getenv("VSEL_SMALL_PATH");
-  const int v = e ? atoi(e) : 4;
-  return v < 0 ? 0 : (v > kSmallMaxSeg ? kSmallMaxSeg : v);
-}();
-extern "C" void vsel_debug_set_small_path(int max_seg) {
-  g_small_path_max_seg = max_seg < 0 ? 0 : (max_seg > kSmallMaxSeg ? kSmallMaxSeg : max_seg);
-}
+// VSEL_SMALL_PATH=<n> / knob VSEL_KNOB_LIS_SMALL_PATH set the limit (0 = never; at most kSmallMaxSeg).
+static_assert(kSmallMaxSeg == 8, "common.hip clamps VSEL_KNOB_LIS_SMALL_PATH to 8");
+static inline int small_path_max_seg() { return knob(VSEL_KNOB_LIS_SMALL_PATH); }
 #ifdef VSEL_TRACE
 // copies the stamps of the last small-batch call: out[kTraceKernels][kTraceBlocks][kTraceSlots] (tools/trace_small.py)
 extern "C" int vsel_debug_read_trace(unsigned long long* out, int clear) {
@@ -86,15 +76,11 @@ extern "C" int vsel_debug_read_trace(unsigned long long* out, int clear) {
 
 // select fused into the gather (select_gather_small_kernel) for mid-size batches of the nine-launch form.  Measured (7B geometry,
 // us per call, fused vs two launches): 8 images 82.0 vs 83.3, 16 135.3 vs 137.0, 32 233.4 vs 238.8, 48 350.9 vs 347.1, 128 900.8 vs
-// 877.0 -> up to 32 segments.  VSEL_FUSED_SELECT=<n> / vsel_debug_set_fused_select(n).
-static int g_fused_select_max_seg = [] {
-  const char* e = getenv("VSEL_FUSED_SELECT");
-  return e ? atoi(e) : 32;
-}();
-extern "C" void vsel_debug_set_fused_select(int max_seg) { g_fused_select_max_seg = max_seg; }
+// 877.0 -> up to 32 segments.  VSEL_FUSED_SELECT=<n> / knob VSEL_KNOB_LIS_FUSED_SELECT.
+static inline int fused_select_max_seg() { return knob(VSEL_KNOB_LIS_FUSED_SELECT); }
 
 static bool use_small_path(const vsel_segments* seg, const vsel_scorer* sc, const LisPlan& p) {
-  return seg->n_seg <= g_small_path_max_seg && small_path_ok(seg, sc, p);
+  return seg->n_seg <= small_path_max_seg() && small_path_ok(seg, sc, p);
 }
 
 template <typename T, typename TW>
@@ -114,10 +100,10 @@ static int select_whole(hipStream_t st, const T* h, const vsel_segments* seg, co
   if (rc) return rc;
   rc = run_score<T>(st, h, seg, sc, ws, p, scores, p2l);
   if (rc) return rc;
-  // up to g_fused_select_max_seg segments: the radix select runs inside every gather workgroup (one launch less; same indices)
+  // up to fused_select_max_seg() segments: the radix select runs inside every gather workgroup (one launch less; same indices)
   // (every gather workgroup repeats its segment's select: not when there are thousands of them -- 32 images at 50 % retain:
   // 308.0 vs 305.7 us)
-  if (seg->n_seg <= g_fused_select_max_seg && seg->n_seg * cdiv(seg->k, 16) <= 1536)
+  if (seg->n_seg <= fused_select_max_seg() && seg->n_seg * cdiv(seg->k, 16) <= 1536)
     return launch_select_gather_small<T>(st, h, (int)sc->d, seg, scores, idx, out, l2p);
   rc = launch_select(st, scores, seg, idx, nullptr);
   if (rc) return rc;
@@ -129,7 +115,7 @@ static int lis_select_impl(hipStream_t st, const T* h, const vsel_segments* seg,
                            int64_t* idx, float* scores, const int64_t* l2p = nullptr, const int64_t* p2l = nullptr,
                            const float* col_sums = nullptr) {
   const int64_t S = seg->n_seg, d = sc->d;
-  const bool halves = g_pipeline_enabled && S >= kPipelineMinSegments && !l2p && !col_sums;
+  const bool halves = pipeline_enabled() && S >= kPipelineMinSegments && !l2p && !col_sums;
   if (!halves) {
     const LisPlan p = make_plan(S, seg->rows_per_seg, d, sc->hd);
     return select_whole<T, TW>(st, h, seg, sc, ws, p, out, idx, scores, l2p, p2l, col_sums);

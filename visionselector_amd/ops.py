@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
+import itertools
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -46,14 +47,14 @@ def _stream() -> int:
 
 
 def _device_guard(fn):
-    """Run `fn` with the device of its first GPU tensor argument current (as every ATen op does): libvsel launches on
+    """Run `fn` with the device of its first GPU tensor argument (positional or keyword) current (as every ATen op does): libvsel launches on
     torch's current stream of the current device, so tensors on cuda:1 in a process whose current device is cuda:0
     (HF device_map, multi-GPU processes) must switch first -- otherwise the kernels would be enqueued on the wrong GPU."""
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
-        for a in args:
-            if isinstance(a, torch.Tensor):
-                if a.is_cuda and a.device.index != torch.cuda.current_device():
+        for a in itertools.chain(args, kwargs.values()):          # positional and keyword tensors alike
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
                     with torch.cuda.device(a.device):
                         return fn(*args, **kwargs)
                 break

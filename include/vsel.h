@@ -231,6 +231,43 @@ int vsel_splice_batched(void* stream, const int64_t* input_ids, int64_t total_le
                         void* new_inputs_embeds, int64_t* new_position_ids, int32_t* cu_seqlens_out, int32_t* src_scratch,
                         int32_t* stats);
 
+/* -------- score + hard top-k + splice in one call: the kept rows are written ONCE ---------------------------------
+ * Replaces EV/token_compression/selector_model.py:184-189 (scores, topk + sort, hidden_states[all_indices, :]) TOGETHER WITH
+ * the splice of :246-262 / :264-290 / :311-320 (OV/compression_method/modeling_selector.py:173-180, :259-276, :311-314).
+ * The reference materialises hidden_states_new [k, D] and masked_scatter()s it into inputs_embeds; vsel_lis_select +
+ * vsel_splice(_batched) do the same with two copies of k x D.  Here the kept rows go straight from the token tensor into
+ * new_inputs_embeds (token width D must equal the LLM width, same dtype): one k x D write + read and, for a few prompts, two
+ * launches less.  Every output is bit-identical to vsel_lis_select(_permuted / _presummed) followed by vsel_splice(_batched).
+ *   seg          one LIS segment per PROMPT (n_seg = S prompts; all images of a prompt are scored jointly, EV :184-186); prompt s
+ *                holds exactly its segment's rows as placeholder tokens, in order
+ *   col_sums     NULL, or the producer's column sums (vsel_lis_select_presummed); row maps NULL or both given (.._permuted)
+ *   input_ids    int64 [T] = S prompts back to back; cu_seqlens int32 [S + 1] DEVICE (may be NULL when S == 1: one prompt of T)
+ *   max_len_out  max over prompts of L_s - N_s + k_s (host value; sizes the launch)
+ *   inputs_embeds [T, D]; position_ids int64 [pos_rows, T] or NULL; attention_mask int64 [T] or NULL
+ *   out: idx int64 [sum k] (local ranks, ascending -- vsel_lis_select's idx), scores fp32 [sum N]; selected_indices,
+ *        new_input_ids int64 [T']; new_inputs_embeds [T', D]; new_position_ids [pos_rows, T']; new_attention_mask [T'] or NULL;
+ *        cu_seqlens_out int32 [S + 1] (may be NULL when S == 1); src_scratch int32 [T']; stats int32 [4] = {visual tokens
+ *        found, rows written, kept visual rows, prompts whose token counts disagree (0 on success)}.  T' = T - sum N + sum k.
+ * Workspace: vsel_lis_workspace_bytes(seg, D, Hd).                                                                        */
+int vsel_lis_select_splice(void* stream, const void* h, vsel_dtype hdtype, const vsel_segments* seg,
+                           const vsel_scorer* scorer, void* workspace, size_t workspace_bytes, const float* col_sums,
+                           const int64_t* logical_to_physical, const int64_t* physical_to_logical,
+                           const int64_t* input_ids, int64_t total_len, const int32_t* cu_seqlens, int64_t max_len_out,
+                           int64_t visual_token_id, const void* inputs_embeds, const int64_t* position_ids, int64_t pos_rows,
+                           const int64_t* attention_mask, int64_t* idx, float* scores, int64_t* selected_indices,
+                           int64_t* new_input_ids, void* new_inputs_embeds, int64_t* new_position_ids,
+                           int64_t* new_attention_mask, int32_t* cu_seqlens_out, int32_t* src_scratch, int32_t* stats);
+
+/* The same on GIVEN scores (fp32 [sum N], logical order; an input here): hard top-k (vsel_topk_select's tie rule) + splice with
+ * the kept rows read from h [sum N, d] (through logical_to_physical when not NULL).  EV :187-189 + :246-262.             */
+int vsel_topk_select_splice(void* stream, const void* h, vsel_dtype hdtype, int64_t d, const vsel_segments* seg,
+                            const float* scores, const int64_t* logical_to_physical, const int64_t* input_ids,
+                            int64_t total_len, const int32_t* cu_seqlens, int64_t max_len_out, int64_t visual_token_id,
+                            const void* inputs_embeds, const int64_t* position_ids, int64_t pos_rows,
+                            const int64_t* attention_mask, int64_t* idx, int64_t* selected_indices, int64_t* new_input_ids,
+                            void* new_inputs_embeds, int64_t* new_position_ids, int64_t* new_attention_mask,
+                            int32_t* cu_seqlens_out, int32_t* src_scratch, int32_t* stats);
+
 /* -------- var-len causal attention (compressed-sequence prefill) --------------------------------
  * Replaces flash_attn_varlen_func as called by FT/qwenvl/train/trainer.py:101-113 and the FA2 prefill
  * of EV/qwen25vl/modeling_qwen2_5_vl.py:900 / OV/llavaonevision1_5/modeling_llavaonevision1_5.py:686.

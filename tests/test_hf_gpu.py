@@ -295,6 +295,33 @@ def test_generic_tower_wrapper_llavaov_style():
     assert new_pos.shape == (1, 1, ids.shape[1] - n + k) and torch.equal(new_pos[0, 0], sel)
 
 
+def test_select_splice_fusion_is_transparent(selector_model):
+    """The *_Selector prefill writes the kept rows once, from the merger's output into inputs_embeds' (vsel_lis_select_splice):
+    same logits / indices / soft scores, bit for bit, as visual() followed by vsel_splice, with and without the un-reorder
+    fusion; the unfused launches are gone from the fused forward."""
+    from visionselector_amd import _native as N
+    m = selector_model
+    m.visual.budgets = 0.25
+    inp, n_vis = make_inputs(grid=(1, 32, 32), seed=10)
+    res = {}
+    for fuse_unreorder in (True, False):
+        m.visual.fuse_unreorder = fuse_unreorder
+        for fuse in (True, False):
+            m.fuse_select_splice = fuse
+            m.model.rope_deltas = None
+            N.profile_start()
+            with torch.no_grad():
+                o = m(**inp)
+            prof = N.profile_stop()
+            assert (("select_splice_small_kernel" in prof) == fuse) and (("splice_embed_kernel" in prof) == (not fuse)), prof
+            res[(fuse_unreorder, fuse)] = (o.logits.clone(), m.visual.last_selected_indices.clone(),
+                                           m.visual.last_combined_scores.clone(), m.model.rope_deltas.clone())
+        for a, b in zip(res[(fuse_unreorder, True)], res[(fuse_unreorder, False)]):
+            assert torch.equal(a, b)
+    m.visual.fuse_unreorder = True
+    m.fuse_select_splice = True
+
+
 def test_unreorder_fusion_is_transparent(selector_model):
     """The inference tower skips transformers' `merged[reverse_indices, :]` gather (vsel_lis_select_permuted): same kept
     tokens / indices / logits as with the gather executed."""
@@ -317,13 +344,26 @@ def test_unreorder_fusion_is_transparent(selector_model):
     calls = []
     orig = hf_generic._select_block_permuted
     hf_generic._select_block_permuted = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    m.fuse_select_splice = False          # the tower's own forward (visual() -> (tokens, indices, N)), as the reference calls it
     try:
         with torch.no_grad():
             m.model.rope_deltas = None
             m(**inp)
     finally:
         hf_generic._select_block_permuted = orig
+        m.fuse_select_splice = True
     assert calls, "permuted path not taken"
+    # and the select->splice form hands the same row maps to vsel_lis_select_splice
+    seen = []
+    orig_ss = hf_generic.ops.lis_select_splice
+    hf_generic.ops.lis_select_splice = lambda *a, **k: (seen.append(k.get("logical_to_physical")), orig_ss(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            m.model.rope_deltas = None
+            m(**inp)
+    finally:
+        hf_generic.ops.lis_select_splice = orig_ss
+    assert seen and seen[0] is not None and not torch.equal(seen[0].cpu(), torch.arange(n_vis))
 
 
 def test_training_through_native_attention_matches_sdpa():

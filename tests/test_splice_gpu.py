@@ -230,3 +230,146 @@ def test_config5_real_geometry_select_splice_attend(ops):
     ref = oattn.varlen_attention(q[a:b, :7].float().cpu().numpy(), kk[a:b, :1].float().cpu().numpy(), vv[a:b, :1].float().cpu().numpy(),
                                  np.array([0, b - a]))
     parity.check_fwd("test_config5_real_geometry", o[a:b, :7].float().cpu().numpy().astype(np.float64), ref)
+
+
+# ---------------------------------------------------------------------------------------------------
+# select -> splice in one call, kept rows written once (vsel_lis_select_splice / vsel_topk_select_splice)
+# ---------------------------------------------------------------------------------------------------
+def _forms():
+    """(knob value, kernel that must have run): the one-launch form and the three-launch general form."""
+    return ((1, "select_splice_small_kernel"), (0, "splice_index_seg_kernel"))
+
+
+@pytest.mark.parametrize("name", ["image_a", "image_b", "video_a"])
+def test_topk_select_splice_matches_reference_golden(ops, golden_dir, name):
+    """The reference's own splice goldens through the fused entry: scores that make top-k pick exactly the golden's
+    all_indices, a token tensor whose kept rows are the golden's kept embeddings -> every output bit-exact, both forms."""
+    from visionselector_amd import _native as N
+    g = np.load(os.path.join(golden_dir, f"splice_{name}.npz"))
+    vis = IMAGE_TOKEN if str(g["kind"]) == "image" else VIDEO_TOKEN
+    n, k, d = int(g["n_visual"]), int(g["k"]), int(g["d_llm"])
+    ids = torch.from_numpy(oin.make_prompt(n, int(g["n_pre"]), int(g["n_post"]), vis, int(g["seed"])))
+    emb = _embed(ids, d)[0]
+    rng = np.random.default_rng(1)
+    h = rng.standard_normal((n, d), dtype=np.float32)
+    h[g["all_idx"]] = g["vis_embeds"]
+    scores = (rng.random(n, dtype=np.float32) * 0.5).astype(np.float32)
+    scores[g["all_idx"]] += 1.0                                      # kept ranks strictly above the rest
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(3))
+    h_phys = torch.empty(n, d)
+    h_phys[perm] = torch.from_numpy(h)                               # logical row i lives at physical row perm[i]
+    for knob, kernel in _forms():
+        for hh, l2p in ((torch.from_numpy(h), None), (h_phys, perm)):
+            with N.debug_knob("lis_splice_fused", knob):
+                N.profile_start()
+                o = ops.topk_select_splice(torch.from_numpy(scores).cuda(), hh.cuda(), ids[0].cuda(), emb.cuda(), vis, [ids.shape[1]],
+                                           [n], [k], position_ids=torch.from_numpy(g["position_ids_full"]).cuda()[:, 0, :],
+                                           attention_mask=torch.ones_like(ids[0]).cuda(),
+                                           logical_to_physical=None if l2p is None else l2p.cuda(), check=True)
+                prof = N.profile_stop()
+            assert kernel in prof, prof
+            assert np.array_equal(o["idx"].cpu().numpy(), g["all_idx"])
+            assert np.array_equal(o["inputs_embeds"].cpu().numpy()[None], g["inputs_embeds"])
+            assert np.array_equal(o["position_ids"].cpu().numpy()[:, None, :], g["position_ids"])
+            assert np.array_equal(o["attention_mask"].cpu().numpy()[None], g["attention_mask"])
+            if str(g["kind"]) == "image":
+                ref_sel, ref_ids = osplice.splice_image(ids.numpy(), vis, g["all_idx"])
+            else:
+                ref_sel, ref_ids, _ = osplice.splice_video(ids.numpy(), vis, g["all_idx"])
+            assert np.array_equal(o["selected_indices"].cpu().numpy(), ref_sel)
+            assert np.array_equal(o["input_ids"].cpu().numpy()[None], ref_ids)
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_topk_select_splice_matches_ov_golden(ops, golden_dir, name):
+    """LLaVA-OV goldens (1-D position row; the reference's LLaVAOneVision1_5_Model_Selector.forward)."""
+    g = np.load(os.path.join(golden_dir, f"ovsplice_{name}.npz"))
+    n, k, d = int(g["n_visual"]), int(g["k"]), int(g["d_llm"])
+    ids = torch.from_numpy(oin.make_prompt(n, int(g["n_pre"]), int(g["n_post"]), IMAGE_TOKEN, int(g["seed"])))
+    L = ids.shape[1]
+    emb = _embed(ids, d)[0]
+    rng = np.random.default_rng(2)
+    h = rng.standard_normal((n, d), dtype=np.float32)
+    h[g["all_idx"]] = g["vis_embeds"]
+    scores = np.zeros(n, np.float32)
+    scores[g["all_idx"]] = 1.0                                       # ties among the rest: lower index first, never reached
+    pos_in = (torch.arange(L) + (5 if bool(g["with_position_ids"]) else 0))[None]
+    o = ops.topk_select_splice(torch.from_numpy(scores).cuda(), torch.from_numpy(h).cuda(), ids[0].cuda(), emb.cuda(), IMAGE_TOKEN,
+                               [L], [n], [k], position_ids=torch.cat([pos_in, torch.arange(L)[None]]).cuda(),
+                               attention_mask=torch.ones(L, dtype=torch.int64).cuda(), check=True)
+    assert np.array_equal(o["inputs_embeds"].cpu().numpy()[None], g["inputs_embeds"])
+    assert np.array_equal(o["position_ids"][0].cpu().numpy(), np.asarray(g["position_ids"]).reshape(-1))
+    assert np.array_equal(o["position_ids"][1].cpu().numpy(), np.asarray(g["cache_position"]).reshape(-1))
+    assert np.array_equal(o["attention_mask"].cpu().numpy()[None], g["attention_mask"])
+
+
+@pytest.mark.parametrize("seq_lens,visual_lens,ks,d,hd,dt", [
+    ([2368], [2304], [460], 3584, 1792, torch.bfloat16),                    # the reference's call: one 1344^2 image, 20 %
+    ([2368], [2304], [1152], 3584, 1792, torch.bfloat16),
+    ([700], [576], [115], 2048, 1024, torch.float32),
+    ([5900], [5832], [1166], 4096, 2048, torch.bfloat16),                   # LLaVA-OV 8 x 729 jointly
+    ([700, 2400, 1300], [576, 2304, 1100], [115, 460, 1100], 2048, 1024, torch.bfloat16),     # packed; k = N prompt
+    ([4200, 64, 3000, 1025, 90, 5000, 33, 800, 640], [4096, 1, 2900, 1024, 60, 4800, 2, 700, 600],
+     [819, 1, 580, 204, 12, 960, 1, 140, 120], 512, 128, torch.bfloat16),   # 9 prompts: general form even with the knob on
+    ([40000], [39000], [7800], 64, 32, torch.float32),                      # > 32 768 visual tokens: general form
+])
+def test_lis_select_splice_equals_select_then_splice(ops, seq_lens, visual_lens, ks, d, hd, dt):
+    """vsel_lis_select_splice == vsel_lis_select + vsel_splice(_batched), every output bit for bit, in both forms; the
+    unfused pair is itself pinned to the reference (test_lis_gpu / the tests above), visual tokens interleaved with text."""
+    from visionselector_amd import _native as N
+    rng = np.random.default_rng(sum(seq_lens) + sum(ks))
+    ids, _, emb, _, pos = _packed_case(rng, seq_lens, visual_lens, ks, d, dt)
+    c = oin.make_case(d, hd, sum(visual_lens), 9)
+    h = torch.from_numpy(c["h"]).to(dt).cuda()
+    wq, bq, wk, bk = (torch.from_numpy(c[x]).bfloat16().cuda() for x in ("wq", "bq", "wk", "bk"))
+    am = torch.from_numpy(rng.integers(0, 2, ids.shape[0]).astype(np.int64)).cuda()
+    ids_t, emb_t, pos_t = torch.from_numpy(ids).cuda(), emb.cuda(), pos.cuda()
+    out, idx, scores = ops.lis_select_varlen(h, visual_lens, ks, wq, bq, wk, bk)
+    sel, new_ids, new_emb, new_pos, cu = ops.splice_batched(ids_t, emb_t, IMAGE_TOKEN, seq_lens, visual_lens, ks, idx, out,
+                                                            position_ids=pos_t, check=True)
+    for knob, kernel in _forms():
+        with N.debug_knob("lis_splice_fused", knob):
+            N.profile_start()
+            o = ops.lis_select_splice(h, wq, bq, wk, bk, ids_t, emb_t, IMAGE_TOKEN, seq_lens, visual_lens, ks, position_ids=pos_t,
+                                      attention_mask=am, check=True)
+            prof = N.profile_stop()
+        small = knob == 1 and len(seq_lens) <= 8 and max(visual_lens) <= 32768
+        assert ("select_splice_small_kernel" in prof) == small and ("splice_index_seg_kernel" in prof) == (not small), prof
+        assert "gather_rows_kernel" not in prof and "select_gather_small_kernel" not in prof      # no [k, D] staging
+        assert torch.equal(o["idx"], idx) and torch.equal(o["scores"], scores)
+        assert torch.equal(o["selected_indices"], sel) and torch.equal(o["input_ids"], new_ids)
+        assert torch.equal(o["inputs_embeds"], new_emb) and torch.equal(o["position_ids"], new_pos)
+        assert torch.equal(o["cu_seqlens"], cu) and torch.equal(o["attention_mask"], am[sel])
+
+
+def test_lis_select_splice_permuted_presummed_and_mismatch(ops):
+    """Window-ordered tokens (row maps) and producer column sums through the fused entry == the unfused entries; a prompt whose
+    placeholder count disagrees with its segment raises (reference: ValueError, FT/compression_method/selector_model.py:210-213)
+    and never reads out of bounds."""
+    d, hd, n, k, L = 2048, 1024, 640, 128, 700
+    rng = np.random.default_rng(4)
+    ids, _, emb, _, pos = _packed_case(rng, [L], [n], [k], d, torch.bfloat16)
+    c = oin.make_case(d, hd, n, 78)
+    h = torch.from_numpy(c["h"]).bfloat16().cuda()
+    wq, bq, wk, bk = (torch.from_numpy(c[x]).bfloat16().cuda() for x in ("wq", "bq", "wk", "bk"))
+    l2p = torch.randperm(n, generator=torch.Generator().manual_seed(3)).cuda()
+    p2l = torch.empty_like(l2p)
+    p2l[l2p] = torch.arange(n, device="cuda")
+    sums = h.float().sum(0, keepdim=True).contiguous()
+    ids_t, emb_t, pos_t = torch.from_numpy(ids).cuda(), emb.cuda(), pos.cuda()
+    out, idx, scores = ops.lis_select_presummed(h, sums, wq, bq, wk, bk, k, logical_to_physical=l2p, physical_to_logical=p2l)
+    ref = ops.splice(ids_t[None], emb_t[None], IMAGE_TOKEN, idx, out, n, position_ids=pos_t[:, None, :])
+    o = ops.lis_select_splice(h, wq, bq, wk, bk, ids_t, emb_t, IMAGE_TOKEN, [L], [n], [k], position_ids=pos_t, col_sums=sums,
+                              logical_to_physical=l2p, physical_to_logical=p2l, check=True)
+    assert torch.equal(o["idx"], idx) and torch.equal(o["scores"], scores)
+    assert torch.equal(o["selected_indices"], ref[0]) and torch.equal(o["input_ids"], ref[1][0])
+    assert torch.equal(o["inputs_embeds"], ref[2][0]) and torch.equal(o["position_ids"], ref[3][:, 0, :])
+    bad = ids_t.clone()
+    bad[(bad == IMAGE_TOKEN).nonzero()[:5, 0]] = 11                  # five placeholders short
+    from visionselector_amd import _native as N
+    for knob in (1, 0):
+        with N.debug_knob("lis_splice_fused", knob):
+            with pytest.raises(ValueError, match="do not match"):
+                ops.lis_select_splice(h, wq, bq, wk, bk, bad, emb_t, IMAGE_TOKEN, [L], [n], [k], check=True)
+    with pytest.raises(ValueError, match="same dtype and width"):
+        ops.lis_select_splice(h, wq, bq, wk, bk, ids_t, emb_t.float(), IMAGE_TOKEN, [L], [n], [k])

@@ -87,6 +87,95 @@ def _merged_tokens(out) -> torch.Tensor:
     return merged
 
 
+@torch.no_grad()
+def tower_tokens_for_selection(self, base_forward: Callable, hidden_states: torch.Tensor, grid_thw: torch.Tensor, **kwargs):
+    """Run the tower up to the LIS block: -> (merged tokens [N, D] as the merger stored them, reverse_indices or None,
+    column sums fp32 [1, D] or None).  With reverse_indices the tokens are still in WINDOW order and the un-reorder gather of
+    EV/token_compression/selector_model.py:179-181 has been recorded instead of executed (_LazyRows); with column sums the
+    merger's GELU was vsel_gelu_colsum and sweep 1 of the LIS can be skipped."""
+    merger = getattr(self, "merger", None)
+    handle = None
+    fused_gelu, slot = None, None
+    if merger is not None and not torch.is_grad_enabled() and getattr(self, "fuse_unreorder", True):
+        handle = merger.register_forward_hook(lambda mod, inp, out: _LazyRows(out) if out.dim() == 2 else out)
+        # visual.fuse_merger_colsum: True / False, or None (default) = automatic: on from kFuseMinTokens merged tokens per
+        # call.  Measured on MI355X (tools/exp_merger_fusion.py, profiles/r02_merger_fusion.jsonl): GELU + LIS 1392 -> 1290 us
+        # at 147 456 tokens (-7.4 %), 391 -> 408 us at 36 864 (+4 %), and a clear loss at one image (the fused GELU costs
+        # ~25 us more than torch's, the skinny fp32 GEMM ~30 us; the sweep it removes is 5 us per image)
+        fuse = getattr(self, "fuse_merger_colsum", None)
+        if fuse is None:
+            merge = int(getattr(self, "spatial_merge_unit", 0) or getattr(self, "spatial_merge_size", 2) ** 2)
+            fuse = hidden_states.shape[0] // max(1, merge) >= kFuseMinTokens
+        slot = _merger_gelu_slot(merger) if fuse else None
+        if slot is not None:
+            fused_gelu = _GeluColsum()
+            original_gelu = slot[0][slot[1]]
+            slot[0][slot[1]] = fused_gelu
+    try:
+        merged = _merged_tokens(base_forward(self, hidden_states, grid_thw, **kwargs))
+    finally:
+        if handle is not None:
+            handle.remove()
+        if slot is not None:
+            slot[0][slot[1]] = original_gelu
+    perm = getattr(merged, "_perm", None) if isinstance(merged, _LazyRows) else None
+    merged = merged.as_subclass(torch.Tensor).detach()
+    col_sums = None
+    if fused_gelu is not None and fused_gelu.col_sums is not None and perm is not None:
+        # sum_rows(H) = sum_rows(G) W2^T + N b2 (one skinny fp32 GEMM; the merger's last Linear is linear)
+        col_sums = merger_col_sums(fused_gelu.col_sums, slot[0][2], merged.shape[0])
+    return merged, perm, col_sums
+
+
+@torch.no_grad()
+def select_and_splice(self, base_forward: Callable, hidden_states: torch.Tensor, grid_thw: torch.Tensor, input_ids: torch.Tensor,
+                      inputs_embeds: torch.Tensor, visual_token_id: int, position_ids=None, attention_mask=None,
+                      check: bool = True, **kwargs):
+    """Tower -> LIS -> splice for ONE prompt with the kept rows written once, straight from the merger's output into
+    inputs_embeds' (vsel_lis_select_splice): what `visual(...)` followed by the splice of EV/token_compression/selector_model.py:
+    246-262 / :264-290 / :311-320 computes, without the [k, D] tensor in between.  input_ids [1, L], inputs_embeds [1, L, D],
+    position_ids [R, 1, L] or None, attention_mask [1, L] or None ->
+    (selected_indices [L'], input_ids' [1, L'], inputs_embeds' [1, L', D], position_ids' [R, 1, L'] | None, attention_mask' |
+    None, total_token_num); sets last_combined_scores / last_selected_indices like the tower's own forward.
+    Returns None when the fused form does not apply (token width / dtype differ from the LLM's): use visual() + ops.splice."""
+    merged, perm, col_sums = tower_tokens_for_selection(self, base_forward, hidden_states, grid_thw, **kwargs)
+    total = merged.shape[0]
+    if merged.dtype != inputs_embeds.dtype or merged.shape[1] != inputs_embeds.shape[-1] or input_ids.shape[0] != 1:
+        return None, (merged, perm, col_sums)
+    k = max(1, int(total * self.budgets))                                                   # EV :186
+    l2p = p2l = None
+    if perm is not None:
+        l2p = perm.to(merged.device).contiguous()
+        p2l = torch.empty_like(l2p)
+        p2l[l2p] = torch.arange(total, device=l2p.device, dtype=l2p.dtype)
+    params = [p.detach().contiguous() for p in self.importance_scorer.params()]
+    L = input_ids.shape[1]
+    o = ops.lis_select_splice(
+        merged.contiguous(), *params, input_ids[0].contiguous(), inputs_embeds[0].contiguous(), visual_token_id, [L], [total], [k],
+        position_ids=None if position_ids is None else position_ids.reshape(-1, L), col_sums=col_sums,
+        attention_mask=None if attention_mask is None else attention_mask[0], logical_to_physical=l2p, physical_to_logical=p2l,
+        check=check)
+    combined = None
+    if 0 < k < total:                                                                        # EV :190 (visualisation only)
+        combined = ops.soft_topk_fwd(o["scores"][None], k)[0][0].to(merged.dtype)
+    self.last_combined_scores = combined
+    self.last_selected_indices = o["idx"]
+    new_pos = None if o["position_ids"] is None else o["position_ids"][:, None, :]
+    new_am = None if o["attention_mask"] is None else o["attention_mask"][None]
+    return (o["selected_indices"], o["input_ids"][None], o["inputs_embeds"][None], new_pos, new_am, total), None
+
+
+def select_block_from_tokens(self, merged, perm, col_sums):
+    """The LIS block on tokens tower_tokens_for_selection returned (the unfused continuation of select_and_splice)."""
+    if perm is not None:
+        out, idx, total, combined = _select_block_permuted(merged, perm, self.importance_scorer, self.budgets, col_sums)
+    else:
+        out, idx, total, combined = lis_select_block(merged, self.importance_scorer, self.budgets)
+    self.last_combined_scores = combined
+    self.last_selected_indices = idx
+    return out, idx, total
+
+
 def make_vision_tower_forward_selector(base_forward: Callable, mode: str):
     """base_forward(self, hidden_states, grid_thw, **kw) -> merged tokens.  mode 'train' -> the reference's
     *_vision_tower_forward_selector of compression_method/selector_model.py (returns (H', img_mask, constraint_img_mask));
@@ -100,37 +189,7 @@ def make_vision_tower_forward_selector(base_forward: Callable, mode: str):
         return lis_train_block(merged, self.importance_scorer, self.budgets)
 
     def forward_eval(self, hidden_states: torch.Tensor, grid_thw: torch.Tensor, **kwargs):
-        merger = getattr(self, "merger", None)
-        handle = None
-        fused_gelu, slot = None, None
-        if merger is not None and not torch.is_grad_enabled() and getattr(self, "fuse_unreorder", True):
-            handle = merger.register_forward_hook(lambda mod, inp, out: _LazyRows(out) if out.dim() == 2 else out)
-            # visual.fuse_merger_colsum: True / False, or None (default) = automatic: on from kFuseMinTokens merged tokens per
-            # call.  Measured on MI355X (tools/exp_merger_fusion.py, profiles/r02_merger_fusion.jsonl): GELU + LIS 1392 -> 1290 us
-            # at 147 456 tokens (-7.4 %), 391 -> 408 us at 36 864 (+4 %), and a clear loss at one image (the fused GELU costs
-            # ~25 us more than torch's, the skinny fp32 GEMM ~30 us; the sweep it removes is 5 us per image)
-            fuse = getattr(self, "fuse_merger_colsum", None)
-            if fuse is None:
-                merge = int(getattr(self, "spatial_merge_unit", 0) or getattr(self, "spatial_merge_size", 2) ** 2)
-                fuse = hidden_states.shape[0] // max(1, merge) >= kFuseMinTokens
-            slot = _merger_gelu_slot(merger) if fuse else None
-            if slot is not None:
-                fused_gelu = _GeluColsum()
-                original_gelu = slot[0][slot[1]]
-                slot[0][slot[1]] = fused_gelu
-        try:
-            merged = _merged_tokens(base_forward(self, hidden_states, grid_thw, **kwargs))
-        finally:
-            if handle is not None:
-                handle.remove()
-            if slot is not None:
-                slot[0][slot[1]] = original_gelu
-        perm = getattr(merged, "_perm", None) if isinstance(merged, _LazyRows) else None
-        merged = merged.as_subclass(torch.Tensor).detach()
-        col_sums = None
-        if fused_gelu is not None and fused_gelu.col_sums is not None and perm is not None:
-            # sum_rows(H) = sum_rows(G) W2^T + N b2 (one skinny fp32 GEMM; the merger's last Linear is linear)
-            col_sums = merger_col_sums(fused_gelu.col_sums, slot[0][2], merged.shape[0])
+        merged, perm, col_sums = tower_tokens_for_selection(self, base_forward, hidden_states, grid_thw, **kwargs)
         if perm is not None:
             out, idx, total, combined = _select_block_permuted(merged, perm, self.importance_scorer, self.budgets, col_sums)
         else:

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as hf
 
 from . import ops
-from .hf_generic import make_vision_tower_forward_selector
+from .hf_generic import make_vision_tower_forward_selector, select_and_splice, select_block_from_tokens
 from .selector import TransformerScorer
 
 _BaseTower = hf.Qwen2_5_VisionTransformerPretrainedModel
@@ -146,18 +146,29 @@ class Qwen2_5_VLForConditionalGeneration_Selector(_BaseCausal):
                     mm_token_type_ids=_mm_types_from_ids(origin_input_ids, self.config))
                 self.model.rope_deltas = deltas
             if pixel_values is not None:
-                pixel_values = pixel_values.type(self.visual.dtype)
-                vis_embeds, all_indices, visual_token_num = self.visual(pixel_values, grid_thw=image_grid_thw)
-                vis_id = self.config.image_token_id
+                pix, grid, vis_id = pixel_values.type(self.visual.dtype), image_grid_thw, self.config.image_token_id
             else:
-                pixel_values_videos = pixel_values_videos.type(self.visual.dtype)
-                vis_embeds, all_indices, visual_token_num = self.visual(pixel_values_videos, grid_thw=video_grid_thw)
-                vis_id = self.config.video_token_id
-            # one fused device splice (vsel_splice) instead of where / cat / sort / index / masked_scatter (:246-262, :264-290)
-            selected_indices, input_ids, inputs_embeds, position_ids, attention_mask = ops.splice(
-                input_ids.contiguous(), inputs_embeds.contiguous(), vis_id, all_indices, vis_embeds, visual_token_num,
-                position_ids=full_pos.contiguous(), attention_mask=None if attention_mask is None else attention_mask.contiguous(),
-                check=getattr(self, "check_token_count", True))     # ValueError on a placeholder / feature count mismatch (FT :210-213)
+                pix, grid, vis_id = pixel_values_videos.type(self.visual.dtype), video_grid_thw, self.config.video_token_id
+            check = getattr(self, "check_token_count", True)     # ValueError on a placeholder / feature count mismatch (FT :210-213)
+            am = None if attention_mask is None else attention_mask.contiguous()
+            fused, tokens = None, None
+            if getattr(self, "fuse_select_splice", True) and type(self.visual).forward is Qwen2_5_VisionTransformerPretrainedModel_Selector.forward:
+                # tower -> scores -> hard top-k -> splice with the kept rows written ONCE, from the merger's output straight into
+                # inputs_embeds' (vsel_lis_select_splice); bit-identical to visual() + vsel_splice below
+                fused, tokens = select_and_splice(self.visual, _BaseTower.forward, pix, grid, input_ids.contiguous(),
+                                                  inputs_embeds.contiguous(), vis_id, position_ids=full_pos.contiguous(),
+                                                  attention_mask=am, check=check)
+            if fused is not None:
+                selected_indices, input_ids, inputs_embeds, position_ids, attention_mask, visual_token_num = fused
+            else:
+                if tokens is not None:             # tower already ran; the LLM has another width / dtype than the tokens
+                    vis_embeds, all_indices, visual_token_num = select_block_from_tokens(self.visual, *tokens)
+                else:
+                    vis_embeds, all_indices, visual_token_num = self.visual(pix, grid_thw=grid)
+                # one fused device splice (vsel_splice) instead of where / cat / sort / index / masked_scatter (:246-262, :264-290)
+                selected_indices, input_ids, inputs_embeds, position_ids, attention_mask = ops.splice(
+                    input_ids.contiguous(), inputs_embeds.contiguous(), vis_id, all_indices, vis_embeds, visual_token_num,
+                    position_ids=full_pos.contiguous(), attention_mask=am, check=check)
             if pixel_values_videos is not None and pixel_values is None:
                 _set_text_image_mask(self.model.language_model, input_ids != vis_id)        # :295-298
             self._n_dropped = origin_input_ids.shape[1] - input_ids.shape[1]

@@ -509,6 +509,118 @@ def splice_batched(input_ids, inputs_embeds, visual_token_id: int, seq_lens: Seq
     return sel, new_ids, new_emb, new_pos, cu_out
 
 
+def _select_splice_common(h, input_ids, inputs_embeds, seq_lens, visual_lens, ks, position_ids, attention_mask, dev):
+    """Shared shape checks / output allocation of lis_select_splice and topk_select_splice."""
+    if h.dim() != 2 or inputs_embeds.dim() != 2 or input_ids.dim() != 1:
+        raise ValueError("select-splice takes h [sum N, D], input_ids [T], inputs_embeds [T, D]")
+    if input_ids.dtype != torch.int64:
+        raise TypeError("input_ids must be int64")
+    if h.dtype != inputs_embeds.dtype or h.shape[1] != inputs_embeds.shape[1]:
+        raise ValueError("fused select-splice needs tokens and embeddings of the same dtype and width "
+                         f"(got {h.dtype} x {h.shape[1]} and {inputs_embeds.dtype} x {inputs_embeds.shape[1]}); use lis_select + splice")
+    s = len(seq_lens)
+    if s == 0 or len(visual_lens) != s or len(ks) != s:
+        raise ValueError("seq_lens, visual_lens and ks must have the same non-zero length")
+    for l_s, n_s, k_s in zip(seq_lens, visual_lens, ks):
+        if not (1 <= k_s <= n_s <= l_s):
+            raise ValueError(f"need 1 <= k <= visual tokens <= length per prompt, got k={k_s}, visual={n_s}, length={l_s}")
+    t = input_ids.numel()
+    if sum(seq_lens) != t or inputs_embeds.shape[0] != t or sum(visual_lens) != h.shape[0]:
+        raise ValueError("sum(seq_lens) / embeds rows / sum(visual_lens) do not match the tensors")
+    if s == 1:
+        seg, cu_r, cu_o, cu_s = _uniform_segments(1, int(visual_lens[0]), int(ks[0])), None, None, None
+    else:
+        seg, cu_r, cu_o = _ragged_segments(visual_lens, ks, dev)
+        c = [0]
+        for x in seq_lens:
+            c.append(c[-1] + int(x))
+        cu_s = torch.tensor(c, dtype=torch.int32).to(dev, non_blocking=True)
+    n_tot, k_tot = sum(visual_lens), sum(ks)
+    l_out = t - n_tot + k_tot
+    d = h.shape[1]
+    pos, rows = None, 0
+    if position_ids is not None:
+        pos = position_ids.to(torch.int64).contiguous()
+        rows = pos.numel() // t
+    am = None if attention_mask is None else attention_mask.to(torch.int64).contiguous()
+    out = dict(idx=torch.empty(k_tot, dtype=torch.int64, device=dev), sel=torch.empty(l_out, dtype=torch.int64, device=dev),
+               new_ids=torch.empty(l_out, dtype=torch.int64, device=dev),
+               new_emb=torch.empty(l_out, d, dtype=inputs_embeds.dtype, device=dev),
+               new_pos=torch.empty(rows, l_out, dtype=torch.int64, device=dev) if pos is not None else None,
+               new_am=torch.empty(l_out, dtype=torch.int64, device=dev) if am is not None else None,
+               cu_out=torch.empty(s + 1, dtype=torch.int32, device=dev), src=torch.empty(l_out, dtype=torch.int32, device=dev),
+               stats=torch.empty(4, dtype=torch.int32, device=dev))
+    max_len_out = max(l - n + k for l, n, k in zip(seq_lens, visual_lens, ks))
+    return seg, (cu_r, cu_o), cu_s, pos, rows, am, out, l_out, max_len_out, n_tot, k_tot
+
+
+def _select_splice_finish(o, check, n_tot, l_out, k_tot, attention_mask):
+    if check:
+        found, written, kept, bad = o["stats"].tolist()
+        if bad or found != n_tot or written != l_out or kept != k_tot:
+            raise ValueError(f"Image features and image tokens do not match: tokens: {found}, features {n_tot}")
+    new_am = o["new_am"]
+    if new_am is not None and attention_mask.dtype != torch.int64:
+        new_am = new_am.to(attention_mask.dtype)
+    return new_am
+
+
+def lis_select_splice(h, wq, bq, wk, bk, input_ids, inputs_embeds, visual_token_id: int, seq_lens: Sequence[int],
+                      visual_lens: Sequence[int], ks: Sequence[int], position_ids=None, attention_mask=None, col_sums=None,
+                      logical_to_physical=None, physical_to_logical=None, check: bool = False):
+    """Scores + hard top-k + splice with the kept rows written once, from the token tensor into inputs_embeds'
+    (vsel_lis_select_splice).  h [sum N, D] = the visual tokens of S prompts back to back (prompt s: visual_lens[s] rows, ONE
+    jointly scored segment, ks[s] kept); input_ids [T] / inputs_embeds [T, D] = the prompts back to back (seq_lens);
+    position_ids [R, T] or None; attention_mask [T] or None ->
+    dict(idx [sum k] local ranks ascending, scores fp32 [sum N], selected_indices [T'], input_ids [T'], inputs_embeds [T', D],
+         position_ids [R, T'] | None, attention_mask [T'] | None, cu_seqlens int32 [S+1]).
+    Bit-identical to lis_select(_varlen / _permuted / _presummed) followed by splice(_batched)."""
+    dev = _dev(h, wq, bq, wk, bk, input_ids, inputs_embeds, position_ids, attention_mask, col_sums, logical_to_physical,
+               physical_to_logical)
+    seg, _keep, cu_s, pos, rows, am, o, l_out, max_len_out, n_tot, k_tot = _select_splice_common(
+        h, input_ids, inputs_embeds, seq_lens, visual_lens, ks, position_ids, attention_mask, dev)
+    sc = _scorer(wq, bq, wk, bk)
+    if sc.d != h.shape[1]:
+        raise ValueError(f"token width {h.shape[1]} != scorer in_features {sc.d}")
+    if (logical_to_physical is None) != (physical_to_logical is None):
+        raise ValueError("give both permutation maps or neither")
+    if col_sums is not None and (col_sums.dtype != torch.float32 or col_sums.numel() != len(seq_lens) * sc.d):
+        raise ValueError("col_sums must be float32 with one row of D sums per prompt")
+    lib = N.lib()
+    ws = _workspace(lib.vsel_lis_workspace_bytes(C.byref(seg), sc.d, sc.hd), dev)
+    scores = torch.empty(n_tot, dtype=torch.float32, device=dev)
+    hc, emb = h.contiguous(), inputs_embeds.contiguous()
+    N.check(lib.vsel_lis_select_splice(
+        _stream(), hc.data_ptr(), _code(hc), C.byref(seg), C.byref(sc), ws.data_ptr(), ws.numel(), _p(col_sums),
+        _p(logical_to_physical), _p(physical_to_logical), input_ids.data_ptr(), input_ids.numel(), _p(cu_s), max_len_out,
+        int(visual_token_id), emb.data_ptr(), _p(pos), rows, _p(am), o["idx"].data_ptr(), scores.data_ptr(), o["sel"].data_ptr(),
+        o["new_ids"].data_ptr(), o["new_emb"].data_ptr(), _p(o["new_pos"]), _p(o["new_am"]), o["cu_out"].data_ptr(),
+        o["src"].data_ptr(), o["stats"].data_ptr()))
+    new_am = _select_splice_finish(o, check, n_tot, l_out, k_tot, attention_mask)
+    return dict(idx=o["idx"], scores=scores, selected_indices=o["sel"], input_ids=o["new_ids"], inputs_embeds=o["new_emb"],
+                position_ids=o["new_pos"], attention_mask=new_am, cu_seqlens=o["cu_out"])
+
+
+def topk_select_splice(scores, h, input_ids, inputs_embeds, visual_token_id: int, seq_lens: Sequence[int],
+                       visual_lens: Sequence[int], ks: Sequence[int], position_ids=None, attention_mask=None,
+                       logical_to_physical=None, check: bool = False):
+    """The same on given fp32 scores [sum N] (vsel_topk_select_splice): hard top-k + splice, kept rows read from h."""
+    dev = _dev(scores, h, input_ids, inputs_embeds, position_ids, attention_mask, logical_to_physical)
+    if scores.dtype != torch.float32 or scores.numel() != h.shape[0]:
+        raise TypeError("scores must be float32 with one entry per token row")
+    seg, _keep, cu_s, pos, rows, am, o, l_out, max_len_out, n_tot, k_tot = _select_splice_common(
+        h, input_ids, inputs_embeds, seq_lens, visual_lens, ks, position_ids, attention_mask, dev)
+    hc, emb, scc = h.contiguous(), inputs_embeds.contiguous(), scores.contiguous()
+    N.check(N.lib().vsel_topk_select_splice(
+        _stream(), hc.data_ptr(), _code(hc), h.shape[1], C.byref(seg), scc.data_ptr(), _p(logical_to_physical),
+        input_ids.data_ptr(), input_ids.numel(), _p(cu_s), max_len_out, int(visual_token_id), emb.data_ptr(), _p(pos), rows,
+        _p(am), o["idx"].data_ptr(), o["sel"].data_ptr(), o["new_ids"].data_ptr(), o["new_emb"].data_ptr(), _p(o["new_pos"]),
+        _p(o["new_am"]), o["cu_out"].data_ptr(), o["src"].data_ptr(), o["stats"].data_ptr()))
+    new_am = _select_splice_finish(o, check, n_tot, l_out, k_tot, attention_mask)
+    return dict(idx=o["idx"], selected_indices=o["sel"], input_ids=o["new_ids"], inputs_embeds=o["new_emb"],
+                position_ids=o["new_pos"], attention_mask=new_am, cu_seqlens=o["cu_out"])
+
+
 # ------------------------------------------------------------------------------------------------
 # var-len attention
 # ------------------------------------------------------------------------------------------------
@@ -662,7 +774,7 @@ def paged_attn(q, k_cache, v_cache, cu_seqlens_q: torch.Tensor, seqlens_k: torch
 # every op that reaches libvsel switches to its tensors' device first
 for _name in ("lis_scores", "lis_select", "lis_select_permuted", "gelu_colsum", "lis_select_presummed", "lis_select_varlen",
               "hard_topk", "gather_rows", "soft_topk_fwd", "soft_topk_bwd", "lis_train_fwd", "lis_train_bwd", "lis_train_bwd_factors", "factors_to_grads", "lis_scores_bwd",
-              "splice", "splice_batched", "varlen_attn", "varlen_attn_fwd_lse", "varlen_attn_bwd", "varlen_attn_kv",
+              "splice", "splice_batched", "lis_select_splice", "topk_select_splice", "varlen_attn", "varlen_attn_fwd_lse", "varlen_attn_bwd", "varlen_attn_kv",
               "attn_head_major", "paged_attn"):
     globals()[_name] = _device_guard(globals()[_name])
 del _name

@@ -55,11 +55,7 @@ def packed_prefill(model, input_ids: Sequence[torch.Tensor], pixel_values: torch
 
     # 1. encoder + merger over all images (transformers' own forward; natural token order)
     h = hf.Qwen2_5_VisionTransformerPretrainedModel.forward(visual, pixel_values.type(visual.dtype), image_grid_thw).pooler_output
-    # 2. ragged LIS: one segment per prompt that has images
-    has = [b for b, n in enumerate(visual_lens) if n > 0]
-    params = [p.detach().contiguous() for p in visual.importance_scorer.params()]
-    out, idx, _ = ops.lis_select_varlen(h.contiguous(), [visual_lens[b] for b in has], [ks[b] for b in has], *params)
-    # 3. M-RoPE positions of every prompt from its ORIGINAL ids (EV :311-317), packed
+    # 2. M-RoPE positions of every prompt from its ORIGINAL ids (EV :311-317), packed
     pos = []
     for b, t in enumerate(ids_list):
         mm = torch.zeros_like(t, dtype=torch.int32)
@@ -68,10 +64,20 @@ def packed_prefill(model, input_ids: Sequence[torch.Tensor], pixel_values: torch
                                           attention_mask=torch.ones_like(t)[None])
         pos.append(p[:, 0, :])
     pos = torch.cat(pos, dim=1).contiguous()                                 # [3, T]
-    # 4. text embeddings + packed splice
     emb = model.get_input_embeddings()(ids)
-    sel, new_ids, new_emb, new_pos, cu = ops.splice_batched(ids, emb.contiguous(), cfg.image_token_id, seq_lens, visual_lens, ks,
-                                                            idx, out.to(emb.dtype), position_ids=pos)
+    params = [p.detach().contiguous() for p in visual.importance_scorer.params()]
+    if all(n > 0 for n in visual_lens) and h.dtype == emb.dtype and h.shape[1] == emb.shape[1] and getattr(model, "fuse_select_splice", True):
+        # 3. ragged LIS (one jointly scored segment per prompt) + packed splice in ONE call: the kept rows go straight from the
+        #    merger's output into the packed inputs_embeds' (vsel_lis_select_splice) -- no [sum k, D] tensor in between
+        o = ops.lis_select_splice(h.contiguous(), *params, ids, emb.contiguous(), cfg.image_token_id, seq_lens, visual_lens, ks,
+                                  position_ids=pos)
+        new_ids, new_emb, new_pos, cu = o["input_ids"], o["inputs_embeds"], o["position_ids"], o["cu_seqlens"]
+    else:
+        # 3. ragged LIS: one segment per prompt that has images; 4. packed splice (prompts without images pass through)
+        has = [b for b, n in enumerate(visual_lens) if n > 0]
+        out, idx, _ = ops.lis_select_varlen(h.contiguous(), [visual_lens[b] for b in has], [ks[b] for b in has], *params)
+        _, new_ids, new_emb, new_pos, cu = ops.splice_batched(ids, emb.contiguous(), cfg.image_token_id, seq_lens, visual_lens, ks,
+                                                              idx, out.to(emb.dtype), position_ids=pos)
     # 5. the LLM over the packed compressed sequence (var-len attention over cu)
     max_len = max(l - n + k for l, n, k in zip(seq_lens, visual_lens, ks))
     hidden = lm(inputs_embeds=new_emb[None], position_ids=new_pos[:, None, :], use_cache=False, cu_seq_lens_q=cu, cu_seq_lens_k=cu,

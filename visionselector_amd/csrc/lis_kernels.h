@@ -655,7 +655,10 @@ __global__ __launch_bounds__(1024) void topk_select_reg_kernel(const float* __re
 // =================================================================================================
 // K6  row gather out[ob + j] = h[rb + idx[ob + j]].  grid (row_chunks, n_seg), block 256, wave per row.
 // =================================================================================================
-template <typename T, bool NT>
+// ITERS > 0: D == ITERS * 64 * kVec (2048 / 3584 / 4096 in bf16: 4 / 7 / 8) -- compile-time trip count, the whole row (ITERS x
+// 16 B per lane) is loaded before the first store and the NEXT row's index is fetched under the current row's copy.
+// ITERS == 0: any D (run-time trip count).
+template <typename T, bool NT, int ITERS = 0>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ h, SegView sv, int d,
                                                           const int64_t* __restrict__ idx, T* __restrict__ out,
                                                           int rows_per_block, const int64_t* __restrict__ src_map) {
@@ -667,14 +670,40 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
   if (jb >= ko) return;
   const int je = min(ko, jb + rows_per_block);
   const int64_t ob = sv.out_begin(s), rb = sv.row_begin(s);
-  for (int j = jb + wave; j < je; j += 4) {
-    const int64_t lsrc = rb + idx[ob + j];
-    const int64_t src = src_map ? src_map[lsrc] : lsrc;
-    const u32x4* sp = reinterpret_cast<const u32x4*>(h + src * d);
-    u32x4* dp = reinterpret_cast<u32x4*>(out + (ob + j) * d);
-    for (int v = lane; v < d / V; v += 64) {
-      if constexpr (NT) __builtin_nontemporal_store(sp[v], dp + v);      // keeps the write-back from slowing the next sweep 1
-      else dp[v] = sp[v];
+  if constexpr (ITERS > 0) {
+    int j = jb + wave;
+    if (j >= je) return;
+    int64_t lsrc = rb + idx[ob + j];
+    int64_t src = src_map ? src_map[lsrc] : lsrc;
+    for (; j < je; j += 4) {
+      const u32x4* sp = reinterpret_cast<const u32x4*>(h + src * d) + lane;
+      u32x4 x[ITERS];
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) {
+        if constexpr (NT) x[i] = __builtin_nontemporal_load(sp + 64 * i);     // read once: do not displace the next sweep's lines
+        else x[i] = sp[64 * i];
+      }
+      if (j + 4 < je) {                                                        // next row's source under this row's copy
+        lsrc = rb + idx[ob + j + 4];
+        src = src_map ? src_map[lsrc] : lsrc;
+      }
+      u32x4* dp = reinterpret_cast<u32x4*>(out + (ob + j) * d) + lane;
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) {
+        if constexpr (NT) __builtin_nontemporal_store(x[i], dp + 64 * i);      // keeps the write-back from slowing the next sweep 1
+        else dp[64 * i] = x[i];
+      }
+    }
+  } else {
+    for (int j = jb + wave; j < je; j += 4) {
+      const int64_t lsrc = rb + idx[ob + j];
+      const int64_t src = src_map ? src_map[lsrc] : lsrc;
+      const u32x4* sp = reinterpret_cast<const u32x4*>(h + src * d);
+      u32x4* dp = reinterpret_cast<u32x4*>(out + (ob + j) * d);
+      for (int v = lane; v < d / V; v += 64) {
+        if constexpr (NT) __builtin_nontemporal_store(sp[v], dp + v);
+        else dp[v] = sp[v];
+      }
     }
   }
 }
@@ -918,10 +947,22 @@ inline int launch_gather(hipStream_t st, const T* h, int d, const vsel_segments*
   int64_t rpb = 32;
   while (rpb > 4 && seg->n_seg * cdiv(seg->k, rpb) < 2048) rpb >>= 1;
   const dim3 grid((unsigned)cdiv(seg->k, rpb), (unsigned)seg->n_seg);
-  if (stream_policy(seg->total_rows, d, sizeof(T)))
-    hipLaunchKernelGGL((gather_rows_kernel<T, true>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map);
-  else
-    hipLaunchKernelGGL((gather_rows_kernel<T, false>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map);
+  const bool nt = stream_policy(seg->total_rows, d, sizeof(T));
+  constexpr int V = Elem<T>::kVec;
+  const int iters = ( d % (64 * V) == 0 && d / (64 * V) <= 8) ? d / (64 * V) : 0;
+#define VSEL_GATHER_CASE(I)                                                                                                   \
+  case I:                                                                                                                     \
+    if (nt) hipLaunchKernelGGL((gather_rows_kernel<T, true, I>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map); \
+    else hipLaunchKernelGGL((gather_rows_kernel<T, false, I>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map);   \
+    break;
+  switch (iters) {
+    VSEL_GATHER_CASE(1) VSEL_GATHER_CASE(2) VSEL_GATHER_CASE(3) VSEL_GATHER_CASE(4)
+    VSEL_GATHER_CASE(5) VSEL_GATHER_CASE(6) VSEL_GATHER_CASE(7) VSEL_GATHER_CASE(8)
+    default:
+      if (nt) hipLaunchKernelGGL((gather_rows_kernel<T, true, 0>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map);
+      else hipLaunchKernelGGL((gather_rows_kernel<T, false, 0>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map);
+  }
+#undef VSEL_GATHER_CASE
   VSEL_AFTER_LAUNCH(st, "gather_rows_kernel");
   return VSEL_OK;
 }

@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--no-attn", action="store_true")
     ap.add_argument("--no-llm", action="store_true", help="skip the whole-LLM prefill leg (7B random-init weights)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (config C3: fwd + bwd + grad all-reduce)")
+    ap.add_argument("--no-single-sweep", action="store_true", help="skip the producer-side column-sum leg (SURVEY 8f N2)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -287,6 +288,12 @@ def main():
 
     if train is not None:
         res["train_step"] = train
+    # ---- single-sweep LIS: column sums from the merger's GELU, sum production timed inside ----------
+    if not args.no_single_sweep:
+        try:
+            res["single_sweep"] = bench_single_sweep(ops, h, wq, bq, wk, bk, k, idx, path_bytes)
+        except Exception as e:  # optional leg: never lose the headline line over it
+            res["single_sweep"] = {"error": str(e)[:300]}
     # ---- prefill attention at the compressed vs the full length (second half of the metric) ----------
     if not args.no_attn:
         try:
@@ -305,6 +312,58 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_single_sweep(ops, h, wq, bq, wk, bk, k, idx_two_sweep, path_bytes, iters=10):
+    """SURVEY.md section 8f N2 on the headline workload: the merger hands the LIS the column sums of its tokens, so the first
+    of the two HBM sweeps is gone.  Sum production is TIMED INSIDE: vsel_gelu_colsum replaces the merger's GELU on the
+    [B N, 5120] hidden activation (Qwen2_5_VLPatchMerger, EV/qwen25vl/modeling_qwen2_5_vl.py:148-161) and
+    vsel_colsum_linear carries the sums through the merger's last Linear; what the LIS is charged is
+        (gelu_colsum + colsum_linear + lis_select_presummed)  -  (the GELU the merger runs anyway, torch's kernel).
+    Parity of the leg: with the tokens' true column sums the selection equals the two-sweep path's."""
+    b, n, d = h.shape
+    cmid = 5120                                                  # merger hidden width at 7B: 4 x 1280
+    gen = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.randn(b * n, cmid, device="cuda", generator=gen).bfloat16()
+    w2 = (0.02 * torch.randn(d, cmid, device="cuda", generator=gen)).bfloat16()
+    b2 = (0.02 * torch.randn(d, device="cuda", generator=gen)).bfloat16()
+
+    def ev_time(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3
+
+    _, gsum = ops.gelu_colsum(x, b)
+    cs = ops.colsum_linear(gsum, w2, b2, n)
+
+    def chain():
+        _, g_ = ops.gelu_colsum(x, b)
+        c_ = ops.colsum_linear(g_, w2, b2, n)
+        return ops.lis_select_presummed(h, c_, wq, bq, wk, bk, k)
+
+    t_gelu = ev_time(lambda: torch.nn.functional.gelu(x))
+    t_gelu_cs = ev_time(lambda: ops.gelu_colsum(x, b))
+    t_lin = ev_time(lambda: ops.colsum_linear(gsum, w2, b2, n))
+    t_pre = ev_time(lambda: ops.lis_select_presummed(h, cs, wq, bq, wk, bk, k))
+    t_chain = ev_time(chain)
+    true_sums = h.float().sum(1).contiguous()
+    _, idx1, _ = ops.lis_select_presummed(h, true_sums, wq, bq, wk, bk, k)
+    step_us = t_chain - t_gelu
+    del x
+    return {"what": "vsel_gelu_colsum (in place of the merger's GELU) + vsel_colsum_linear + vsel_lis_select_presummed; "
+                    "step_us = that chain minus torch's GELU on the same activation",
+            "torch_gelu_us": t_gelu, "gelu_colsum_us": t_gelu_cs, "colsum_linear_us": t_lin, "lis_select_presummed_us": t_pre,
+            "chain_us": t_chain, "step_us": step_us, "tokens_per_s": b * n / (step_us * 1e-6),
+            "roofline_path": {"algorithmic_bytes_per_step": path_bytes, "achieved_GBps": path_bytes / (step_us * 1e-6) / 1e9,
+                              "frac_of_8TBps": path_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
+            "idx_equal_two_sweep_with_true_sums": bool(torch.equal(idx1, idx_two_sweep))}
 
 
 def bench_train_step(ops, dist, world, rank, iters=20):

@@ -204,6 +204,15 @@ int vsel_splice(void* stream, const int64_t* input_ids, int64_t seq_len, int64_t
 size_t vsel_gelu_colsum_workspace_bytes(const vsel_segments* seg, int64_t cols);
 int vsel_gelu_colsum(void* stream, const void* x, vsel_dtype dtype, const vsel_segments* seg, int64_t cols, void* y,
                      float* col_sums, void* workspace, size_t workspace_bytes);
+/* sum_rows(H) from sum_rows(G) through the merger's last Linear H = G W^T + b (Qwen2_5_VLPatchMerger.mlp[2],
+ * EV/qwen25vl/modeling_qwen2_5_vl.py:148-161), on the STORED weight:  out[s][j] = sum_i in[s][i] W[j][i] + N_s b[j].
+ *   col_sums_in fp32 [n_seg, cin] (vsel_gelu_colsum's output); weight [cout, cin] row-major, bias [cout] or NULL, both `wdtype`;
+ *   N_s from `seg`; col_sums_out fp32 [n_seg, cout] = what vsel_lis_select_presummed / vsel_lis_select_splice take.
+ * fp32 accumulation (bf16x3-exact MFMA operands beyond 8 segments); deterministic.                                  */
+size_t vsel_colsum_linear_workspace_bytes(int64_t n_seg, int64_t cin, int64_t cout);
+int vsel_colsum_linear(void* stream, const float* col_sums_in, const vsel_segments* seg, const void* weight, const void* bias,
+                       vsel_dtype wdtype, int64_t cin, int64_t cout, float* col_sums_out, void* workspace,
+                       size_t workspace_bytes);
 int vsel_lis_select_presummed(void* stream, const void* h, vsel_dtype hdtype, const vsel_segments* seg,
                               const vsel_scorer* scorer, const float* col_sums, void* workspace, size_t workspace_bytes,
                               const int64_t* logical_to_physical, const int64_t* physical_to_logical, void* out,

@@ -435,7 +435,7 @@ def test_merger_colsum_fusion_is_transparent(selector_model):
             o = m(**inp)
         prof = N.profile_stop()
         outs.append((o.logits.clone(), m.visual.last_selected_indices.clone(), m.visual.last_combined_scores.clone(), prof))
-    m.visual.fuse_merger_colsum = None            # back to automatic (on from 65 536 tokens per call)
+    m.visual.fuse_merger_colsum = None            # back to automatic (on from 24 576 tokens per call)
     assert "gelu_colsum_kernel" in outs[0][3] and "colsum_partial_kernel" not in outs[0][3], outs[0][3].keys()
     assert "gelu_colsum_kernel" not in outs[1][3] and "colsum_partial_kernel" in outs[1][3]
     assert torch.equal(outs[0][1], outs[1][1])

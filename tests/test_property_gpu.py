@@ -161,6 +161,28 @@ def test_presummed_select_matches_reference_goldens(golden_dir, name, storage):
         assert np.array_equal(idx.cpu().numpy(), want) and torch.equal(out, h[idx])
 
 
+@pytest.mark.parametrize("s,cin,cout,dt", [(1, 5120, 3584, torch.bfloat16), (3, 5120, 3584, torch.bfloat16), (8, 1280, 2048, torch.bfloat16),
+                                           (9, 5120, 3584, torch.bfloat16), (128, 5120, 3584, torch.bfloat16), (40, 512, 96, torch.bfloat16),
+                                           (2, 520, 77, torch.float32), (11, 64, 40, torch.float32)])
+def test_colsum_linear_matches_fp64(s, cin, cout, dt):
+    """vsel_colsum_linear (sum_rows(G) -> sum_rows(H) through the merger's last Linear, stored weight, fp32 accumulate) against
+    fp64: both forms (wave per output row up to 8 segments, bf16x3 MFMA beyond), bias scaled by the row count; deterministic."""
+    from visionselector_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(s * 7 + cin)
+    n = 2304
+    gs = (torch.randn(s, cin, device="cuda", generator=g) * 40 + 300).float()          # column sums of a GELU output: large, positive-ish
+    w = (0.02 * torch.randn(cout, cin, device="cuda", generator=g)).to(dt)
+    b = (0.1 * torch.randn(cout, device="cuda", generator=g)).to(dt)
+    out = ops.colsum_linear(gs, w, b, n)
+    ref = gs.double() @ w.double().t() + n * b.double()
+    # TOLERANCE: fp32 accumulation of Cin products: 2e-6 of sum |in . w| + |N b|
+    scale = gs.double().abs() @ w.double().abs().t() + n * b.double().abs()
+    assert float(((out.double() - ref).abs() / scale).max()) <= 2e-6
+    assert torch.equal(out, ops.colsum_linear(gs, w, b, n))
+    out0 = ops.colsum_linear(gs, w, None, n)
+    assert float(((out0.double() - gs.double() @ w.double().t()).abs() / scale).max()) <= 2e-6
+
+
 @pytest.mark.parametrize("n,seed", [(2304, 5), (576, 6)])
 def test_merger_colsum_path_matches_oracle(n, seed):
     """The whole N2 chain -- vsel_gelu_colsum in the merger, sum_rows(H) by linearity of the merger's last Linear

@@ -33,7 +33,7 @@ def timeit(fn, iters=30):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-for n in (2304, 4 * 2304, 16 * 2304, 64 * 2304):
+for n in (2304, 4 * 2304, 8 * 2304, 16 * 2304, 64 * 2304):
     k = int(n * 0.2)
     x = torch.randn(n, c, device="cuda", generator=g).bfloat16()          # output of the merger's first Linear
     h = torch.randn(n, d, device="cuda", generator=g).bfloat16()          # output of its second Linear (window order)
@@ -47,11 +47,13 @@ for n in (2304, 4 * 2304, 16 * 2304, 64 * 2304):
 
     def one_sweep():
         _, sums = ops.gelu_colsum(x, 1)
-        cs = torch.addmm(b2.float() * n, sums, w2f_t)
+        cs = ops.colsum_linear(sums, w2, b2, n)
         return ops.lis_select_presummed(h, cs, wq, bq, wk, bk, k, logical_to_physical=perm, physical_to_logical=p2l)
 
     res = {"n_tokens": n, "torch_gelu_us": timeit(lambda: torch.nn.functional.gelu(x)),
            "gelu_colsum_us": timeit(lambda: ops.gelu_colsum(x, 1)),
+           "colsum_linear_us": timeit(lambda: ops.colsum_linear(ops.gelu_colsum(x, 1)[1], w2, b2, n)) - timeit(lambda: ops.gelu_colsum(x, 1)),
+           "torch_addmm_fp32_us": timeit(lambda: torch.addmm(b2.float() * n, torch.zeros(1, c, device="cuda"), w2.float().t())),
            "lis_two_sweep_us": timeit(lambda: ops.lis_select_permuted(h, perm, p2l, wq, bq, wk, bk, k)),
            "gelu+lis_two_sweep_us": timeit(two_sweep), "gelu+lis_one_sweep_us": timeit(one_sweep)}
     res["saving"] = 1 - res["gelu+lis_one_sweep_us"] / res["gelu+lis_two_sweep_us"]

@@ -51,6 +51,8 @@ SIGNATURES = {
     "vsel_lis_scores_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _SC, _P, _SZ, _P, _P, _P, _P, _P]),
     "vsel_gelu_colsum_workspace_bytes": (_SZ, [_SEG, _I64]),
     "vsel_gelu_colsum": (C.c_int, [_P, _P, C.c_int, _SEG, _I64, _P, _P, _P, _SZ]),
+    "vsel_colsum_linear_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
+    "vsel_colsum_linear": (C.c_int, [_P, _P, _SEG, _P, _P, C.c_int, _I64, _I64, _P, _P, _SZ]),
     "vsel_lis_select_presummed": (C.c_int, [_P, _P, C.c_int, _SEG, _SC, _P, _P, _SZ, _P, _P, _P, _P, _P]),
     "vsel_splice": (C.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, C.c_int, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vsel_splice_batched": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, C.c_int, _I64, _P, _I64,

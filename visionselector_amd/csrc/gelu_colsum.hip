@@ -6,7 +6,7 @@
 // (its first HBM sweep over H).  The last Linear is linear:  sum_rows(H) = sum_rows(G) W2^T + N b2  with G = GELU(...).
 // This kernel replaces the GELU launch: it writes G exactly as nn.GELU() would (erf form, fp32 math, rounded to the
 // activation dtype) and accumulates the column sums of the ROUNDED G on the way -- no extra HBM traffic -- so that
-// vsel_lis_select_presummed can skip sweep 1.  Deterministic: fixed 128-row chunks, then a fixed-order finish.
+// vsel_lis_select_presummed can skip sweep 1.  Deterministic: fixed row chunks per workgroup, then a fixed-order finish.
 #include "common.h"
 #include "lis_kernels.h"
 
@@ -17,7 +17,9 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // Rows per workgroup: 128 when that already gives several rounds of workgroups, halved (down to 16) otherwise -- a 128-row
 // workgroup runs ~100 us of erf, so at 36 k rows (2880 workgroups on 2048 slots) the tail round cost 15-30 % (207 vs 159 us for
 // torch's GELU).  The column sums are a fixed function of (rows per segment, columns), not bit-identical across batch shapes; the
-// bit-exact path is the two-sweep one.
+// bit-exact path is the two-sweep one.  (Round 3 also tried ONE running sum per workgroup over statically strided 16-row chunks
+// -- a bounded number of partials whatever the row count: same time at 18 k tokens, 8 % slower at 147 k and 295 k (1458 vs
+// 1355 us): the partial traffic was never the cost, and contiguous rows per workgroup stream better.  Not kept.)
 constexpr int kGeluRowsMax = 128;
 inline int gelu_rows_per_wg(const vsel_segments* seg, int64_t cols, int vec) {
   int rows = kGeluRowsMax;
@@ -25,10 +27,17 @@ inline int gelu_rows_per_wg(const vsel_segments* seg, int64_t cols, int vec) {
   return rows;
 }
 
-template <typename T>
+// NT: the activation is far larger than the caches and both x and y are touched once here -> non-temporal loads and stores
+// (chosen from 384 MB of activation up, as the LIS sweeps do): 1355 vs 1402 us (torch) at 294 912 x 5120, before 1.07x torch's.
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void gelu_colsum_kernel(const T* __restrict__ x, SegView sv, int c, int row_splits, int rows_per_wg,
                                                           T* __restrict__ y, float* __restrict__ partial) {
   constexpr int V = Elem<T>::kVec;
+  typedef typename std::conditional<sizeof(T) == 2, u32x4, f32x4>::type raw_t;
+  auto ld = [](const T* p) -> raw_t {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(p));
+    else return *reinterpret_cast<const raw_t*>(p);
+  };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = blockIdx.z, rs = blockIdx.y;
   const int col = (blockIdx.x * 64 + lane) * V;
@@ -42,32 +51,43 @@ __global__ __launch_bounds__(256) void gelu_colsum_kernel(const T* __restrict__ 
   if (col < c) {
     const int64_t base = r0 * (int64_t)c + col;
     int r = rb + wave;
-    // software-pipelined: the next two rows' loads are in flight while this row's erf runs (the erf body is emitted once)
-    float cur[V], nx1[V], nx2[V];
-    if (r < re) load_vec(x + base + (int64_t)r * c, cur);
-    if (r + 4 < re) load_vec(x + base + (int64_t)(r + 4) * c, nx1);
+    // software-pipelined on the RAW 16-byte vectors (unpacked only when consumed, so no wait is forced at the load): the next
+    // two rows are in flight while this row's erf runs
+    raw_t cur, nx1, nx2;
+    if (r < re) cur = ld(x + base + (int64_t)r * c);
+    if (r + 4 < re) nx1 = ld(x + base + (int64_t)(r + 4) * c);
     for (; r < re; r += 4) {
-      if (r + 8 < re) load_vec(x + base + (int64_t)(r + 8) * c, nx2);
+      if (r + 8 < re) nx2 = ld(x + base + (int64_t)(r + 8) * c);
+      float v[V];
+      if constexpr (sizeof(T) == 2) {
+        unpack_vec<T>(cur, v);
+      } else {
 #pragma unroll
-      for (int i = 0; i < V; ++i) cur[i] = gelu_erf(cur[i]);
+        for (int i = 0; i < V; ++i) v[i] = cur[i];
+      }
+#pragma unroll
+      for (int i = 0; i < V; ++i) v[i] = gelu_erf(v[i]);
       if constexpr (sizeof(T) == 2) {
         // round once: the stored bf16 bits are also what the column sums add up
         uint32_t bits[V];
 #pragma unroll
-        for (int i = 0; i < V; ++i) bits[i] = f32_to_bf16_bits(cur[i]);
+        for (int i = 0; i < V; ++i) bits[i] = f32_to_bf16_bits(v[i]);
         u32x4 pk;
 #pragma unroll
         for (int i = 0; i < 4; ++i) pk[i] = bits[2 * i] | (bits[2 * i + 1] << 16);
-        *reinterpret_cast<u32x4*>(y + base + (int64_t)r * c) = pk;
+        if constexpr (NT) __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(y + base + (int64_t)r * c));
+        else *reinterpret_cast<u32x4*>(y + base + (int64_t)r * c) = pk;
 #pragma unroll
         for (int i = 0; i < V; ++i) acc[i] += __uint_as_float(bits[i] << 16);
       } else {
-        store_vec(y + base + (int64_t)r * c, cur);
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(y + base + (int64_t)r * c));
+        else *reinterpret_cast<f32x4*>(y + base + (int64_t)r * c) = o;
 #pragma unroll
-        for (int i = 0; i < V; ++i) acc[i] += cur[i];
+        for (int i = 0; i < V; ++i) acc[i] += v[i];
       }
-#pragma unroll
-      for (int i = 0; i < V; ++i) { cur[i] = nx1[i]; nx1[i] = nx2[i]; }
+      cur = nx1;
+      nx1 = nx2;
     }
   }
   __shared__ float red[4][64][V + 1];
@@ -113,6 +133,90 @@ static __global__ __launch_bounds__(1024) void gelu_colsum_finish_kernel(const f
   }
 }
 
+
+// -------------------------------------------------------------------------------------------------------------------------
+// sum_rows(H) from sum_rows(G) for H = G W^T + b (the merger's last Linear; W [Cout, Cin] row-major as stored, bias [Cout]):
+//   out[s][j] = sum_i in[s][i] W[j][i] + N_s b[j]
+// on the STORED (bf16) weight with fp32 accumulation -- torch's route was weight.float().t() (a 73 MB fp32 copy per call at 7B)
+// + an fp32 addmm.  Few segments: one wave per output row, the weight row (Cin x 2 B, contiguous) read once with every load of
+// a batch in flight, fp32 FMA against the <= kLinSmallSeg input rows, fixed-order lane reduction.  Many segments: the scorer's
+// own bf16x3 MFMA projection (proj_bf16x3.h: planes of in / N_s, gemm_nt, slabs) and a finish that adds the bias and scales
+// back by N_s.  Deterministic either way.
+// -------------------------------------------------------------------------------------------------------------------------
+constexpr int kLinSmallSeg = 8;
+
+template <typename TW>
+__global__ __launch_bounds__(256) void colsum_linear_small_kernel(const float* __restrict__ in, const TW* __restrict__ w,
+                                                                  const TW* __restrict__ bias, SegView sv, int S, int cin, int cout,
+                                                                  float* __restrict__ out) {
+  constexpr int V = Elem<TW>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= cout) return;
+  const TW* wr = w + (int64_t)j * cin;
+  float acc[kLinSmallSeg];
+#pragma unroll
+  for (int s = 0; s < kLinSmallSeg; ++s) acc[s] = 0.f;
+  constexpr int U = 5;                                   // weight vectors in flight per lane (5120 / (64 x 8) = 10 = 2 batches)
+  for (int c0 = lane * V; c0 < cin; c0 += 64 * V * U) {
+    float wv[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_vec(wr + min(c0 + 64 * V * u, cin - V), wv[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 64 * V * u;
+      if (c < cin) {
+#pragma unroll
+        for (int s = 0; s < kLinSmallSeg; ++s) {
+          if (s < S) {
+            const float* g = in + (int64_t)s * cin + c;
+#pragma unroll
+            for (int q = 0; q < V; q += 4) {
+              const f32x4 gv = *reinterpret_cast<const f32x4*>(g + q);
+              acc[s] = fmaf(wv[u][q], gv[0], acc[s]);
+              acc[s] = fmaf(wv[u][q + 1], gv[1], acc[s]);
+              acc[s] = fmaf(wv[u][q + 2], gv[2], acc[s]);
+              acc[s] = fmaf(wv[u][q + 3], gv[3], acc[s]);
+            }
+          }
+        }
+      }
+    }
+  }
+  const float b = bias ? load_elem(bias + j) : 0.f;
+#pragma unroll
+  for (int s = 0; s < kLinSmallSeg; ++s) {
+    if (s < S) {
+      const float t = wave_sum(acc[s]);
+      if (lane == 0) out[(int64_t)s * cout + j] = t + (float)sv.n_rows(s) * b;
+    }
+  }
+}
+
+// out[m][n] = (sum_ks part[ks][n][m] + b[n]) N_m   (the planes held in / N_m).  grid (ceil(m_pad/32), ceil(N/8)), block 256.
+static __global__ __launch_bounds__(256) void colsum_linear_finish_kernel(const float* __restrict__ part, int KS, int M, int N, int m_pad,
+                                                                          const uint16_t* __restrict__ bias, SegView sv,
+                                                                          float* __restrict__ out) {
+  const int m = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int n = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (m < M && n < N) {
+    const float v = strided_sum(part + (int64_t)n * m_pad + m, KS, (int64_t)N * m_pad) + (bias ? bf16_to_f32(bias[n]) : 0.f);
+    out[(int64_t)m * N + n] = v * (float)sv.n_rows(m);
+  }
+}
+
+struct LinPlan { int ks, kslice, m_pad; size_t off_planes, off_slabs, total; };
+static LinPlan lin_plan(int64_t S, int64_t cin, int64_t cout) {
+  LinPlan p{};
+  p.kslice = (int)std::min<int64_t>(kSliceNT, cdiv(cin, 16) * 16);
+  p.ks = (int)cdiv(cin, p.kslice);
+  p.m_pad = 32 * (int)cdiv(S, 32);
+  p.off_planes = 0;
+  p.off_slabs = align_up((size_t)3 * p.m_pad * cin * sizeof(uint16_t), 256);
+  p.total = p.off_slabs + align_up((size_t)p.ks * cout * p.m_pad * sizeof(float), 256);
+  return p;
+}
+
 }  // namespace vsel
 
 using namespace vsel;
@@ -122,8 +226,7 @@ extern "C" size_t vsel_gelu_colsum_workspace_bytes(const vsel_segments* seg, int
   // the partials of the chunking the launch will use: rows per workgroup depend on the vector width (dtype), which this query
   // does not take, so the larger of the two (bf16: 8 elements per lane, fp32: 4) -- not the 16-row worst case, which was 8x too
   // large exactly where the fusion is on (147 456 x 5120: 23.6 MB instead of 188 MB)
-  const int rows = gelu_rows_per_wg(seg, cols, 8) < gelu_rows_per_wg(seg, cols, 4) ? gelu_rows_per_wg(seg, cols, 8)
-                                                                                  : gelu_rows_per_wg(seg, cols, 4);
+  const int rows = std::min(gelu_rows_per_wg(seg, cols, 8), gelu_rows_per_wg(seg, cols, 4));
   return (size_t)seg->n_seg * (size_t)cdiv(seg->rows_per_seg, rows) * (size_t)cols * sizeof(float);
 }
 
@@ -144,15 +247,75 @@ extern "C" int vsel_gelu_colsum(void* stream, const void* x, vsel_dtype dtype, c
   const int rows_per_wg = gelu_rows_per_wg(seg, cols, vec);
   const int row_splits = (int)cdiv(seg->rows_per_seg, rows_per_wg);
   float* partial = (float*)workspace;
-  if (dtype == VSEL_BF16)
-    hipLaunchKernelGGL((gelu_colsum_kernel<bf16_t>), dim3((unsigned)cdiv(cols, 64 * 8), row_splits, S), dim3(256), 0, st,
-                       (const bf16_t*)x, sv, (int)cols, row_splits, rows_per_wg, (bf16_t*)y, partial);
-  else
-    hipLaunchKernelGGL((gelu_colsum_kernel<float>), dim3((unsigned)cdiv(cols, 64 * 4), row_splits, S), dim3(256), 0, st,
-                       (const float*)x, sv, (int)cols, row_splits, rows_per_wg, (float*)y, partial);
+  const bool nt = seg->total_rows * cols * (dtype == VSEL_BF16 ? 2 : 4) >= kStreamBytes;   // (from 16 / 64 MB up: no difference)
+  const dim3 grid((unsigned)cdiv(cols, 64 * vec), row_splits, S);
+  if (dtype == VSEL_BF16) {
+    if (nt) hipLaunchKernelGGL((gelu_colsum_kernel<bf16_t, true>), grid, dim3(256), 0, st, (const bf16_t*)x, sv, (int)cols, row_splits, rows_per_wg, (bf16_t*)y, partial);
+    else hipLaunchKernelGGL((gelu_colsum_kernel<bf16_t, false>), grid, dim3(256), 0, st, (const bf16_t*)x, sv, (int)cols, row_splits, rows_per_wg, (bf16_t*)y, partial);
+  } else {
+    if (nt) hipLaunchKernelGGL((gelu_colsum_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, sv, (int)cols, row_splits, rows_per_wg, (float*)y, partial);
+    else hipLaunchKernelGGL((gelu_colsum_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, sv, (int)cols, row_splits, rows_per_wg, (float*)y, partial);
+  }
   VSEL_AFTER_LAUNCH(st, "gelu_colsum_kernel");
   hipLaunchKernelGGL(gelu_colsum_finish_kernel, dim3((unsigned)cdiv(cols, 64), S), dim3(1024), 0, st, partial, (int)cols, row_splits,
                      col_sums);
   VSEL_AFTER_LAUNCH(st, "gelu_colsum_finish_kernel");
+  return VSEL_OK;
+}
+
+extern "C" size_t vsel_colsum_linear_workspace_bytes(int64_t n_seg, int64_t cin, int64_t cout) {
+  if (n_seg < 1 || cin < 1 || cout < 1) return 0;
+  return n_seg <= kLinSmallSeg ? 16 : lin_plan(n_seg, cin, cout).total;
+}
+
+extern "C" int vsel_colsum_linear(void* stream, const float* col_sums_in, const vsel_segments* seg, const void* weight,
+                                  const void* bias, vsel_dtype wdtype, int64_t cin, int64_t cout, float* col_sums_out,
+                                  void* workspace, size_t workspace_bytes) {
+  if (!col_sums_in || !weight || !col_sums_out) return fail(VSEL_ERR_INVALID, "NULL pointer");
+  int rc = check_segments_impl(seg, false);
+  if (rc) return rc;
+  if (wdtype != VSEL_BF16 && wdtype != VSEL_F32) return fail(VSEL_ERR_INVALID, "bad dtype");
+  const int vec = wdtype == VSEL_BF16 ? 8 : 4;
+  if (cin < vec || cin % vec || cout < 1) return fail(VSEL_ERR_UNSUPPORTED, "Cin must be a multiple of %d", vec);
+  if (((uintptr_t)col_sums_in | (uintptr_t)weight | (uintptr_t)col_sums_out) & 15)
+    return fail(VSEL_ERR_INVALID, "col_sums / weight must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(st);
+  const SegView sv = make_view(seg);
+  const int S = (int)seg->n_seg;
+  const bool mfma = S > kLinSmallSeg && wdtype == VSEL_BF16 && cin % 16 == 0;
+  if (!mfma) {
+    // <= kLinSmallSeg segments per launch (fp32 weights with many segments take several launches: not a path the models use)
+    for (int s0 = 0; s0 < S; s0 += kLinSmallSeg) {
+      const int sc = std::min(kLinSmallSeg, S - s0);
+      SegView svc = sv;
+      if (seg->seg_rows) svc.seg_rows = seg->seg_rows + s0;          // n_rows(s) of the chunk's segments
+      const dim3 grid((unsigned)cdiv(cout, 4));
+      if (wdtype == VSEL_BF16)
+        hipLaunchKernelGGL((colsum_linear_small_kernel<bf16_t>), grid, dim3(256), 0, st, col_sums_in + (int64_t)s0 * cin,
+                           (const bf16_t*)weight, (const bf16_t*)bias, svc, sc, (int)cin, (int)cout, col_sums_out + (int64_t)s0 * cout);
+      else
+        hipLaunchKernelGGL((colsum_linear_small_kernel<float>), grid, dim3(256), 0, st, col_sums_in + (int64_t)s0 * cin,
+                           (const float*)weight, (const float*)bias, svc, sc, (int)cin, (int)cout, col_sums_out + (int64_t)s0 * cout);
+      VSEL_AFTER_LAUNCH(st, "colsum_linear_small_kernel");
+    }
+    return VSEL_OK;
+  }
+  const LinPlan p = lin_plan(S, cin, cout);
+  if (!workspace || workspace_bytes < p.total) return fail(VSEL_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, p.total);
+  if ((uintptr_t)workspace & 15) return fail(VSEL_ERR_INVALID, "workspace must be 16-byte aligned");
+  uint16_t* planes = (uint16_t*)((char*)workspace + p.off_planes);
+  float* slabs = (float*)((char*)workspace + p.off_slabs);
+  const unsigned mtiles = (unsigned)(p.m_pad / 32);
+  // planes of in[s][.] / N_s (row_splits = 1: the "partials" are the sums themselves); rows m >= S of a tile are never read back
+  hipLaunchKernelGGL(colsum_finish_split_kernel, dim3((unsigned)cdiv(cin, 256), S), dim3(256), 0, st, col_sums_in, sv, (int)cin, 1, S,
+                     planes);
+  VSEL_AFTER_LAUNCH(st, "colsum_finish_split_kernel");
+  hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, dim3((unsigned)cdiv(cout, 64), mtiles, p.ks), dim3(64), 0, st, planes,
+                     (const uint16_t*)weight, S, (int)cout, (int)cin, p.kslice, slabs);
+  VSEL_AFTER_LAUNCH(st, "gemm_nt_bf16x3_kernel");
+  hipLaunchKernelGGL(colsum_linear_finish_kernel, dim3(mtiles, (unsigned)cdiv(cout, 8)), dim3(256), 0, st, slabs, p.ks, S, (int)cout,
+                     p.m_pad, (const uint16_t*)bias, sv, col_sums_out);
+  VSEL_AFTER_LAUNCH(st, "colsum_linear_finish_kernel");
   return VSEL_OK;
 }

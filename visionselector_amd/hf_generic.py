@@ -14,7 +14,7 @@ from . import ops
 from .selector import lis_select_block, lis_train_block
 
 
-kFuseMinTokens = 65536      # merged visual tokens per call from which the merger-side column sums pay (see forward_eval)
+kFuseMinTokens = 24576      # merged visual tokens per call from which the merger-side column sums pay (see tower_tokens_for_selection)
 
 
 class _LazyRows(torch.Tensor):
@@ -72,9 +72,13 @@ def _merger_gelu_slot(merger):
 
 def merger_col_sums(gelu_col_sums: torch.Tensor, last: torch.nn.Linear, n_rows: int) -> torch.Tensor:
     """sum_rows(H) = sum_rows(G) W2^T + N b2 for H = Linear(G) (the merger's last Linear, EV/qwen25vl/modeling_qwen2_5_vl.py:
-    148-161): fp32 [n_seg, D_out] from the fp32 column sums of the GELU output."""
-    bias = last.bias.float() * n_rows if last.bias is not None else torch.zeros(last.out_features, device=gelu_col_sums.device)
-    return torch.addmm(bias, gelu_col_sums, last.weight.float().t()).contiguous()
+    148-161): fp32 [n_seg, D_out] from the fp32 column sums of the GELU output, on the stored weight with fp32 accumulation
+    (vsel_colsum_linear; the torch route -- weight.float().t() + addmm -- copied 73 MB of fp32 weight per call at 7B)."""
+    w = last.weight.detach()
+    if w.dtype not in (torch.bfloat16, torch.float32) or not w.is_contiguous() or w.shape[1] % 8:
+        bias = last.bias.float() * n_rows if last.bias is not None else torch.zeros(last.out_features, device=gelu_col_sums.device)
+        return torch.addmm(bias, gelu_col_sums, w.float().t()).contiguous()
+    return ops.colsum_linear(gelu_col_sums.contiguous(), w, None if last.bias is None else last.bias.detach(), n_rows)
 
 
 def _merged_tokens(out) -> torch.Tensor:
@@ -99,9 +103,11 @@ def tower_tokens_for_selection(self, base_forward: Callable, hidden_states: torc
     if merger is not None and not torch.is_grad_enabled() and getattr(self, "fuse_unreorder", True):
         handle = merger.register_forward_hook(lambda mod, inp, out: _LazyRows(out) if out.dim() == 2 else out)
         # visual.fuse_merger_colsum: True / False, or None (default) = automatic: on from kFuseMinTokens merged tokens per
-        # call.  Measured on MI355X (tools/exp_merger_fusion.py, profiles/r02_merger_fusion.jsonl): GELU + LIS 1392 -> 1290 us
-        # at 147 456 tokens (-7.4 %), 391 -> 408 us at 36 864 (+4 %), and a clear loss at one image (the fused GELU costs
-        # ~25 us more than torch's, the skinny fp32 GEMM ~30 us; the sweep it removes is 5 us per image)
+        # call.  Measured on MI355X (tools/exp_merger_fusion.py, profiles/r03_merger_fusion.jsonl; round 3: non-temporal GELU
+        # streams, vsel_colsum_linear on the stored bf16 weight instead of an fp32 addmm): GELU + LIS 1408 -> 1185 us at
+        # 147 456 tokens (-15.9 %), 400 -> 367 us at 36 864 (-8.2 %), 219.3 -> 218.4 at 18 432 (break-even), 111 -> 123 at 9 216
+        # and 52 -> 63 us at one image (the fused GELU costs 7-20 us more than torch's below 40 k tokens, the sum's trip through
+        # the last Linear 10-19 us; the sweep it removes is 1.1 us per 1 000 tokens)
         fuse = getattr(self, "fuse_merger_colsum", None)
         if fuse is None:
             merge = int(getattr(self, "spatial_merge_unit", 0) or getattr(self, "spatial_merge_size", 2) ** 2)

@@ -192,6 +192,28 @@ def gelu_colsum(x: torch.Tensor, n_seg: int = 1):
     return y, sums
 
 
+def colsum_linear(col_sums_in: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], rows_per_seg: int):
+    """sum_rows(H) from sum_rows(G) for H = G W^T + b on the stored weight (vsel_colsum_linear): col_sums_in fp32 [S, Cin],
+    weight [Cout, Cin] (bf16 / fp32), bias [Cout] or None, rows_per_seg = N -> fp32 [S, Cout] = col_sums_in W^T + N b."""
+    dev = _dev(col_sums_in, weight, bias)
+    if col_sums_in.dtype != torch.float32 or col_sums_in.dim() != 2 or not col_sums_in.is_contiguous():
+        raise ValueError("col_sums_in must be contiguous float32 [n_seg, Cin]")
+    if weight.dim() != 2 or weight.shape[1] != col_sums_in.shape[1] or not weight.is_contiguous():
+        raise ValueError("weight must be contiguous [Cout, Cin]")
+    if bias is not None and (bias.dtype != weight.dtype or bias.numel() != weight.shape[0]):
+        raise ValueError("bias must be [Cout] of the weight's dtype")
+    s, cin = col_sums_in.shape
+    cout = weight.shape[0]
+    seg = _uniform_segments(s, int(rows_per_seg), 1)
+    lib = N.lib()
+    ws = _workspace(lib.vsel_colsum_linear_workspace_bytes(s, cin, cout), dev)
+    out = torch.empty(s, cout, dtype=torch.float32, device=dev)
+    b = None if bias is None else bias.contiguous()
+    N.check(lib.vsel_colsum_linear(_stream(), col_sums_in.data_ptr(), C.byref(seg), weight.data_ptr(), _p(b), _code(weight), cin, cout,
+                                   out.data_ptr(), ws.data_ptr(), ws.numel()))
+    return out
+
+
 def lis_select_presummed(h, col_sums, wq, bq, wk, bk, k: int, logical_to_physical=None, physical_to_logical=None):
     """lis_select / lis_select_permuted with the column sums of the tokens supplied by their producer (fp32 [B, D] or [D]):
     the first HBM sweep over h is skipped.  h [N,D] or [B,N,D]."""
@@ -772,7 +794,7 @@ def paged_attn(q, k_cache, v_cache, cu_seqlens_q: torch.Tensor, seqlens_k: torch
 
 
 # every op that reaches libvsel switches to its tensors' device first
-for _name in ("lis_scores", "lis_select", "lis_select_permuted", "gelu_colsum", "lis_select_presummed", "lis_select_varlen",
+for _name in ("lis_scores", "lis_select", "lis_select_permuted", "gelu_colsum", "colsum_linear", "lis_select_presummed", "lis_select_varlen",
               "hard_topk", "gather_rows", "soft_topk_fwd", "soft_topk_bwd", "lis_train_fwd", "lis_train_bwd", "lis_train_bwd_factors", "factors_to_grads", "lis_scores_bwd",
               "splice", "splice_batched", "lis_select_splice", "topk_select_splice", "varlen_attn", "varlen_attn_fwd_lse", "varlen_attn_bwd", "varlen_attn_kv",
               "attn_head_major", "paged_attn"):

@@ -50,6 +50,8 @@ void vsel_debug_reset(void);
  * out[kTraceKernels = 8][kTraceBlocks = 1024][kTraceSlots = 8] uint64; clear != 0 zeroes the device table afterwards. */
 int vsel_debug_read_trace(unsigned long long* out, int clear);
 int vsel_debug_read_attn_trace(unsigned long long* out, int clear);
+/* s_memtime stamps of one steady-state dK / dV tile of workgroup 0: out[4 waves][8 slots] (tools/trace_attn_bwd.py) */
+int vsel_debug_read_bwd_trace(unsigned long long* out);
 #endif
 
 #ifdef __cplusplus

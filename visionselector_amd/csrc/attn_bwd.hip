@@ -64,6 +64,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dot_kernel(const uint16_t* __res
 
 __device__ int g_bwd_counter[64];
 
+#ifdef VSEL_TRACE
+// s_memtime (shader clock) stamps of ONE steady-state dK/dV tile of workgroup 0, one row per wave (tools/trace_attn_bwd.py)
+__device__ unsigned long long g_bwd_tile_trace[4][8];
+#define VSEL_BWD_STAMP(slot)                                                                        \
+  do {                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    if (trace_on && lane == 0) g_bwd_tile_trace[wave][slot] = __builtin_readcyclecounter();          \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+  } while (0)
+#else
+#define VSEL_BWD_STAMP(slot) do {} while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------
 // dQ: the forward's loop with two extra contractions.  4 waves x 32 queries.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -326,6 +339,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
     load_tile(0);
     __syncthreads();
 
+#ifdef VSEL_TRACE
+    bool trace_on = false;
+#endif
     int qt = q_begin;                                            // query tile being processed
     // one 64-query tile from LDS buffer CUR (compile-time, so that every LDS address is a per-lane base + an immediate)
     auto tile_body = [&](auto cur_c) {
@@ -336,6 +352,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
         const bool need_mask = __builtin_amdgcn_readfirstlane((int)((causal && kw0 + 31 > qt) || qt + kTile > len)) != 0;
         const char* qtile = smem + CUR * kTileB;
         const char* dotile = smem + (2 + CUR) * kTileB;
+        VSEL_BWD_STAMP(0);
         f32x16 s[2], dp[2];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
@@ -349,6 +366,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
             dp[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, as_bf16x8(vf[st]), dp[qb], 0, 0, 0);
           }
         }
+        VSEL_BWD_STAMP(1);
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
           bf16x8_t pf[2], dsf[2];
@@ -381,6 +399,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
               }
             }
           }
+          VSEL_BWD_STAMP(2 + 2 * qb);
 #pragma unroll
           for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -396,6 +415,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
               dka[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(q_lo, q_hi, 0, 1, 2, 3, 4, 5, 6, 7), dsf[m],
                                                                 dka[dt], 0, 0, 0);
             }
+          VSEL_BWD_STAMP(3 + 2 * qb);
         }
       }
       qt += kTile;
@@ -403,9 +423,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
     };
 
     for (int it = 0; it < n_iter; it += 2) {
+#ifdef VSEL_TRACE
+      trace_on = blockIdx.x == 0 && round == 0 && it == 8;
+#endif
       if (it + 1 < n_iter) load_tile(1);
       tile_body(std::integral_constant<int, 0>{});
+      VSEL_BWD_STAMP(6);
       __syncthreads();                       // also drains this wave's global_load_lds queue (vmcnt(0)) before the release
+      VSEL_BWD_STAMP(7);
+#ifdef VSEL_TRACE
+      trace_on = false;
+#endif
       if (it + 1 >= n_iter) break;
       if (it + 2 < n_iter) load_tile(0);
       tile_body(std::integral_constant<int, 1>{});
@@ -476,6 +504,12 @@ __global__ __launch_bounds__(256) void attn_bwd_group_sum_kernel(const float* __
 }  // namespace vsel
 
 using namespace vsel;
+
+#ifdef VSEL_TRACE
+extern "C" int vsel_debug_read_bwd_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(bwd::g_bwd_tile_trace), sizeof(bwd::g_bwd_tile_trace)) == hipSuccess ? VSEL_OK : VSEL_ERR_HIP;
+}
+#endif
 
 // Items of the in-kernel-group dK/dV pass below which the per-q-head split (fp32 partials + group sum) is used instead:
 // measured (tools/bench_attn_bwd.py): the split wins up to ~300 items (4 x 2368: 635 vs 802 us) and loses at 576 (16 x 1100).

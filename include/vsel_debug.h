@@ -33,7 +33,9 @@ typedef enum vsel_debug_knob {
   VSEL_KNOB_ATTN_BWD_SPLIT = 8,   /* dK/dV per-q-head split: -1 by item count (default), 0 / 1 force; deterministic either way */
   VSEL_KNOB_LIS_SPLICE_FUSED = 9, /* 0 / 1: vsel_lis_select_splice writes kept rows straight into inputs_embeds' (default 1) or runs
                                      select then splice as two steps; bit-identical */
-  VSEL_KNOB_COUNT = 10
+  VSEL_KNOB_ATTN_BWD_WAVES = 10,  /* 4 / 8: dK/dV workgroup: four waves with K/V operands in registers, or eight (two per SIMD, query tile split
+                                     across wave pairs, K/V fragments from LDS); deterministic either way, fp32 association differs */
+  VSEL_KNOB_COUNT = 11
 } vsel_debug_knob;
 
 /* Set knob to value (clamped to the knob's range).  *previous (may be NULL) receives the value it had.

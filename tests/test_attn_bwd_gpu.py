@@ -139,6 +139,26 @@ def test_split_and_grouped_dkdv_agree(ops):
         assert float((a.float() - b.float()).abs().max()) <= 2 ** -7 * float(a.float().abs().max())
 
 
+def test_four_and_eight_wave_dkdv_agree(ops):
+    """dK / dV with four waves per workgroup (K / V operands in registers, one wave per SIMD) and with eight (two per SIMD: the
+    query tile split across wave pairs, K / V fragments from LDS, pair sums handed over through LDS): the same contractions with a
+    different fp32 association over the queries -> within 1 bf16 ulp; dQ does not depend on the form; each form is deterministic."""
+    from visionselector_amd._native import debug_knob
+    res = {}
+    for w in (4, 8):
+        with debug_knob("attn_bwd_waves", w):
+            _, _, _, g = _run(ops, [300, 77, 513, 1200], 14, 2, True, seed=9)
+            _, _, _, g2 = _run(ops, [300, 77, 513, 1200], 14, 2, True, seed=9)
+            with debug_knob("attn_bwd_split", 1):
+                _, _, _, gs = _run(ops, [300, 77, 513], 14, 2, True, seed=8)
+        for a, b in zip(g, g2):
+            assert torch.equal(a, b)
+        res[w] = (g, gs)
+    assert torch.equal(res[4][0][0], res[8][0][0])
+    for a, b in list(zip(res[4][0][1:], res[8][0][1:])) + list(zip(res[4][1][1:], res[8][1][1:])):
+        assert float((a.float() - b.float()).abs().max()) <= 2 ** -7 * float(a.float().abs().max())
+
+
 def test_flash_attn_compat_functions(ops):
     """flash_attn_varlen_func / flash_attn_func with the flash-attn call shapes: same packing (differentiable), different
     query / key packings (forward only, bottom-right causal) and the batched dense form."""

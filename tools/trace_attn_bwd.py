@@ -26,18 +26,23 @@ out, lse = ops.varlen_attn_fwd_lse(q, k, v, cu, L)
 lib = _native.lib()
 lib.vsel_debug_read_bwd_trace.argtypes = [C.c_void_p]
 lib.vsel_debug_read_bwd_trace.restype = C.c_int
-names = ["S, dP of both sub-blocks (32 MFMA)", "P, dS of sub-block 0 (VALU)", "dV, dK += sub-block 0 (16 MFMA)",
-         "P, dS of sub-block 1 (VALU)", "dV, dK += sub-block 1 (16 MFMA)", "tile tail", "barrier + vmcnt(0)"]
+W8 = _native.debug_get("attn_bwd_waves") == 8
+if W8:           # eight waves (two per SIMD): each wave owns one 32-query half of the tile
+    names = ["S, dP of the wave's half (16 MFMA)", "P, dS (VALU)", "dV, dK (16 MFMA)", "tile tail", "barrier + vmcnt(0)"]
+else:
+    names = ["S, dP of both sub-blocks (32 MFMA)", "P, dS of sub-block 0 (VALU)", "dV, dK += sub-block 0 (16 MFMA)",
+             "P, dS of sub-block 1 (VALU)", "dV, dK += sub-block 1 (16 MFMA)", "tile tail", "barrier + vmcnt(0)"]
+NW = 8 if W8 else 4
 acc = []
 for _ in range(5):
     ops.varlen_attn_bwd(do, q, k, v, out, lse, cu, L)
     torch.cuda.synchronize()
-    buf = np.zeros((4, 8), dtype=np.uint64)
+    buf = np.zeros((8, 8), dtype=np.uint64)
     assert lib.vsel_debug_read_bwd_trace(buf.ctypes.data) == 0
     acc.append(buf.astype(np.int64))
 a = np.median(np.stack(acc), axis=0)
-print(f"{n_seq} x {L}: cycles per phase of one 64-query tile (median of 5 launches), waves 0..3")
+print(f"{n_seq} x {L}: cycles per phase of one 64-query tile (median of 5 launches), waves 0..{NW - 1}")
 for i, nm in enumerate(names):
-    print(f"  {nm:36s}", "  ".join(f"{int(a[w, i + 1] - a[w, i]):6d}" for w in range(4)))
-print(f"  {'tile total':36s}", "  ".join(f"{int(a[w, 7] - a[w, 0]):6d}" for w in range(4)))
+    print(f"  {nm:36s}", "  ".join(f"{int(a[w, i + 1] - a[w, i]):6d}" for w in range(NW)))
+print(f"  {'tile total':36s}", "  ".join(f"{int(a[w, len(names)] - a[w, 0]):6d}" for w in range(NW)))
 print("  (16 x v_mfma_f32_32x32x16_bf16 = 512 cycles of the SIMD's matrix pipe)")

@@ -66,7 +66,7 @@ __device__ int g_bwd_counter[64];
 
 #ifdef VSEL_TRACE
 // s_memtime (shader clock) stamps of ONE steady-state dK/dV tile of workgroup 0, one row per wave (tools/trace_attn_bwd.py)
-__device__ unsigned long long g_bwd_tile_trace[4][8];
+__device__ unsigned long long g_bwd_tile_trace[8][8];
 #define VSEL_BWD_STAMP(slot)                                                                        \
   do {                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                              \
@@ -473,6 +473,279 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// dK, dV with TWO waves per SIMD (round 3).  The 4-wave kernel above holds 128 accumulator + 64 K / V operand registers per wave,
+// i.e. one wave per SIMD, and a lone wave retires one LDS wave-instruction per ~29 cycles whatever its width (tools/lds_tr_bench.hip):
+// its transposed-read phases (two reads per MFMA) cannot beat ~58 cycles per MFMA and its P / dS arithmetic runs with the matrix
+// pipe idle (profiles/r03_attn_bwd_tile_timeline.txt).  Here a workgroup is 8 waves on the same 128 keys: wave (kb, qh) owns key
+// block kb (32 keys) and the 32-query HALF qh of every 64-query tile, so each SIMD carries a pair of waves with independent
+// instruction streams (the per-wave LDS rate doubles per SIMD, one wave's VALU runs under the other's MFMAs).  To fit 256 registers
+// the K / V fragments are not resident: the item's 128-key K and V tiles are staged in LDS once (64 KiB) and read as row fragments
+// next to the Q / dO fragments.  Each wave of a pair accumulates dK / dV over its own half of the queries; at the end of the item the
+// qh = 1 waves hand their fp32 accumulators over through LDS and the qh = 0 waves add them (own + partner, fixed order) and store --
+// still no atomics, reruns bit-identical.
+// LDS: K 32 KiB | V 32 KiB | Q[2] 32 KiB | dO[2] 32 KiB | lse[2][64], D[2][64] | work-item slot  (the first 128 KiB double as the
+// hand-over buffer).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool SPLIT>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+    const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dvec,
+    const int32_t* __restrict__ cu, int hq, int hkv, float scale, int causal, uint16_t* __restrict__ dk,
+    uint16_t* __restrict__ dv, float* __restrict__ dk_part, float* __restrict__ dv_part, int k_blocks, int n_seq, int slot) {
+  constexpr int kKV = 2 * kTileB;                               // one 128-key tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * kKV + 4 * kTileB + 4 * kTile * sizeof(float) + 16];
+  char* const k_sm = smem;
+  char* const v_sm = smem + kKV;
+  char* const q_sm = smem + 2 * kKV;
+  char* const do_sm = smem + 2 * kKV + 2 * kTileB;
+  float (*lse_sm)[kTile] = reinterpret_cast<float (*)[kTile]>(smem + 2 * kKV + 4 * kTileB);
+  float (*d_sm)[kTile] = reinterpret_cast<float (*)[kTile]>(smem + 2 * kKV + 4 * kTileB + 2 * kTile * sizeof(float));
+  int& s_item = *reinterpret_cast<int*>(smem + 2 * kKV + 4 * kTileB + 4 * kTile * sizeof(float));
+  const int heads_per_item_dim = SPLIT ? hq : hkv;
+  const int n_items = k_blocks * heads_per_item_dim * n_seq;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kb = wave & 3, qh = wave >> 2;
+  const int j = lane & 31, hh = lane >> 5;
+  const float sl2 = scale * kLog2e;
+  const int rep = hq / hkv;
+  // Row-fragment addresses are rebuilt per use instead of held in 16 registers (256 per wave is the budget of two waves per SIMD):
+  // chunk_off(row, 2 st + hh) = row * 256 + (((2 st) ^ (swz(row) ^ hh)) << 4), i.e. a per-lane base and a per-lane XOR term against
+  // the compile-time constant 32 st -- two VALU per address.
+  int tr_addr[4][2];
+  make_tr_addr<4>(tr_addr, lane);
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { tr_addr[dt][0] += qh * 32 * kRowB; tr_addr[dt][1] += qh * 32 * kRowB; }
+  const int q_row = perm_row(j) + 32 * qh;                       // A fragment row of the wave's own 32-query half
+  const int q_base = q_row * kRowB, q_x = (swz(q_row) ^ hh) << 4;
+  const int kv_row = 32 * kb + j;                                // B fragment: key kw0 + j, features 16 st + 8 hh .. + 7
+  const int kv_base = kv_row * kRowB, kv_x = (swz(kv_row) ^ hh) << 4;
+  auto q_addr = [&](int st) { return q_base + ((32 * st) ^ q_x); };
+  auto kv_addr = [&](int st) { return kv_base + ((32 * st) ^ kv_x); };
+
+  for (int round = 0;; ++round) {
+    int item;
+    if (slot < 0) {
+      if (round > 0) return;
+      item = blockIdx.x;
+    } else {
+      if (tid == 0) s_item = atomicAdd(&g_bwd_counter[slot], 1);
+      __syncthreads();
+      item = s_item;
+      __syncthreads();
+    }
+    if (item >= n_items) return;
+    const int kblock = item / (heads_per_item_dim * n_seq);
+    const int rest = item % (heads_per_item_dim * n_seq);
+    const int hsel = rest % heads_per_item_dim, seq = rest / heads_per_item_dim;
+    const int kvh = SPLIT ? hsel / rep : hsel;
+    const int qs = cu[seq];
+    const int len = cu[seq + 1] - qs;
+    const int k0 = kblock * 128;
+    if (k0 >= len) continue;
+    const int kw0 = k0 + 32 * kb;
+    const int my_k = min(kw0 + j, len - 1);
+    const bool k_valid = (kw0 + j) < len;
+
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int ld_part = slice_src_part(lane, wave) * 8;
+    {
+      // the item's K / V tiles: 32 one-KiB slices each, wave w issues slices w, w + 8, w + 16, w + 24 (source-swizzled)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = wave + 8 * u;
+        const int kpos = min(k0 + 4 * i + (lane >> 4), len - 1);
+        const int64_t off = ((int64_t)(qs + kpos) * hkv + kvh) * kD + ld_part;
+        __builtin_amdgcn_global_load_lds((gptr_t)(k + off), (lptr_t)(k_sm + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(v + off), (lptr_t)(v_sm + i * 1024), 16, 0, 0);
+      }
+    }
+    f32x16 dka[4], dva[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dka[dt][r] = 0.f; dva[dt][r] = 0.f; }
+
+    const int q_begin = causal ? k0 : 0;
+    const int tiles_per_head = (len - q_begin + kTile - 1) / kTile;
+    const int n_iter = SPLIT ? tiles_per_head : tiles_per_head * rep;
+    int ld_qt = q_begin, ld_head = SPLIT ? hsel : kvh * rep;
+    auto load_tile = [&](int buf) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = wave + 8 * u;
+        const int qpos = min(ld_qt + 4 * i + (lane >> 4), len - 1);
+        const int64_t off = ((int64_t)(qs + qpos) * hq + ld_head) * kD + ld_part;
+        __builtin_amdgcn_global_load_lds((gptr_t)(q + off), (lptr_t)(q_sm + buf * kTileB + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(dout + off), (lptr_t)(do_sm + buf * kTileB + i * 1024), 16, 0, 0);
+      }
+      if (wave < 2) {
+        const int64_t o = (int64_t)(qs + min(ld_qt + lane, len - 1)) * hq + ld_head;
+        if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(lse + o), (lptr_t)(&lse_sm[buf][0]), 4, 0, 0);
+        else __builtin_amdgcn_global_load_lds((gptr_t)(dvec + o), (lptr_t)(&d_sm[buf][0]), 4, 0, 0);
+      }
+      ld_qt += kTile;
+      if (ld_qt >= len) { ld_qt = q_begin; ++ld_head; }
+    };
+    load_tile(0);
+    __syncthreads();
+
+#ifdef VSEL_TRACE
+    bool trace_on = false;
+#endif
+    int qt = q_begin;
+    auto tile_body = [&](auto cur_c) {
+      constexpr int CUR = decltype(cur_c)::value;
+      const int qw0 = qt + 32 * qh;                              // first query of the wave's half
+      const bool visible = __builtin_amdgcn_readfirstlane((int)((!causal || qw0 + 31 >= kw0) && qw0 < len)) != 0;
+      if (visible) {
+        const bool need_mask = __builtin_amdgcn_readfirstlane((int)((causal && kw0 + 31 > qw0) || qw0 + 32 > len)) != 0;
+        const char* qtile = q_sm + CUR * kTileB;
+        const char* dotile = do_sm + CUR * kTileB;
+        VSEL_BWD_STAMP(0);
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          const bf16x8_t aq = as_bf16x8(*reinterpret_cast<const u32x4*>(qtile + q_addr(st)));
+          const bf16x8_t kf = as_bf16x8(*reinterpret_cast<const u32x4*>(k_sm + kv_addr(st)));
+          const bf16x8_t ad = as_bf16x8(*reinterpret_cast<const u32x4*>(dotile + q_addr(st)));
+          const bf16x8_t vf = as_bf16x8(*reinterpret_cast<const u32x4*>(v_sm + kv_addr(st)));
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf, s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf, dp, 0, 0, 0);
+        }
+        VSEL_BWD_STAMP(1);
+        bf16x8_t pf[2], dsf[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int rb = 32 * qh + 16 * m;                        // + 8*hh through the per-lane base
+          const f32x4 l0 = *reinterpret_cast<const f32x4*>(&lse_sm[CUR][rb] + 8 * hh);
+          const f32x4 l1 = *reinterpret_cast<const f32x4*>(&lse_sm[CUR][rb + 4] + 8 * hh);
+          const f32x4 e0 = *reinterpret_cast<const f32x4*>(&d_sm[CUR][rb] + 8 * hh);
+          const f32x4 e1 = *reinterpret_cast<const f32x4*>(&d_sm[CUR][rb + 4] + 8 * hh);
+          const float lv[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+          const float dv8[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+          if (need_mask) {
+            const int rel = causal ? kw0 + j - (qt + rb + 8 * hh) : -(1 << 30);    // key visible iff rel <= e
+            const int qlim = len - (qt + rb + 8 * hh);                              // query row real iff e < qlim
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int r = 8 * m + e;
+              const float p = (rel <= e && e < qlim) ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lv[e])) : 0.f;
+              pf[m][e] = (__bf16)p;
+              dsf[m][e] = (__bf16)(p * (dp[r] - dv8[e]));
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int r = 8 * m + e;
+              const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lv[e]));
+              pf[m][e] = (__bf16)p;
+              dsf[m][e] = (__bf16)(p * (dp[r] - dv8[e]));
+            }
+          }
+        }
+        VSEL_BWD_STAMP(2);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
+            const int off = 16 * m * kRowB;
+            const bf16x4_t d_lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dotile + tr_addr[dt][0] + off));
+            const bf16x4_t d_hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dotile + tr_addr[dt][1] + off));
+            const bf16x4_t q_lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(qtile + tr_addr[dt][0] + off));
+            const bf16x4_t q_hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(qtile + tr_addr[dt][1] + off));
+            dva[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(d_lo, d_hi, 0, 1, 2, 3, 4, 5, 6, 7), pf[m],
+                                                              dva[dt], 0, 0, 0);
+            dka[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(q_lo, q_hi, 0, 1, 2, 3, 4, 5, 6, 7), dsf[m],
+                                                              dka[dt], 0, 0, 0);
+          }
+        VSEL_BWD_STAMP(3);
+      }
+      qt += kTile;
+      if (qt >= len) qt = q_begin;
+    };
+
+    for (int it = 0; it < n_iter; it += 2) {
+#ifdef VSEL_TRACE
+      trace_on = blockIdx.x == 0 && round == 0 && it == 8;
+#endif
+      if (it + 1 < n_iter) load_tile(1);
+      tile_body(std::integral_constant<int, 0>{});
+      VSEL_BWD_STAMP(4);
+      __syncthreads();
+      VSEL_BWD_STAMP(5);
+#ifdef VSEL_TRACE
+      trace_on = false;
+#endif
+      if (it + 1 >= n_iter) break;
+      if (it + 2 < n_iter) load_tile(0);
+      tile_body(std::integral_constant<int, 1>{});
+      __syncthreads();
+    }
+    // ---- pair hand-over: qh = 1 -> LDS [kb][dk / dv][dt][r / 4][lane][4], qh = 0 adds (own + partner) and stores ------------
+    // (the loop's last barrier has passed: nobody reads the tiles any more, and no direct-to-LDS load is in flight)
+    float* xch = reinterpret_cast<float*>(smem) + (size_t)kb * (2 * 4 * 4 * 64 * 4);
+    if (qh == 1) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          *reinterpret_cast<f32x4*>(xch + ((0 * 4 + dt) * 4 + g4) * 256 + lane * 4) =
+              f32x4{dka[dt][4 * g4], dka[dt][4 * g4 + 1], dka[dt][4 * g4 + 2], dka[dt][4 * g4 + 3]};
+          *reinterpret_cast<f32x4*>(xch + ((1 * 4 + dt) * 4 + g4) * 256 + lane * 4) =
+              f32x4{dva[dt][4 * g4], dva[dt][4 * g4 + 1], dva[dt][4 * g4 + 2], dva[dt][4 * g4 + 3]};
+        }
+    }
+    __syncthreads();
+    if (qh == 0) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 pk = *reinterpret_cast<const f32x4*>(xch + ((0 * 4 + dt) * 4 + g4) * 256 + lane * 4);
+          const f32x4 pv = *reinterpret_cast<const f32x4*>(xch + ((1 * 4 + dt) * 4 + g4) * 256 + lane * 4);
+#pragma unroll
+          for (int z = 0; z < 4; ++z) { dka[dt][4 * g4 + z] += pk[z]; dva[dt][4 * g4 + z] += pv[z]; }
+        }
+      if (SPLIT) {
+        if (k_valid) {
+          const int64_t ro = ((int64_t)(qs + my_k) * hq + hsel) * kD;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const int d0 = 32 * dt + 8 * g4 + 4 * hh;
+              *reinterpret_cast<f32x4*>(dk_part + ro + d0) =
+                  f32x4{dka[dt][4 * g4], dka[dt][4 * g4 + 1], dka[dt][4 * g4 + 2], dka[dt][4 * g4 + 3]};
+              *reinterpret_cast<f32x4*>(dv_part + ro + d0) =
+                  f32x4{dva[dt][4 * g4], dva[dt][4 * g4 + 1], dva[dt][4 * g4 + 2], dva[dt][4 * g4 + 3]};
+            }
+        }
+      } else if (k_valid) {
+        const int64_t ro = ((int64_t)(qs + my_k) * hkv + kvh) * kD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int d0 = 32 * dt + 8 * g4 + 4 * hh;
+            uint2 pk;
+            pk.x = f32_to_bf16_bits(dka[dt][4 * g4] * scale) | (f32_to_bf16_bits(dka[dt][4 * g4 + 1] * scale) << 16);
+            pk.y = f32_to_bf16_bits(dka[dt][4 * g4 + 2] * scale) | (f32_to_bf16_bits(dka[dt][4 * g4 + 3] * scale) << 16);
+            *reinterpret_cast<uint2*>(dk + ro + d0) = pk;
+            pk.x = f32_to_bf16_bits(dva[dt][4 * g4]) | (f32_to_bf16_bits(dva[dt][4 * g4 + 1]) << 16);
+            pk.y = f32_to_bf16_bits(dva[dt][4 * g4 + 2]) | (f32_to_bf16_bits(dva[dt][4 * g4 + 3]) << 16);
+            *reinterpret_cast<uint2*>(dv + ro + d0) = pk;
+          }
+      }
+    }
+    __syncthreads();                           // the hand-over buffer is the next item's K / V / Q / dO
+  }
+}
+
 // dK[t, g, :] = scale * sum_{h in group g} dk_part[t, h, :] (heads added in ascending order), dV likewise without the scale.
 // One thread per 4 consecutive d.
 __global__ __launch_bounds__(256) void attn_bwd_group_sum_kernel(const float* __restrict__ dk_part, const float* __restrict__ dv_part,
@@ -577,14 +850,17 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
     float* dk_part = split ? (float*)((char*)workspace + 2 * d_bytes) : nullptr;
     float* dv_part = split ? dk_part + (size_t)rows * bwd::kD : nullptr;
     const dim3 grid((unsigned)std::min<int64_t>(n_items, 256));
-    if (split)
-      hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<true>), grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                         (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu_seqlens, (int)hq, (int)hkv, scale, causal,
-                         (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, k_blocks, (int)n_seq, slot);
-    else
-      hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<false>), grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                         (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu_seqlens, (int)hq, (int)hkv, scale, causal,
-                         (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, k_blocks, (int)n_seq, slot);
+    const bool w8 = knob(VSEL_KNOB_ATTN_BWD_WAVES) == 8;
+#define VSEL_DKDV_ARGS (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu_seqlens, (int)hq, \
+                       (int)hkv, scale, causal, (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, k_blocks, (int)n_seq, slot
+    if (w8) {
+      if (split) hipLaunchKernelGGL((bwd::attn_bwd_dkdv2_kernel<true>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS);
+      else hipLaunchKernelGGL((bwd::attn_bwd_dkdv2_kernel<false>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS);
+    } else {
+      if (split) hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<true>), grid, dim3(256), 0, st, VSEL_DKDV_ARGS);
+      else hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<false>), grid, dim3(256), 0, st, VSEL_DKDV_ARGS);
+    }
+#undef VSEL_DKDV_ARGS
     VSEL_AFTER_LAUNCH(st, "attn_bwd_dkdv_kernel");
     if (split) {
       // rows past a sequence's end never exist in the packed layout, so every (t, h) partial row was written

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
 
     for (int it = 0; it < n_iter; it += 2) {
 #ifdef VSEL_TRACE
-      trace_on = blockIdx.x == 0 && round == 0 && it == 8;
+      trace_on = blockIdx.x == 0 && round == 0 && it == ((n_iter / 2) & ~1);   // mid-item: steady state (the first tiles of a launch see every workgroup's prologue burst)
 #endif
       if (it + 1 < n_iter) load_tile(1);
       tile_body(std::integral_constant<int, 0>{});
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
 
     for (int it = 0; it < n_iter; it += 2) {
 #ifdef VSEL_TRACE
-      trace_on = blockIdx.x == 0 && round == 0 && it == 8;
+      trace_on = blockIdx.x == 0 && round == 0 && it == ((n_iter / 2) & ~1);   // mid-item: steady state (the first tiles of a launch see every workgroup's prologue burst)
 #endif
       if (it + 1 < n_iter) load_tile(1);
       tile_body(std::integral_constant<int, 0>{});

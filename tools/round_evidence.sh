@@ -1,12 +1,25 @@
 #!/bin/bash
+# Everything under profiles/r03_* in one gpurun call: the -m gpu suite (parity margins), bench + rocprofv3 + PMC (collect_round.sh),
+# timelines, sweeps.  Copy what is to be judged from gpurun_out/r03_final/ into profiles/.
 set -u
 ROOT="${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is set there)}"
 cd "$ROOT"
-mkdir -p gpurun_out/r03_final
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -5 > gpurun_out/r03_final/pytest_gpu.txt
-timeout 1500 bash tools/collect_round.sh r03_final > gpurun_out/r03_final/collect.log 2>&1
-timeout 200 python tools/trace_small.py 1 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_final/small_batch_timeline.txt
-timeout 200 python tools/trace_attn.py 524 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_final/attention_timeline.txt
-timeout 120 tools/launch_floor > gpurun_out/r03_final/launch_floor.txt 2>&1
-timeout 300 python tools/bench_attn.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_final/bench_attn.txt
-cat gpurun_out/r03_final/pytest_gpu.txt; head -c 600 gpurun_out/r03_final/bench_default.json
+O=gpurun_out/r03_final
+mkdir -p $O
+rm -f gpurun_out/parity/r03_parity.jsonl
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/pytest_gpu.txt
+python tools/merge_parity.py gpurun_out/parity/r03_parity.jsonl $O/parity.json > /dev/null 2>&1
+timeout 1500 bash tools/collect_round.sh r03_final > $O/collect.log 2>&1
+g() { grep -v amdgpu.ids; }
+timeout 200 python tools/trace_small.py 1 2>&1 | g > $O/small_batch_timeline.txt
+timeout 200 python tools/trace_attn.py 524 2>&1 | g > $O/attention_timeline.txt
+(for w in 4 8; do VSEL_ATTN_BWD_WAVES=$w timeout 200 python tools/trace_attn_bwd.py 2>&1 | g; done) > $O/attn_bwd_tile_timeline.txt
+timeout 300 python tools/bench_attn.py 2>&1 | g > $O/bench_attn.txt
+timeout 300 python tools/bench_attn_bwd.py 2>&1 | g > $O/bench_attn_bwd.txt
+timeout 300 python tools/bench_sdpa_ref.py 2>&1 | g > $O/sdpa_ref.jsonl
+timeout 300 python tools/bench_select_splice.py 2>&1 | g > $O/select_splice.jsonl
+timeout 300 python tools/exp_merger_fusion.py 2>&1 | g > $O/merger_fusion.jsonl
+timeout 600 python tools/sweep.py 2>&1 | g > $O/config_sweep.json
+timeout 600 python tools/bench_c5.py 2>&1 | g > $O/config5.jsonl
+timeout 120 tools/lds_tr_bench > $O/lds_read_rates.txt 2>&1
+cat $O/pytest_gpu.txt; head -c 600 $O/bench_default.json

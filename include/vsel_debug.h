@@ -52,8 +52,10 @@ void vsel_debug_reset(void);
  * out[kTraceKernels = 8][kTraceBlocks = 1024][kTraceSlots = 8] uint64; clear != 0 zeroes the device table afterwards. */
 int vsel_debug_read_trace(unsigned long long* out, int clear);
 int vsel_debug_read_attn_trace(unsigned long long* out, int clear);
-/* s_memtime stamps of one steady-state dK / dV tile of workgroup 0: out[4 waves][8 slots] (tools/trace_attn_bwd.py) */
+/* s_memtime stamps of one steady-state dK / dV tile of workgroup 0: out[8 waves][8 slots] (tools/trace_attn_bwd.py) */
 int vsel_debug_read_bwd_trace(unsigned long long* out);
+/* the same for one steady-state tile of the attention forward's main loop: out[8 waves][8 slots] (tools/trace_attn_fwd.py) */
+int vsel_debug_read_fwd_tile_trace(unsigned long long* out);
 #endif
 
 #ifdef __cplusplus

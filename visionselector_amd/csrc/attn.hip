@@ -29,6 +29,7 @@ using namespace attn;      // tile layout + fragment addressing shared with the 
 
 // LDS rows are 256 bytes for every supported head_dim (64 / 80 / 128)
 constexpr int kTileK = 64;
+constexpr float kLazyTau = 8.f;     // online softmax: the reference exponent of a row moves only past this slack (log2 units)
 constexpr int kBuf = kTileBytes;             // 16 KiB per tile
 constexpr int kLds = 4 * kBuf;               // K[2], V[2]: 64 KiB
 
@@ -39,6 +40,19 @@ __device__ __forceinline__ bf16x8_t to_bf16x8(u32x4 v) { return __builtin_bit_ca
 // tiles under the causal mask) through one atomic counter, so the causal triangle is load-balanced over the 2 x 256
 // resident workgroups instead of being bounded by the last q-tile (1.9x fewer tiles on the critical path at L = 2368).
 __device__ int g_attn_work_counter[64];
+
+#ifdef VSEL_TRACE
+// s_memtime (shader clock) stamps of ONE steady-state tile of workgroup 0's first item, one row per wave (tools/trace_attn_fwd.py)
+__device__ unsigned long long g_fwd_tile_trace[8][8];
+#define VSEL_FWD_STAMP(slot)                                                                        \
+  do {                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    if (trace_on && lane == 0) g_fwd_tile_trace[wave_all][slot] = __builtin_readcyclecounter();      \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+  } while (0)
+#else
+#define VSEL_FWD_STAMP(slot) do {} while (0)
+#endif
 
 // Optional paged-KV / separate key lengths.  Contiguous var-len prefill (the reference's call sites) leaves it empty.
 struct PagedKV {
@@ -276,6 +290,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
   __syncthreads();
   VSEL_STAMP(0, 1);
 
+  [[maybe_unused]] bool trace_on = false;
   // one 64-key tile from LDS buffer CUR (compile-time, so that every LDS address is a per-lane base + an immediate)
   auto tile_body = [&](auto cur_c, int t) {
     constexpr int CUR = decltype(cur_c)::value;
@@ -294,7 +309,8 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
         for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
       if constexpr (USE_TR && kSteps == 8 && !PACK) {
         // per 32-key block: its 8 K fragments in ONE batch of ds_read_b128, then its 8 MFMAs (one LDS round trip per block instead
-        // of one per MFMA; a second batch in flight would need 32 more registers and spills)
+        // of one per MFMA; a second batch in flight would need 32 more registers and spills; batches of 4 with two in flight --
+        // same registers, reads ahead of the MFMAs -- measured SLOWER, 880 vs 973 TFLOP/s at 16 x 4096)
         auto s_block = [&](auto kb_c) {
           constexpr int KB = decltype(kb_c)::value;
           constexpr int SI = KH == 1 ? KB : 0;
@@ -331,6 +347,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
             s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(a), to_bf16x8(qf[st]), s[kb], 0, 0, 0);
           }
       }
+      VSEL_FWD_STAMP(2);
       // the first group of V fragments does not depend on P: put its transpose reads in flight now, under the softmax
       u32x2 vr0[8], vr1[8];
       if constexpr (USE_TR && kDTiles == 4 && NW >= 8 && !PACK) {
@@ -365,9 +382,16 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
           for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx * scale_log2e);      // scale > 0: max commutes with the scaling
-      if (!__all(m_new == m_run)) {                            // wave-uniform: most tiles leave the running max alone
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      // Lazy reference exponent: m_run is the exponent the row's (l, O) are expressed in, not necessarily the running maximum.
+      // It moves only when the tile's maximum exceeds it by more than kLazyTau (log2 units), so p = exp2(s - m_run) <= 2^kLazyTau:
+      // harmless in fp32 / bf16, and the max / rescale of O leaves the common path (with the exact running maximum some lane of
+      // the wave moved in most of the first ~2000 keys of a row).  The decision is per lane (per query), so a row's arithmetic does
+      // not depend on which other rows share its wave (PACK / NW forms stay bit-identical to each other).
+      const float m_cand = fmaxf(m_run, mx * scale_log2e);     // scale > 0: max commutes with the scaling
+      const bool moves = m_cand > m_run + kLazyTau;
+      if (__any(moves)) {                                      // wave-uniform branch
+        const float m_new = moves ? m_cand : m_run;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exactly 1 for the lanes that stay
         m_run = m_new;
         l_run *= alpha;
 #pragma unroll
@@ -386,6 +410,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
           pf[kb][r >> 3][r & 7] = (__bf16)p;
         }
       l_run += psum;
+      VSEL_FWD_STAMP(3);
       // ---- O^T += V^T P^T -------------------------------------------------------------------------------------
       if constexpr (USE_TR && kDTiles == 4 && !PACK) {
         // four (32-key block, 16-key half) groups; a group = 8 transpose reads (4 d-tiles x lo / hi) feeding 4 MFMAs; the next
@@ -464,9 +489,19 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
   };
   if constexpr (KVS == 1) {
     for (int t = 0; t < n_tiles; t += 2) {
+#ifdef VSEL_TRACE
+      trace_on = blockIdx.x == 0 && round == 0 && t == ((n_tiles / 2) & ~1);
+#endif
+      VSEL_FWD_STAMP(0);
       if (t + 1 < n_tiles) load_tile(t + 1, 1);
+      VSEL_FWD_STAMP(1);
       tile_body(std::integral_constant<int, 0>{}, t);
+      VSEL_FWD_STAMP(4);
       __syncthreads();                       // also drains this wave's global_load_lds queue (vmcnt(0)) before the release
+      VSEL_FWD_STAMP(5);
+#ifdef VSEL_TRACE
+      trace_on = false;
+#endif
       if (t + 1 >= n_tiles) break;
       if (t + 2 < n_tiles) load_tile(t + 2, 0);
       tile_body(std::integral_constant<int, 1>{}, t + 1);
@@ -584,6 +619,9 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
 using namespace vsel;
 
 #ifdef VSEL_TRACE
+extern "C" int vsel_debug_read_fwd_tile_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_tile_trace), sizeof(g_fwd_tile_trace)) == hipSuccess ? VSEL_OK : VSEL_ERR_HIP;
+}
 // copies the stamps of the last forward launch: out[kTraceKernels][kTraceBlocks][kTraceSlots] (tools/trace_attn.py)
 extern "C" int vsel_debug_read_attn_trace(unsigned long long* out, int clear) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(g_trace)) != hipSuccess) return VSEL_ERR_HIP;

@@ -2,9 +2,15 @@
 """Attention kernel throughput vs problem size (Qwen2.5-VL-7B geometry: 28 q heads, 4 kv heads, d = 128, causal)."""
 import os, sys, json, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from visionselector_amd import _native
+if "--lib" in sys.argv:            # another build of the library (same-box A/B runs: tools/ab_attn.sh)
+    _native.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from visionselector_amd import ops
 rows = []
-for nseq, L in [(1, 524), (1, 2368), (8, 524), (32, 524), (4, 2368), (16, 2368), (16, 4096), (4, 8192)]:
+shapes = [(1, 524), (1, 2368), (8, 524), (32, 524), (4, 2368), (16, 2368), (16, 4096), (4, 8192)]
+if "--big" in sys.argv:
+    shapes = [(16, 2368), (16, 4096), (4, 8192)]
+for nseq, L in shapes:
     g = torch.Generator(device="cuda").manual_seed(7)
     T = nseq * L
     q = torch.randn(T, 28, 128, device="cuda", generator=g).bfloat16()

@@ -59,6 +59,10 @@ def check_no_spills(src: str, remarks: str) -> None:
         if m is None:
             raise RuntimeError(f"no resource-usage remark for {name}")
         seen += 1
+        sc = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", block)
+        if sc is not None and int(sc.group(1)) != 0:
+            raise RuntimeError(f"{name}: {sc.group(1)} bytes of scratch per lane -- a tile-loop lambda was not inlined or an array was "
+                               "indexed dynamically; the hand-scheduled kernels must keep everything in registers")
         if int(m.group(1)) != 0:
             raise RuntimeError(f"{name}: {m.group(1)} spilled VGPRs -- its asm-issued LDS reads (attn_common.h) would read stale "
                                "registers; reduce live registers before shipping this build")

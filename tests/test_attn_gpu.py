@@ -66,6 +66,29 @@ def test_attention_rescale_path(ops):
     check(*run_case(ops, [333, 260], 4, 4, False, seed=6, spike=True))
 
 
+def test_attention_lazy_exponent_ramp(ops):
+    """The row's reference exponent moves only when a tile's maximum exceeds it by more than 8 log2 units (csrc/attn.hip kLazyTau):
+    keys whose logits creep up tile after tile keep it stale (p up to 2^8) for many tiles, then a jump moves it.  Oracle parity at
+    the usual gate, and the 4- / 8-wave forms (different sets of rows per wave) stay bit-identical."""
+    from visionselector_amd._native import debug_knob
+    lens = [900, 333]
+    total = sum(lens)
+    q, k, v = make_qkv(total, 4, 2, 23)
+    ramp = torch.linspace(0.2, 2.5, total).view(-1, 1, 1)          # logits grow ~12x along the sequence, a little per 64-key tile
+    k = (k.float() * ramp).bfloat16()
+    k[700] *= 5                                                     # ... and one jump far past the slack
+    cu = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    cu_t = torch.from_numpy(cu).cuda()
+    for causal in (True, False):
+        ref = oattn.varlen_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu, causal=causal)
+        outs = []
+        for nw in (4, 8):
+            with debug_knob("attn_split", 0), debug_knob("attn_waves", nw):
+                outs.append(ops.varlen_attn(q.cuda(), k.cuda(), v.cuda(), cu_t, max(lens), causal=causal))
+        assert torch.equal(outs[0], outs[1])
+        check(outs[0].float().cpu().numpy(), ref, f"[causal={causal}]")
+
+
 def test_attention_transpose_read_equals_plain_reads(ops):
     """The ds_read_b64_tr_b16 V^T fragments and plain 16-bit column reads give bit-identical outputs."""
     from visionselector_amd._native import debug_knob

@@ -9,6 +9,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visionselector_amd import _native as N  # noqa: E402
+if "--lib" in sys.argv:            # another build of the library (same-box A/B runs: tools/ab_attn.sh)
+    N.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from visionselector_amd import ops  # noqa: E402
 
 
@@ -36,5 +38,8 @@ def run(n_seq, L, hq=28, hkv=4, iters=20):
 
 
 if __name__ == "__main__":
-    for n_seq, L in [(1, 524), (1, 2368), (8, 524), (4, 2368), (16, 2368), (16, 4096), (4, 8192), (16, 1100)]:
+    shapes = [(1, 524), (1, 2368), (8, 524), (4, 2368), (16, 2368), (16, 4096), (4, 8192), (16, 1100)]
+    if "--big" in sys.argv:
+        shapes = [(16, 4096), (4, 8192), (16, 1100)]
+    for n_seq, L in shapes:
         run(n_seq, L)

@@ -506,6 +506,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
   const int n_items = k_blocks * heads_per_item_dim * n_seq;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kb = wave & 3, qh = wave >> 2;
+  // the second-dispatched half loses every issue arbitration against its SIMD partners; one static priority bump (no per-phase
+  // flips) takes 0.5-1.4 % off the kernel (same-box A/B, MI355X_MICROARCH.md: static priority for the younger half)
+  if (qh == 1) __builtin_amdgcn_s_setprio(1);
   const int j = lane & 31, hh = lane >> 5;
   const float sl2 = scale * kLog2e;
   const int rep = hq / hkv;

@@ -35,7 +35,9 @@ typedef enum vsel_debug_knob {
                                      select then splice as two steps; bit-identical */
   VSEL_KNOB_ATTN_BWD_WAVES = 10,  /* 4 / 8: dK/dV workgroup: four waves with K/V operands in registers, or eight (two per SIMD, query tile split
                                      across wave pairs, K/V fragments from LDS); deterministic either way, fp32 association differs */
-  VSEL_KNOB_COUNT = 11
+  VSEL_KNOB_ATTN_TAIL_FIRST = 11, /* query tiles aligned to the END of each sequence (the partial tile is the cheap first one): -1 when
+                                     the grid is throughput-bound (default), 0 / 1 force; bit-identical outputs */
+  VSEL_KNOB_COUNT = 12
 } vsel_debug_knob;
 
 /* Set knob to value (clamped to the knob's range).  *previous (may be NULL) receives the value it had.

@@ -89,6 +89,42 @@ def test_attention_lazy_exponent_ramp(ops):
         check(outs[0].float().cpu().numpy(), ref, f"[causal={causal}]")
 
 
+def test_tail_first_tiling_is_bit_identical_and_matches_oracle(ops):
+    """Query tiles aligned to the end of each sequence (the partial tile is the first, cheapest one under the causal mask) against
+    the start-aligned tiling: same key tiles and the same arithmetic per query -> bit-identical outputs and log-sum-exps, for
+    ragged packings, both workgroup sizes, the two-stream form and a key sequence longer than the queries (bottom-right mask)."""
+    from visionselector_amd._native import debug_knob
+    lens = [300, 77, 513, 1200, 1, 129]
+    total = sum(lens)
+    q, k, v = make_qkv(total, 4, 2, 31, spike=True)
+    cu = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    cu_t = torch.from_numpy(cu).cuda()
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    ref = oattn.varlen_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu, causal=True)
+    for nw, split in ((4, 0), (8, 0), (0, 1)):
+        res = []
+        for tf in (0, 1):
+            with debug_knob("attn_tail_first", tf), debug_knob("attn_waves", nw), debug_knob("attn_split", split):
+                o = ops.varlen_attn(qc, kc, vc, cu_t, max(lens), causal=True)
+                o2, lse = ops.varlen_attn_fwd_lse(qc, kc, vc, cu_t, max(lens), causal=True)
+            res.append((o, o2, lse))
+        for a, b in zip(res[0], res[1]):
+            assert torch.equal(a, b)
+        if split == 0:
+            check(res[1][0].float().cpu().numpy(), ref, f"[nw={nw}]")
+    # chunked prefill against longer key sequences: queries are the LAST qlen positions of each key sequence
+    qlens, klens = [70, 200, 33], [300, 200, 1000]
+    qq, _, _ = make_qkv(sum(qlens), 4, 2, 32)
+    _, kk, vv = make_qkv(sum(klens), 4, 2, 33)
+    cq = torch.from_numpy(np.concatenate(([0], np.cumsum(qlens))).astype(np.int32)).cuda()
+    ck = torch.from_numpy(np.concatenate(([0], np.cumsum(klens))).astype(np.int32)).cuda()
+    outs = []
+    for tf in (0, 1):
+        with debug_knob("attn_tail_first", tf), debug_knob("attn_split", 0):
+            outs.append(ops.varlen_attn_kv(qq.cuda(), kk.cuda(), vv.cuda(), cq, ck, max(qlens), causal=True))
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_attention_transpose_read_equals_plain_reads(ops):
     """The ds_read_b64_tr_b16 V^T fragments and plain 16-bit column reads give bit-identical outputs."""
     from visionselector_amd._native import debug_knob

@@ -85,13 +85,15 @@ struct PagedKV {
 // halve the work of a wave per round and 64-query workgroups use 252 CUs.
 // launch bounds: two waves per SIMD for the 4- / 8-wave workgroups; the single-wave GQA-packed decode workgroup owns 32 KiB of
 // LDS by itself, so waves-per-SIMD is LDS-bound there (5 workgroups per CU ~ 1 per SIMD) and asking for 2 only drew a warning
-template <bool USE_TR, int NW, int D, bool PACK = false, int KVS = 1, int KH = 1>
+template <bool USE_TR, int NW, int D, bool PACK = false, int KVS = 1, int KH = 1, bool TAIL = false>
 __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                               const uint16_t* __restrict__ v,
                                                               const int32_t* __restrict__ cu, int hq, int hkv,
                                                               float scale_log2e, int causal, uint16_t* __restrict__ out,
                                                               int q_tiles, int n_seq, int slot, PagedKV pg,
                                                               float* __restrict__ lse) {
+  constexpr bool tail_first = TAIL;                // query tiles aligned to the END of each sequence (below)
+  static_assert(!TAIL || (!PACK && KVS == 1), "end-aligned query tiles: single-stream per-head form only");
   constexpr int GW = NW / KVS;                     // waves that share one K/V stream
   constexpr int QW = GW / KH;                      // ... of which QW own distinct 32-query slices (KH waves per slice)
   constexpr int kBlockQ = 32 * QW;
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
     seq = item / hkv;
     head = kvh * rep + (j % rep);                             // per lane
   } else {
-    qtile = q_tiles - 1 - item / (hq * n_seq);
+    qtile = item / (hq * n_seq);                               // counted from the END of the sequence: 0 = its last (heaviest) tile
     const int rest = item % (hq * n_seq);
     head = rest % hq;
     seq = rest / hq;
@@ -192,17 +194,33 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
   }
   const int qs = cu[seq];
   const int qlen = cu[seq + 1] - qs;
-  const int q0 = qtile * kBlockQ;
-  if (q0 >= qlen) continue;
+  // qtile counts from the END of the longest sequence (0 = heaviest).  Two tilings, bit-identical outputs (key tiles stay aligned
+  // to key 0 and a query's arithmetic does not depend on its tile):
+  //   start-aligned: tile t covers [t * kBlockQ, (t + 1) * kBlockQ); the PARTIAL tile of a sequence is its last one, i.e. the one
+  //     with the most key tiles under the causal mask (L / 64 rounds for a handful of queries);
+  //   tail_first: tiles aligned to the END of the sequence, [qlen - (t + 1) * kBlockQ, qlen - t * kBlockQ): the partial tile is the
+  //     first one (one or two key tiles), at the price of a diagonal that crosses one more key tile in every other tile -- about
+  //     one tile-round per query tile less in all.  Pays when the grid is throughput-bound (many items per workgroup: packed
+  //     batches of compressed sequences), not when one sequence's longest chain is the run time.
+  int q0, q_lim;                        // this tile's queries: [q0, min(q0 + kBlockQ, q_lim))
+  if constexpr (TAIL) {
+    q_lim = qlen - qtile * kBlockQ;
+    if (q_lim <= 0) continue;
+    q0 = max(0, q_lim - kBlockQ);
+  } else {
+    q_lim = qlen;
+    q0 = (PACK ? 0 : q_tiles - 1 - qtile) * kBlockQ;
+    if (q0 >= qlen) continue;
+  }
   // keys: same rows as the queries (prefill), or their own length / base / page table (KV cache).  Causal masking is
   // bottom-right aligned when the key sequence is longer: query i sees keys <= i + (klen - qlen)  (flash-attn >= 2.1).
   const int len = pg.seqlens_k ? pg.seqlens_k[seq] : qlen;
   const int shift = len - qlen;
   const int ks = pg.cu_k ? pg.cu_k[seq] : qs;
   const int vq = PACK ? j / rep : q0 + qw * 32 + j;           // this lane's query
-  const int my_q = min(vq, qlen - 1);                         // clamped: padding lanes replay the last query
-  const bool q_valid = vq < qlen;
-  const int wave_qmax = PACK ? qlen - 1 : min(q0 + qw * 32 + 31, qlen - 1);
+  const int my_q = min(vq, q_lim - 1);                        // clamped: padding lanes replay the tile's last query
+  const bool q_valid = vq < q_lim;
+  const int wave_qmax = PACK ? qlen - 1 : min(q0 + qw * 32 + 31, q_lim - 1);
   const int wave_qmin = PACK ? 0 : q0 + qw * 32;
 
   // Q^T fragments (B operand of S^T = K Q^T): lane (j, hh) holds q[my_q][16*step + 8*hh .. +7]
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
 
-  const int kv_end = causal ? max(0, min(len, (PACK ? qlen : q0 + kBlockQ) + shift)) : len;
+  const int kv_end = causal ? max(0, min(len, (PACK ? qlen : (TAIL ? q_lim : q0 + kBlockQ)) + shift)) : len;
   const int n_tiles = (kv_end + kTileK - 1) / kTileK;
   if (n_tiles <= 0) {     // no visible key for this whole q-tile (key sequence shorter than the query offset): zeros
     if (q_valid) {
@@ -297,7 +315,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
     // a wave whose 32 query slots are all padding (short q-tiles: decode, ragged tails) only helps with the loads
     // (KH = 2: the wave's own 32-key block must hold a visible key)
     const int kblk0 = t * kTileK + 32 * kh;
-    const bool wave_active = (wave_qmin < qlen) && (!causal || (kblk0 <= wave_qmax + shift)) && (KH == 1 || kblk0 < len);
+    const bool wave_active = (wave_qmin < q_lim) && (!causal || (kblk0 <= wave_qmax + shift)) && (KH == 1 || kblk0 < len);
     if (wave_active) {
       const char* kt = smem + CUR * kBuf;
       const char* vt = smem + (2 + CUR) * kBuf;
@@ -677,6 +695,12 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   }
   const dim3 grid((unsigned)std::min<int64_t>(n_items, slots));
   const float sl2 = scale * 1.4426950408889634f;
+  // query tiles aligned to the end of each sequence when the 4-wave grid is throughput-bound (more than two rounds of items): +4-5 %
+  // on packed batches of short / medium sequences (8 x 524, 32 x 524, 4 x 2368); -3 to -8 % when one sequence's longest chain is the
+  // run time; the 8-wave instantiation measured -3 % at 16 x 4096 (where both tilings are the same tiles) and +2 % at 16 x 2368, so
+  // it keeps the start-aligned tiling unless forced (same-box A/B, tools/ab_attn.sh)
+  const int g_tail = knob(VSEL_KNOB_ATTN_TAIL_FIRST);
+  const bool tail_first = causal && !pack && !split2 && d == 128 && g_attn_use_tr && (g_tail == 1 || (g_tail < 0 && !big && n_items > 2 * slots));
 #define VSEL_ATTN_LAUNCH(TR, NWV, DV)                                                                                          \
   hipLaunchKernelGGL((varlen_attn_fwd_kernel<TR, NWV, DV>), grid, dim3(64 * NWV), 0, st, (const uint16_t*)q, (const uint16_t*)k, \
                      (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg, lse)
@@ -692,7 +716,14 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
     hipLaunchKernelGGL((varlen_attn_fwd_kernel<true, 1, 128, true>), grid, dim3(64), 0, st, (const uint16_t*)q, (const uint16_t*)k,
                        (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg, lse);
   } else if (d == 128) {
-    if (g_attn_use_tr) {
+    if (g_attn_use_tr && tail_first) {
+#define VSEL_ATTN_LAUNCH_TAIL(NWV)                                                                                                  \
+  hipLaunchKernelGGL((varlen_attn_fwd_kernel<true, NWV, 128, false, 1, 1, true>), grid, dim3(64 * NWV), 0, st, (const uint16_t*)q, \
+                     (const uint16_t*)k, (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles,        \
+                     (int)n_seq, slot, pg, lse)
+      if (big) VSEL_ATTN_LAUNCH_TAIL(8); else VSEL_ATTN_LAUNCH_TAIL(4);
+#undef VSEL_ATTN_LAUNCH_TAIL
+    } else if (g_attn_use_tr) {
       if (big) VSEL_ATTN_LAUNCH(true, 8, 128); else VSEL_ATTN_LAUNCH(true, 4, 128);
     } else {
       if (big) VSEL_ATTN_LAUNCH(false, 8, 128); else VSEL_ATTN_LAUNCH(false, 4, 128);

@@ -112,17 +112,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
       __syncthreads();
     }
     if (item >= n_items) return;
-    const int qtile = q_tiles - 1 - item / (hq * n_seq);
+    const int t_end = item / (hq * n_seq);                       // query tile counted from the heaviest one
     const int rest = item % (hq * n_seq);
     const int head = rest % hq, seq = rest / hq;
     const int qs = cu[seq];
     const int len = cu[seq + 1] - qs;
-    const int q0 = qtile * 128;
-    if (q0 >= len) continue;
+    // Under the causal mask the query tiles are aligned to the END of the sequence, so that its partial tile is the first one
+    // (one or two key tiles) instead of the last (len / 64 of them for a handful of queries) -- attn.hip, TAIL; a query's
+    // arithmetic does not depend on its tile: bit-identical dQ.
+    int q0, q_lim;                                               // this tile's queries: [q0, min(q0 + 128, q_lim))
+    if (causal) {
+      q_lim = len - t_end * 128;
+      if (q_lim <= 0) continue;
+      q0 = max(0, q_lim - 128);
+    } else {
+      q_lim = len;
+      q0 = (q_tiles - 1 - t_end) * 128;
+      if (q0 >= len) continue;
+    }
     const int kvh = head / (hq / hkv);
-    const int my_q = min(q0 + wave * 32 + j, len - 1);
-    const bool q_valid = (q0 + wave * 32 + j) < len;
-    const int wave_qmax = min(q0 + wave * 32 + 31, len - 1);
+    const int my_q = min(q0 + wave * 32 + j, q_lim - 1);
+    const bool q_valid = (q0 + wave * 32 + j) < q_lim;
+    const int wave_qmax = min(q0 + wave * 32 + 31, q_lim - 1);
 
     u32x4 qf[8], dof[8];
     {
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
 
-    const int kv_end = causal ? min(len, q0 + 128) : len;
+    const int kv_end = causal ? q_lim : len;
     const int n_tiles = (kv_end + kTile - 1) / kTile;
     // K / V tiles go global -> LDS directly (global_load_lds_dwordx4), swizzle applied to the source address (see the
     // dK / dV kernel below); the mask is evaluated only on tiles that touch the causal diagonal or the end of the keys.

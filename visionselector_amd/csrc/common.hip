@@ -41,6 +41,7 @@ constexpr KnobSpec kKnobs[VSEL_KNOB_COUNT] = {
     {nullptr, -1, -1, 1},              // VSEL_KNOB_ATTN_BWD_SPLIT
     {"VSEL_SPLICE_FUSED", 1, 0, 1},    // VSEL_KNOB_LIS_SPLICE_FUSED
     {"VSEL_ATTN_BWD_WAVES", 8, 4, 8},  // VSEL_KNOB_ATTN_BWD_WAVES
+    {nullptr, -1, -1, 1},              // VSEL_KNOB_ATTN_TAIL_FIRST
 };
 int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 int knob_default(int id) {

@@ -123,6 +123,28 @@ def test_tail_first_tiling_is_bit_identical_and_matches_oracle(ops):
         with debug_knob("attn_tail_first", tf), debug_knob("attn_split", 0):
             outs.append(ops.varlen_attn_kv(qq.cuda(), kk.cuda(), vv.cuda(), cq, ck, max(qlens), causal=True))
     assert torch.equal(outs[0], outs[1])
+    # paged cache with scattered pages, chunked prefill / plain prefill / decode / a q > k sequence (leading rows see no key)
+    rng = np.random.default_rng(77)
+    hq, hkv, page = 8, 2, 16
+    qlens, klens = [70, 200, 1, 40, 300], [300, 200, 517, 25, 900]
+    pages_per = [-(-kl // page) for kl in klens]
+    perm = rng.permutation(sum(pages_per) + 3)
+    bt = np.zeros((len(qlens), max(pages_per)), np.int32)
+    cur = 0
+    for i, pp in enumerate(pages_per):
+        bt[i, :pp] = perm[cur:cur + pp]
+        cur += pp
+    f = lambda *sh: torch.from_numpy(rng.standard_normal(sh, dtype=np.float32)).bfloat16()  # noqa: E731
+    qp, kcache, vcache = f(sum(qlens), hq, 128), f(len(perm), page, hkv, 128), f(len(perm), page, hkv, 128)
+    cu_q = np.concatenate(([0], np.cumsum(qlens))).astype(np.int32)
+    outs = []
+    for tf in (0, 1):
+        with debug_knob("attn_tail_first", tf), debug_knob("attn_split", 0), debug_knob("attn_pack", 0):
+            outs.append(ops.paged_attn(qp.cuda(), kcache.cuda(), vcache.cuda(), torch.from_numpy(cu_q).cuda(),
+                                       torch.tensor(klens, dtype=torch.int32).cuda(), torch.from_numpy(bt).cuda(), max(qlens), causal=True))
+    assert torch.equal(outs[0], outs[1])
+    refp = oattn.paged_attention(qp.float().numpy(), kcache.float().numpy(), vcache.float().numpy(), cu_q, np.array(klens), bt, causal=True)
+    check(outs[1].float().cpu().numpy().astype(np.float64), refp, "[paged]")
 
 
 def test_attention_transpose_read_equals_plain_reads(ops):

@@ -92,7 +92,6 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
                                                               float scale_log2e, int causal, uint16_t* __restrict__ out,
                                                               int q_tiles, int n_seq, int slot, PagedKV pg,
                                                               float* __restrict__ lse) {
-  constexpr bool tail_first = TAIL;                // query tiles aligned to the END of each sequence (below)
   static_assert(!TAIL || (!PACK && KVS == 1), "end-aligned query tiles: single-stream per-head form only");
   constexpr int GW = NW / KVS;                     // waves that share one K/V stream
   constexpr int QW = GW / KH;                      // ... of which QW own distinct 32-query slices (KH waves per slice)
@@ -198,7 +197,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
   // to key 0 and a query's arithmetic does not depend on its tile):
   //   start-aligned: tile t covers [t * kBlockQ, (t + 1) * kBlockQ); the PARTIAL tile of a sequence is its last one, i.e. the one
   //     with the most key tiles under the causal mask (L / 64 rounds for a handful of queries);
-  //   tail_first: tiles aligned to the END of the sequence, [qlen - (t + 1) * kBlockQ, qlen - t * kBlockQ): the partial tile is the
+  //   TAIL: tiles aligned to the END of the sequence, [qlen - (t + 1) * kBlockQ, qlen - t * kBlockQ): the partial tile is the
   //     first one (one or two key tiles), at the price of a diagonal that crosses one more key tile in every other tile -- about
   //     one tile-round per query tile less in all.  Pays when the grid is throughput-bound (many items per workgroup: packed
   //     batches of compressed sequences), not when one sequence's longest chain is the run time.

@@ -205,6 +205,45 @@ def test_lis_ragged_segments(ops):
         oo += k
 
 
+def test_segment_sum_sweep_is_bit_identical(ops):
+    """Many (segment, column slab) pairs: sweep 1 runs as colsum_seg_kernel -- one wave streams a segment slab and adds its 128-row
+    chunks up itself, no per-chunk partials (knob lis_seg_sums: from how many pairs; 1 = whenever the batched form runs, 0 = never).
+    Scores, indices and rows must equal the per-chunk form's BIT FOR BIT, and each segment those of a separate call (small-batch
+    form): ragged lengths incl. 1 / 128 / 129 rows, bf16 and fp32 tokens, a uniform batch, the presummed entry untouched."""
+    from visionselector_amd._native import debug_knob
+    d, hd = 1024, 512
+    rng = np.random.default_rng(5)
+    lens = [int(x) for x in rng.integers(100, 700, 40)]
+    lens[3], lens[10], lens[20] = 128, 129, 1
+    ks = [max(1, n // 5) for n in lens]
+    c = oin.make_case(d, hd, sum(lens), 44)
+    for dt in (torch.bfloat16, torch.float32):
+        h, wq, bq, wk, bk = (dev(c[x], dt) for x in ("h", "wq", "bq", "wk", "bk"))
+        res = []
+        for mn in (0, 1):
+            with debug_knob("lis_seg_sums", mn):
+                res.append(ops.lis_select_varlen(h, lens, ks, wq, bq, wk, bk))
+        for a_, b_ in zip(res[0], res[1]):
+            assert torch.equal(a_, b_)
+        out, idx, scores = res[1]
+        ro = oo = 0
+        for j, (n, k) in enumerate(zip(lens, ks)):
+            if j in (3, 10, 20) or j < 6:                    # a sample of segments (all the edge lengths) against separate calls
+                o1, i1, s1 = ops.lis_select(h[ro:ro + n][None].contiguous(), wq, bq, wk, bk, k)
+                assert torch.equal(scores[ro:ro + n], s1[0]) and torch.equal(idx[oo:oo + k], i1[0]) and torch.equal(out[oo:oo + k], o1[0])
+            ro += n
+            oo += k
+    c2 = oin.make_case(d, hd, 24 * 300, 45)
+    h, wq, bq, wk, bk = (dev(c2[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    hb = h.view(24, 300, d)
+    res = []
+    for mn in (0, 1):
+        with debug_knob("lis_seg_sums", mn):
+            res.append(ops.lis_select(hb, wq, bq, wk, bk, 60) + (ops.lis_scores(hb, wq, bq, wk, bk),))
+    for a_, b_ in zip(res[0], res[1]):
+        assert torch.equal(a_, b_)
+
+
 def test_near_zero_init_edge_case(ops):
     """The shipped init (std 1e-4, zero bias) gives scores ~1e-5: still selects exactly what its own scores say."""
     c = oin.make_case(2048, 1024, 576, 3, near_zero_init=True)

@@ -144,6 +144,96 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   VSEL_STAMP_DRAIN(0, 2);
 }
 
+// K1 for many segments: ONE WAVE owns a (segment, 64-lane column slab), streams it from the first row to the last and plays the
+// four waves of colsum_partial_kernel itself -- accumulator set w takes rows w, w + 4, ... of each 128-row chunk, four rows at a
+// time ((acc + v0) + v1) + (v2 + v3), the last < 4 one by one; per chunk (set 0 + set 1) + (set 2 + set 3); across chunks the
+// finish kernels' order (acc = 0; acc += chunk 0, 1, ...).  The segment's sums therefore come out bit-identical to partials +
+// finish, with no LDS, no barrier and no [S][chunks][D] partial round trip.  Why it pays (B = 128, 7B geometry, same-box numbers in
+// DESIGN.md section 5): the chunked form is 16 128 short workgroups that each end in a cross-wave reduction behind a barrier and
+// write 33 MB of partials in 2-KiB pieces into the read stream -- 335-360 us; without the epilogue and the stores the same loads
+// take 306-313 us; this kernel reads the tensor in ~301 us, a little under the score sweep.  The four waves of a workgroup take
+// four ADJACENT slabs of the same rows.  32 rows (32 x 16 B per lane) in flight per wave.  Output: sums[s][col] = the finish
+// kernels' input with row_splits = 1.  grid ceil(col_tiles * n_seg / 4), block 256 (four independent waves).  One wave streams a
+// whole segment slab, so this needs many (segment, slab) pairs -- seg_sums_form() below.
+template <typename T, bool NT>
+__global__ __launch_bounds__(256) void colsum_seg_kernel(const T* __restrict__ h, SegView sv, int d, int col_tiles, int n_seg,
+                                                         float* __restrict__ sums) {
+  constexpr int V = Elem<T>::kVec;
+  const int lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);         // (segment, slab), wave-uniform
+  if (unit >= col_tiles * n_seg) return;
+  const int s = unit / col_tiles;
+  const int col = ((unit - s * col_tiles) * 64 + lane) * V;
+  const int n = sv.n_rows(s);
+  const int64_t r0 = sv.row_begin(s);
+  const bool col_ok = col < d;
+  const T* base = h + (r0 * (int64_t)d + (col_ok ? col : 0));
+  auto ldraw = [](const T* p) -> u32x4 {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    else return *reinterpret_cast<const u32x4*>(p);
+  };
+  float tot[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) tot[i] = 0.f;
+  // (chunks past the segment's end, which the chunked form adds as exact zeros, are skipped: tot + 0.0f == tot, and tot is never
+  // -0.0f because it starts from +0.0f)
+  for (int rb = 0; rb < n; rb += kRowsPerChunk) {
+    const int re = min(n, rb + kRowsPerChunk);
+    float acc[4][V];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc[w][i] = 0.f;
+    int b = rb;
+    for (; b + 31 < re; b += 32) {                                // every set has two full four-row steps in rows b .. b + 31
+      u32x4 x[32];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) x[q] = ldraw(base + (int64_t)(b + q) * d);
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          float v0[V], v1[V], v2[V], v3[V];
+          unpack_vec<T>(x[16 * half + w], v0);
+          unpack_vec<T>(x[16 * half + w + 4], v1);
+          unpack_vec<T>(x[16 * half + w + 8], v2);
+          unpack_vec<T>(x[16 * half + w + 12], v3);
+#pragma unroll
+          for (int i = 0; i < V; ++i) acc[w][i] = ((acc[w][i] + v0[i]) + v1[i]) + (v2[i] + v3[i]);
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {                                  // the segment's last, partial chunk: set by set
+      int r = b + w;
+      for (; r + 12 < re; r += 16) {
+        float v0[V], v1[V], v2[V], v3[V];
+        unpack_vec<T>(ldraw(base + (int64_t)r * d), v0);
+        unpack_vec<T>(ldraw(base + (int64_t)(r + 4) * d), v1);
+        unpack_vec<T>(ldraw(base + (int64_t)(r + 8) * d), v2);
+        unpack_vec<T>(ldraw(base + (int64_t)(r + 12) * d), v3);
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[w][i] = ((acc[w][i] + v0[i]) + v1[i]) + (v2[i] + v3[i]);
+      }
+      for (; r < re; r += 4) {
+        float v0[V];
+        unpack_vec<T>(ldraw(base + (int64_t)r * d), v0);
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[w][i] += v0[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) tot[i] += (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+  }
+  if (col_ok) {
+    float* dst = sums + ((int64_t)s * d + col);
+#pragma unroll
+    for (int i = 0; i < V; i += 4) {
+      f32x4 o = {tot[i], tot[i + 1], tot[i + 2], tot[i + 3]};
+      *reinterpret_cast<f32x4*>(dst + i) = o;
+    }
+  }
+}
+
 // K1b  xbar[s][c] = sum_rs partial[s][rs][c] / N_s   (fixed order)
 static __attribute__((unused)) __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, SegView sv, int d,
                                                             int row_splits, float* __restrict__ xbar) {
@@ -821,10 +911,31 @@ inline int launch_score(hipStream_t st, const T* h, const SegView& sv, const vse
   return VSEL_OK;
 }
 
+// sweep 1 as colsum_seg_kernel (the segments' sums, one "chunk") instead of per-chunk partials: from knob LIS_SEG_SUMS (segment,
+// slab) pairs = waves (default 640: B >= 92 at the 7B geometry; measured B = 64 483 vs 442 us per call, 96 649 vs 670, 128 831 vs
+// 858; 0 = never), never for the <= 8 segments the small-batch form may take (its kernels rebuild x-bar from chunk partials), more
+// than one chunk, 16-byte column vectors, and no segment far longer than the average (its waves would finish last).  Same sums
+// bit for bit either way: batch invariance is untouched.
+inline bool seg_sums_form(const LisPlan& p, const vsel_segments* seg) {
+  const int mn = knob(VSEL_KNOB_LIS_SEG_SUMS);
+  // (pairs counted as for bf16 tokens, 512 columns per slab, whatever the token type: the projection stage does not know it)
+  return mn > 0 && p.S > 8 && p.S * cdiv(p.d, 512) >= mn && p.row_splits > 1 && p.d % 8 == 0 && seg->total_rows * 2 >= p.S * p.maxn;
+}
+
 template <typename T>
 inline int launch_colsum(hipStream_t st, const T* h, const SegView& sv, int d, int S, int row_splits, float* partial,
-                         int64_t total_rows) {
+                         int64_t total_rows, bool seg_sums = false) {
   constexpr int V = Elem<T>::kVec;
+  if (seg_sums) {
+    const int col_tiles = (int)cdiv(d, 64 * V);
+    const dim3 g2((unsigned)cdiv((int64_t)col_tiles * S, 4));
+    if (stream_policy(total_rows, d, sizeof(T)))
+      hipLaunchKernelGGL((colsum_seg_kernel<T, true>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial);
+    else
+      hipLaunchKernelGGL((colsum_seg_kernel<T, false>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial);
+    VSEL_AFTER_LAUNCH(st, "colsum_partial_kernel");
+    return VSEL_OK;
+  }
   const dim3 grid((unsigned)cdiv(d, 64 * V), row_splits, S);
   if ((int64_t)grid.x * grid.y * grid.z <= 1024)       // <= one workgroup per SIMD-quad: latency-bound, use the deep form
     hipLaunchKernelGGL((colsum_partial_kernel<T, false, true>), grid, dim3(256), 0, st, h, sv, d, row_splits, partial);
@@ -839,7 +950,8 @@ inline int launch_colsum(hipStream_t st, const T* h, const SegView& sv, int d, i
 // stage 1: sweep 1 (column-sum partials)
 template <typename T>
 inline int run_colsum(hipStream_t st, const T* h, const vsel_segments* seg, int d, char* ws, const LisPlan& p) {
-  return launch_colsum<T>(st, h, make_view(seg), d, (int)seg->n_seg, p.row_splits, (float*)(ws + p.off_partial), seg->total_rows);
+  return launch_colsum<T>(st, h, make_view(seg), d, (int)seg->n_seg, p.row_splits, (float*)(ws + p.off_partial), seg->total_rows,
+                          seg_sums_form(p, seg));
 }
 
 // stage 2: partials -> xbar -> kbar -> (w, c)   (small, latency-bound kernels)
@@ -851,7 +963,7 @@ inline int run_proj(hipStream_t st, const vsel_segments* seg, const vsel_scorer*
   const SegView sv = make_view(seg);
   const int d = (int)sc->d, hd = (int)sc->hd, S = (int)seg->n_seg;
   LisPlan p = p_in;
-  if (col_sums) p.row_splits = 1;
+  if (col_sums || seg_sums_form(p_in, seg)) p.row_splits = 1;     // the producer's column sums / colsum_seg_kernel's: one "chunk"
   const float* partial = col_sums ? col_sums : (const float*)(ws + p.off_partial);
   float* xbar = (float*)(ws + p.off_xbar);
   float* part1 = (float*)(ws + p.off_part1);

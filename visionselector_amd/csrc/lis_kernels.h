@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 // whole segment slab, so this needs many (segment, slab) pairs -- seg_sums_form() below.
 template <typename T, bool NT>
 __global__ __launch_bounds__(256) void colsum_seg_kernel(const T* __restrict__ h, SegView sv, int d, int col_tiles, int n_seg,
-                                                         float* __restrict__ sums) {
+                                                         float* __restrict__ sums, uint16_t* __restrict__ xs) {
   constexpr int V = Elem<T>::kVec;
   const int lane = threadIdx.x & 63;
   const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);         // (segment, slab), wave-uniform
@@ -230,6 +230,31 @@ __global__ __launch_bounds__(256) void colsum_seg_kernel(const T* __restrict__ h
     for (int i = 0; i < V; i += 4) {
       f32x4 o = {tot[i], tot[i + 1], tot[i + 2], tot[i + 3]};
       *reinterpret_cast<f32x4*>(dst + i) = o;
+    }
+    if (xs) {
+      // ... and x-bar = sums / N split into the three bf16 planes of the MFMA projections, fragment-major: what
+      // colsum_finish_split_kernel would compute from the sums ((0 + sum) / N, the same bits), one launch less
+      const float fn = (float)n;
+      const int mt = (n_seg + 31) >> 5, ksteps = d >> 4;
+      // (a lane's V columns are the consecutive elements e of ONE fragment row: one 16- / 8-byte store per plane)
+      uint32_t bits[3][V];
+#pragma unroll
+      for (int i = 0; i < V; ++i) split3((0.f + tot[i]) / fn, bits[0][i], bits[1][i], bits[2][i]);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        uint16_t* dstp = xs + frag_off(pl, s, col, mt, ksteps);
+        if constexpr (V == 8) {
+          u32x4 pk;
+#pragma unroll
+          for (int z = 0; z < 4; ++z) pk[z] = bits[pl][2 * z] | (bits[pl][2 * z + 1] << 16);
+          *reinterpret_cast<u32x4*>(dstp) = pk;
+        } else {
+          uint2 pk;
+          pk.x = bits[pl][0] | (bits[pl][1] << 16);
+          pk.y = bits[pl][2] | (bits[pl][3] << 16);
+          *reinterpret_cast<uint2*>(dstp) = pk;
+        }
+      }
     }
   }
 }
@@ -924,15 +949,15 @@ inline bool seg_sums_form(const LisPlan& p, const vsel_segments* seg) {
 
 template <typename T>
 inline int launch_colsum(hipStream_t st, const T* h, const SegView& sv, int d, int S, int row_splits, float* partial,
-                         int64_t total_rows, bool seg_sums = false) {
+                         int64_t total_rows, bool seg_sums = false, uint16_t* xs = nullptr) {
   constexpr int V = Elem<T>::kVec;
   if (seg_sums) {
     const int col_tiles = (int)cdiv(d, 64 * V);
     const dim3 g2((unsigned)cdiv((int64_t)col_tiles * S, 4));
     if (stream_policy(total_rows, d, sizeof(T)))
-      hipLaunchKernelGGL((colsum_seg_kernel<T, true>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial);
+      hipLaunchKernelGGL((colsum_seg_kernel<T, true>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial, xs);
     else
-      hipLaunchKernelGGL((colsum_seg_kernel<T, false>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial);
+      hipLaunchKernelGGL((colsum_seg_kernel<T, false>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial, xs);
     VSEL_AFTER_LAUNCH(st, "colsum_partial_kernel");
     return VSEL_OK;
   }
@@ -951,7 +976,7 @@ inline int launch_colsum(hipStream_t st, const T* h, const SegView& sv, int d, i
 template <typename T>
 inline int run_colsum(hipStream_t st, const T* h, const vsel_segments* seg, int d, char* ws, const LisPlan& p) {
   return launch_colsum<T>(st, h, make_view(seg), d, (int)seg->n_seg, p.row_splits, (float*)(ws + p.off_partial), seg->total_rows,
-                          seg_sums_form(p, seg));
+                          seg_sums_form(p, seg), p.mfma_bf16 ? (uint16_t*)(ws + p.off_xs) : nullptr);
 }
 
 // stage 2: partials -> xbar -> kbar -> (w, c)   (small, latency-bound kernels)
@@ -977,9 +1002,11 @@ inline int run_proj(hipStream_t st, const vsel_segments* seg, const vsel_scorer*
       uint16_t* xs = (uint16_t*)(ws + p.off_xs);
       uint16_t* ksp = (uint16_t*)(ws + p.off_ksp);
       float* cpart = (float*)(ws + p.off_cpart);
-      hipLaunchKernelGGL(colsum_finish_split_kernel, dim3((unsigned)cdiv(d, 256), S), dim3(256), 0, st, partial, sv, d,
-                         p.row_splits, S, xs);
-      VSEL_AFTER_LAUNCH(st, "colsum_finish_split_kernel");
+      if (col_sums || !seg_sums_form(p_in, seg)) {       // (colsum_seg_kernel leaves the planes itself)
+        hipLaunchKernelGGL(colsum_finish_split_kernel, dim3((unsigned)cdiv(d, 256), S), dim3(256), 0, st, partial, sv, d,
+                           p.row_splits, S, xs);
+        VSEL_AFTER_LAUNCH(st, "colsum_finish_split_kernel");
+      }
       const unsigned mtiles = (unsigned)cdiv(S, 32);
       const int m_pad = 32 * (int)mtiles;
       hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, dim3((unsigned)cdiv(hd, 64), mtiles, p.ks1), dim3(64), 0, st, xs,

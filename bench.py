@@ -41,6 +41,7 @@ def kernel_bytes(name, b, n, d, hd, k, e=2):
     """Algorithmic bytes of ONE launch of a named kernel ('kernels')."""
     return {
         "colsum_partial_kernel": b * n * d * e,                    # first sweep of the tokens
+        "colsum_seg_kernel": b * n * d * e,                        # ... in its many-segments form (one wave per image slab)
         "score_kernel": b * n * d * e + b * n * 4,                 # second sweep + scores out
         "gather_rows_kernel": 2 * b * k * d * e + b * k * 8,       # read kept rows + write them
         # small-batch form (csrc/lis_small.h)

@@ -15,4 +15,4 @@ for mode in ("scores_only", "select"):
     for _ in range(10): f()
     torch.cuda.synchronize()
     p = _native.profile_stop()
-    print(b, mode, {kk: round(v[0] / v[1] * 1e3, 1) for kk, v in p.items() if "colsum_partial" in kk or "score" in kk or "gather" in kk})
+    print(b, mode, {kk: round(v[0] / v[1] * 1e3, 1) for kk, v in p.items() if "colsum_" in kk or "score" in kk or "gather" in kk})

@@ -36,7 +36,7 @@ def run(name, step, gap_us=0):
     torch.cuda.synchronize()
     p = _native.profile_stop()
     t = {kk.split("<")[0].replace("vsel::", ""): round(v[0] / v[1] * 1e3, 1) for kk, v in p.items()
-         if any(s in kk for s in ("colsum_partial", "score_kernel", "gather_rows"))}
+         if any(s in kk for s in ("colsum_partial", "colsum_seg", "score_kernel", "gather_rows"))}
     print(f"{name:44s} step {e0.elapsed_time(e1) / 12 * 1e3 - gap_us:7.1f} us (gap excluded)  {t}")
 
 

@@ -958,7 +958,7 @@ inline int launch_colsum(hipStream_t st, const T* h, const SegView& sv, int d, i
       hipLaunchKernelGGL((colsum_seg_kernel<T, true>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial, xs);
     else
       hipLaunchKernelGGL((colsum_seg_kernel<T, false>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial, xs);
-    VSEL_AFTER_LAUNCH(st, "colsum_partial_kernel");
+    VSEL_AFTER_LAUNCH(st, "colsum_seg_kernel");
     return VSEL_OK;
   }
   const dim3 grid((unsigned)cdiv(d, 64 * V), row_splits, S);

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
   char* const k_sm = smem;
   char* const v_sm = smem + 2 * kTileB;
   const int n_items = q_tiles * hq * n_seq;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
   const float sl2 = scale * kLog2e;
   // per-lane LDS byte offsets inside a tile; the buffer, the 32-key block and the 16-row step add immediates
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
       item = s_item;
       __syncthreads();
     }
+    item = __builtin_amdgcn_readfirstlane(item);       // (uniform by construction: lets the per-item / per-tile address arithmetic run on the scalar ALU)
     if (item >= n_items) return;
     const int t_end = item / (hq * n_seq);                       // query tile counted from the heaviest one
     const int rest = item % (hq * n_seq);
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
   char* const do_sm = smem + 2 * kTileB;
   const int heads_per_item_dim = SPLIT ? hq : hkv;
   const int n_items = k_blocks * heads_per_item_dim * n_seq;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
   const float sl2 = scale * kLog2e;
   const int rep = hq / hkv;
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
       item = s_item;
       __syncthreads();
     }
+    item = __builtin_amdgcn_readfirstlane(item);       // (uniform by construction: lets the per-item / per-tile address arithmetic run on the scalar ALU)
     if (item >= n_items) return;
     const int kblock = item / (heads_per_item_dim * n_seq);   // block 0 first: under the causal mask it is seen by the most queries
     const int rest = item % (heads_per_item_dim * n_seq);
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
   int& s_item = *reinterpret_cast<int*>(smem + 2 * kKV + 4 * kTileB + 4 * kTile * sizeof(float));
   const int heads_per_item_dim = SPLIT ? hq : hkv;
   const int n_items = k_blocks * heads_per_item_dim * n_seq;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kb = wave & 3, qh = wave >> 2;
   // the second-dispatched half loses every issue arbitration against its SIMD partners; one static priority bump (no per-phase
   // flips) takes 0.5-1.4 % off the kernel (same-box A/B, MI355X_MICROARCH.md: static priority for the younger half)
@@ -548,6 +550,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
       item = s_item;
       __syncthreads();
     }
+    item = __builtin_amdgcn_readfirstlane(item);       // (uniform by construction: lets the per-item / per-tile address arithmetic run on the scalar ALU)
     if (item >= n_items) return;
     const int kblock = item / (heads_per_item_dim * n_seq);
     const int rest = item % (heads_per_item_dim * n_seq);
@@ -564,6 +567,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int ld_part = slice_src_part(lane, wave) * 8;
+    const uint32_t lane_off_q = (uint32_t)(((lane >> 4) * hq * kD + ld_part) * 2);     // bytes from a slice's first row, this lane
+    const int64_t slice_step_q = (int64_t)32 * hq * kD * 2;                             // bytes from slice i to slice i + 8
     {
       // the item's K / V tiles: 32 one-KiB slices each, wave w issues slices w, w + 8, w + 16, w + 24 (source-swizzled)
 #pragma unroll
@@ -586,13 +591,29 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
     const int n_iter = SPLIT ? tiles_per_head : tiles_per_head * rep;
     int ld_qt = q_begin, ld_head = SPLIT ? hsel : kvh * rep;
     auto load_tile = [&](int buf) {
+      if (ld_qt + kTile <= len) {
+        // full tile: a wave-uniform 64-bit row base on the scalar ALU plus the per-lane 32-bit offset computed once per item
+        // (the clamped form below costs every load its own min and 64-bit multiply on the vector ALU -- attn.hip, load_kv)
+        const int64_t row0 = ((int64_t)(qs + ld_qt + 4 * wave) * hq + ld_head) * kD;
+        const char* qp = reinterpret_cast<const char*>(q + row0);
+        const char* dp = reinterpret_cast<const char*>(dout + row0);
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int i = wave + 8 * u;
-        const int qpos = min(ld_qt + 4 * i + (lane >> 4), len - 1);
-        const int64_t off = ((int64_t)(qs + qpos) * hq + ld_head) * kD + ld_part;
-        __builtin_amdgcn_global_load_lds((gptr_t)(q + off), (lptr_t)(q_sm + buf * kTileB + i * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(dout + off), (lptr_t)(do_sm + buf * kTileB + i * 1024), 16, 0, 0);
+        for (int u = 0; u < 2; ++u) {
+          const int i = wave + 8 * u;
+          __builtin_amdgcn_global_load_lds((gptr_t)(qp + lane_off_q), (lptr_t)(q_sm + buf * kTileB + i * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gptr_t)(dp + lane_off_q), (lptr_t)(do_sm + buf * kTileB + i * 1024), 16, 0, 0);
+          qp += slice_step_q;
+          dp += slice_step_q;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = wave + 8 * u;
+          const int qpos = min(ld_qt + 4 * i + (lane >> 4), len - 1);
+          const int64_t off = ((int64_t)(qs + qpos) * hq + ld_head) * kD + ld_part;
+          __builtin_amdgcn_global_load_lds((gptr_t)(q + off), (lptr_t)(q_sm + buf * kTileB + i * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gptr_t)(dout + off), (lptr_t)(do_sm + buf * kTileB + i * 1024), 16, 0, 0);
+        }
       }
       if (wave < 2) {
         const int64_t o = (int64_t)(qs + min(ld_qt + lane, len - 1)) * hq + ld_head;

@@ -532,6 +532,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
   make_tr_addr<4>(tr_addr, lane);
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) { tr_addr[dt][0] += qh * 32 * kRowB; tr_addr[dt][1] += qh * 32 * kRowB; }
+  uint32_t tr_u[4][2];                                           // LDS byte addresses of the per-lane bases (for the asm reads)
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {      // (based at the Q / dO area: the 16-bit ds offset field then reaches both tensors' buffers)
+    tr_u[dt][0] = lds_u32(smem) + 2 * kKV + tr_addr[dt][0];
+    tr_u[dt][1] = lds_u32(smem) + 2 * kKV + tr_addr[dt][1];
+  }
   const int q_row = perm_row(j) + 32 * qh;                       // A fragment row of the wave's own 32-query half
   const int q_base = q_row * kRowB, q_x = (swz(q_row) ^ hh) << 4;
   const int kv_row = 32 * kb + j;                                // B fragment: key kw0 + j, features 16 st + 8 hh .. + 7
@@ -683,21 +689,39 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
           }
         }
         VSEL_BWD_STAMP(2);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
-            const int off = 16 * m * kRowB;
-            const bf16x4_t d_lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dotile + tr_addr[dt][0] + off));
-            const bf16x4_t d_hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dotile + tr_addr[dt][1] + off));
-            const bf16x4_t q_lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(qtile + tr_addr[dt][0] + off));
-            const bf16x4_t q_hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(qtile + tr_addr[dt][1] + off));
-            dva[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(d_lo, d_hi, 0, 1, 2, 3, 4, 5, 6, 7), pf[m],
-                                                              dva[dt], 0, 0, 0);
-            dka[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(q_lo, q_hi, 0, 1, 2, 3, 4, 5, 6, 7), dsf[m],
-                                                              dka[dt], 0, 0, 0);
-          }
+        // The transposed dO / Q fragments are read from inline asm, a group (16-query half m, d-tile dt) = 4 reads feeding 2 MFMAs,
+        // the next group in flight behind the current one's MFMAs, counted lgkmcnt waits.  With the read BUILTIN hipcc puts
+        // `s_waitcnt vmcnt(0)` in front of the first transposed read of every tile (the trap attn.hip documents): the direct-to-LDS
+        // prefetch of the NEXT tile, issued at the top of this one, was drained HERE, with only the S / dP and P / dS phases to
+        // cover its ~2 us, instead of at the barrier a whole tile later.
+        {
+          constexpr int kQOff = CUR * kTileB, kDoOff = 2 * kTileB + CUR * kTileB;      // relative to the Q / dO area (tr_u)
+          auto issue = [&](auto g_c, u32x2 (&dst)[4]) __attribute__((always_inline)) {
+            constexpr int G = decltype(g_c)::value, M = G >> 2, DT = G & 3;
+            dst[0] = lds_read_tr16_b64_asm<kDoOff + 16 * M * kRowB>(tr_u[DT][0]);
+            dst[1] = lds_read_tr16_b64_asm<kDoOff + 16 * M * kRowB>(tr_u[DT][1]);
+            dst[2] = lds_read_tr16_b64_asm<kQOff + 16 * M * kRowB>(tr_u[DT][0]);
+            dst[3] = lds_read_tr16_b64_asm<kQOff + 16 * M * kRowB>(tr_u[DT][1]);
+          };
+          auto fma2 = [&](auto g_c, u32x2 (&src)[4]) __attribute__((always_inline)) {
+            constexpr int G = decltype(g_c)::value, M = G >> 2, DT = G & 3;
+            const u32x4 wd = {src[0][0], src[0][1], src[1][0], src[1][1]};
+            const u32x4 wq = {src[2][0], src[2][1], src[3][0], src[3][1]};
+            dva[DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wd), pf[M], dva[DT], 0, 0, 0);
+            dka[DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wq), dsf[M], dka[DT], 0, 0, 0);
+          };
+          u32x2 ra[4], rb[4];
+          issue(std::integral_constant<int, 0>{}, ra);
+          issue(std::integral_constant<int, 1>{}, rb);
+          lds_wait4<4>(ra); fma2(std::integral_constant<int, 0>{}, ra); issue(std::integral_constant<int, 2>{}, ra);
+          lds_wait4<4>(rb); fma2(std::integral_constant<int, 1>{}, rb); issue(std::integral_constant<int, 3>{}, rb);
+          lds_wait4<4>(ra); fma2(std::integral_constant<int, 2>{}, ra); issue(std::integral_constant<int, 4>{}, ra);
+          lds_wait4<4>(rb); fma2(std::integral_constant<int, 3>{}, rb); issue(std::integral_constant<int, 5>{}, rb);
+          lds_wait4<4>(ra); fma2(std::integral_constant<int, 4>{}, ra); issue(std::integral_constant<int, 6>{}, ra);
+          lds_wait4<4>(rb); fma2(std::integral_constant<int, 5>{}, rb); issue(std::integral_constant<int, 7>{}, rb);
+          lds_wait4<4>(ra); fma2(std::integral_constant<int, 6>{}, ra);
+          lds_wait4<0>(rb); fma2(std::integral_constant<int, 7>{}, rb);
+        }
         VSEL_BWD_STAMP(3);
       }
       qt += kTile;

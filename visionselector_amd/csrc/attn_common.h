@@ -117,6 +117,11 @@ __device__ __forceinline__ void lds_wait4(u32x4 (&a)[4]) {
   __builtin_amdgcn_sched_barrier(0);
 }
 template <int N>
+__device__ __forceinline__ void lds_wait4(u32x2 (&a)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N));
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int N>
 __device__ __forceinline__ void lds_wait8(u32x2 (&a)[8]) {
   asm volatile("s_waitcnt lgkmcnt(%8)"
                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])

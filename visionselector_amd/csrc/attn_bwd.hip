@@ -519,9 +519,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
   const int n_items = k_blocks * heads_per_item_dim * n_seq;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kb = wave & 3, qh = wave >> 2;
-  // the second-dispatched half loses every issue arbitration against its SIMD partners; one static priority bump (no per-phase
-  // flips) takes 0.5-1.4 % off the kernel (same-box A/B, MI355X_MICROARCH.md: static priority for the younger half)
-  if (qh == 1) __builtin_amdgcn_s_setprio(1);
   const int j = lane & 31, hh = lane >> 5;
   const float sl2 = scale * kLog2e;
   const int rep = hq / hkv;
@@ -657,6 +654,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf, s, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf, dp, 0, 0, 0);
         }
+        // Priority by phase: 1 through the two MFMA phases, 0 through the P / dS arithmetic.  The two waves of a SIMD then take turns --
+        // the one feeding the matrix pipe wins the issue arbitration over its partner's VALU work -- instead of one wave winning
+        // every phase (whichever half is older or statically raised finished ~1000 cycles early and waited at the barrier).
+        // Same-box A/B: dK/dV kernel -1.6 % against a static bump of the second-dispatched half, -2.5 % against none.
+        __builtin_amdgcn_s_setprio(0);
         VSEL_BWD_STAMP(1);
         bf16x8_t pf[2], dsf[2];
 #pragma unroll
@@ -688,6 +690,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
             }
           }
         }
+        __builtin_amdgcn_s_setprio(1);
         VSEL_BWD_STAMP(2);
         // The transposed dO / Q fragments are read from inline asm, a group (16-query half m, d-tile dt) = 4 reads feeding 2 MFMAs,
         // the next group in flight behind the current one's MFMAs, counted lgkmcnt waits.  With the read BUILTIN hipcc puts

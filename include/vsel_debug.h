@@ -37,8 +37,9 @@ typedef enum vsel_debug_knob {
                                      across wave pairs, K/V fragments from LDS); deterministic either way, fp32 association differs */
   VSEL_KNOB_ATTN_TAIL_FIRST = 11, /* query tiles aligned to the END of each sequence (the partial tile is the cheap first one): -1 when
                                      the grid is throughput-bound (default), 0 / 1 force; bit-identical outputs */
-  VSEL_KNOB_LIS_SEG_SUMS = 12,    /* sweep 1 by one wave per (segment, 512-column slab), no per-chunk partials, from this many such pairs
-                                     (default 640, 0 = never; env VSEL_SEG_SUMS); bit-identical sums */
+  VSEL_KNOB_LIS_SEG_SUMS = 12,    /* sweep 1 by one wave per (segment, column slab), no per-chunk partials: the widest slab (512 / 256 / 128
+                                     bf16 columns) that gives this many pairs, else the chunked form (default 896, 0 = never; env
+                                     VSEL_SEG_SUMS); bit-identical sums */
   VSEL_KNOB_COUNT = 13
 } vsel_debug_knob;
 

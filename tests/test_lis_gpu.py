@@ -220,11 +220,12 @@ def test_segment_sum_sweep_is_bit_identical(ops):
     for dt in (torch.bfloat16, torch.float32):
         h, wq, bq, wk, bk = (dev(c[x], dt) for x in ("h", "wq", "bq", "wk", "bk"))
         res = []
-        for mn in (0, 1):
+        for mn in (0, 1, 100, 200):          # chunked form; 16- / 8- / 4-byte loads per lane (2 / 4 / 8 slabs of the 1024 columns)
             with debug_knob("lis_seg_sums", mn):
                 res.append(ops.lis_select_varlen(h, lens, ks, wq, bq, wk, bk))
-        for a_, b_ in zip(res[0], res[1]):
-            assert torch.equal(a_, b_)
+        for other in res[1:]:
+            for a_, b_ in zip(res[0], other):
+                assert torch.equal(a_, b_)
         out, idx, scores = res[1]
         ro = oo = 0
         for j, (n, k) in enumerate(zip(lens, ks)):

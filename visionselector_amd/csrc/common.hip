@@ -42,7 +42,7 @@ constexpr KnobSpec kKnobs[VSEL_KNOB_COUNT] = {
     {"VSEL_SPLICE_FUSED", 1, 0, 1},    // VSEL_KNOB_LIS_SPLICE_FUSED
     {"VSEL_ATTN_BWD_WAVES", 8, 4, 8},  // VSEL_KNOB_ATTN_BWD_WAVES
     {nullptr, -1, -1, 1},              // VSEL_KNOB_ATTN_TAIL_FIRST
-    {"VSEL_SEG_SUMS", 640, 0, 1 << 30},  // VSEL_KNOB_LIS_SEG_SUMS
+    {"VSEL_SEG_SUMS", 896, 0, 1 << 30},  // VSEL_KNOB_LIS_SEG_SUMS
 };
 int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 int knob_default(int id) {

@@ -155,10 +155,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 // four ADJACENT slabs of the same rows.  32 rows (32 x 16 B per lane) in flight per wave.  Output: sums[s][col] = the finish
 // kernels' input with row_splits = 1.  grid ceil(col_tiles * n_seg / 4), block 256 (four independent waves).  One wave streams a
 // whole segment slab, so this needs many (segment, slab) pairs -- seg_sums_form() below.
-template <typename T, bool NT>
+// NW = 32-bit words per lane and load (4 / 2 / 1: 16- / 8- / 4-byte loads, i.e. 512 / 256 / 128 bf16 columns per slab): narrower slabs
+// give more (segment, slab) pairs -- more waves -- for smaller batches; the rows in flight grow to keep 128 registers of loads.
+template <typename T, bool NT, int NW>
 __global__ __launch_bounds__(256) void colsum_seg_kernel(const T* __restrict__ h, SegView sv, int d, int col_tiles, int n_seg,
                                                          float* __restrict__ sums, uint16_t* __restrict__ xs) {
-  constexpr int V = Elem<T>::kVec;
+  constexpr int V = NW * (sizeof(T) == 2 ? 2 : 1);               // elements per lane
+  constexpr int RIF = 32 * (4 / NW);                             // rows in flight in the main loop: 32 / 64 / 128
+  typedef uint32_t raw_t __attribute__((ext_vector_type(NW)));
   const int lane = threadIdx.x & 63;
   const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);         // (segment, slab), wave-uniform
   if (unit >= col_tiles * n_seg) return;
@@ -168,9 +172,22 @@ __global__ __launch_bounds__(256) void colsum_seg_kernel(const T* __restrict__ h
   const int64_t r0 = sv.row_begin(s);
   const bool col_ok = col < d;
   const T* base = h + (r0 * (int64_t)d + (col_ok ? col : 0));
-  auto ldraw = [](const T* p) -> u32x4 {
-    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-    else return *reinterpret_cast<const u32x4*>(p);
+  auto ldraw = [](const T* p) -> raw_t {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(p));
+    else return *reinterpret_cast<const raw_t*>(p);
+  };
+  auto unpack = [](raw_t raw, float (&v)[V]) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      uint32_t wd;
+      wd = raw[i];                                            // (a 1-element ext vector indexes like the others)
+      if constexpr (sizeof(T) == 2) {
+        v[2 * i] = __uint_as_float(wd << 16);
+        v[2 * i + 1] = __uint_as_float(wd & 0xffff0000u);
+      } else {
+        v[i] = __uint_as_float(wd);
+      }
+    }
   };
   float tot[V];
 #pragma unroll
@@ -184,39 +201,44 @@ __global__ __launch_bounds__(256) void colsum_seg_kernel(const T* __restrict__ h
     for (int w = 0; w < 4; ++w)
 #pragma unroll
       for (int i = 0; i < V; ++i) acc[w][i] = 0.f;
-    int b = rb;
-    for (; b + 31 < re; b += 32) {                                // every set has two full four-row steps in rows b .. b + 31
-      u32x4 x[32];
+    // four-row steps of every set over the rows blk .. blk + 16 G - 1 (each set: G consecutive steps, in row order)
+    auto steps = [&](auto g_c, int blk) __attribute__((always_inline)) {
+      constexpr int G = decltype(g_c)::value;
+      raw_t x[16 * G];
 #pragma unroll
-      for (int q = 0; q < 32; ++q) x[q] = ldraw(base + (int64_t)(b + q) * d);
+      for (int q = 0; q < 16 * G; ++q) x[q] = ldraw(base + (int64_t)(blk + q) * d);
 #pragma unroll
-      for (int half = 0; half < 2; ++half)
+      for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           float v0[V], v1[V], v2[V], v3[V];
-          unpack_vec<T>(x[16 * half + w], v0);
-          unpack_vec<T>(x[16 * half + w + 4], v1);
-          unpack_vec<T>(x[16 * half + w + 8], v2);
-          unpack_vec<T>(x[16 * half + w + 12], v3);
+          unpack(x[16 * g + w], v0);
+          unpack(x[16 * g + w + 4], v1);
+          unpack(x[16 * g + w + 8], v2);
+          unpack(x[16 * g + w + 12], v3);
 #pragma unroll
           for (int i = 0; i < V; ++i) acc[w][i] = ((acc[w][i] + v0[i]) + v1[i]) + (v2[i] + v3[i]);
         }
-    }
+    };
+    int b = rb;
+    if constexpr (RIF > 32)
+      for (; b + RIF - 1 < re; b += RIF) steps(std::integral_constant<int, RIF / 16>{}, b);
+    for (; b + 31 < re; b += 32) steps(std::integral_constant<int, 2>{}, b);   // every set: two full steps in rows b .. b + 31
 #pragma unroll
     for (int w = 0; w < 4; ++w) {                                  // the segment's last, partial chunk: set by set
       int r = b + w;
       for (; r + 12 < re; r += 16) {
         float v0[V], v1[V], v2[V], v3[V];
-        unpack_vec<T>(ldraw(base + (int64_t)r * d), v0);
-        unpack_vec<T>(ldraw(base + (int64_t)(r + 4) * d), v1);
-        unpack_vec<T>(ldraw(base + (int64_t)(r + 8) * d), v2);
-        unpack_vec<T>(ldraw(base + (int64_t)(r + 12) * d), v3);
+        unpack(ldraw(base + (int64_t)r * d), v0);
+        unpack(ldraw(base + (int64_t)(r + 4) * d), v1);
+        unpack(ldraw(base + (int64_t)(r + 8) * d), v2);
+        unpack(ldraw(base + (int64_t)(r + 12) * d), v3);
 #pragma unroll
         for (int i = 0; i < V; ++i) acc[w][i] = ((acc[w][i] + v0[i]) + v1[i]) + (v2[i] + v3[i]);
       }
       for (; r < re; r += 4) {
         float v0[V];
-        unpack_vec<T>(ldraw(base + (int64_t)r * d), v0);
+        unpack(ldraw(base + (int64_t)r * d), v0);
 #pragma unroll
         for (int i = 0; i < V; ++i) acc[w][i] += v0[i];
       }
@@ -227,32 +249,21 @@ __global__ __launch_bounds__(256) void colsum_seg_kernel(const T* __restrict__ h
   if (col_ok) {
     float* dst = sums + ((int64_t)s * d + col);
 #pragma unroll
-    for (int i = 0; i < V; i += 4) {
-      f32x4 o = {tot[i], tot[i + 1], tot[i + 2], tot[i + 3]};
-      *reinterpret_cast<f32x4*>(dst + i) = o;
-    }
+    for (int i = 0; i < V; ++i) dst[i] = tot[i];                   // (V consecutive floats: the compiler merges them into one or two stores)
     if (xs) {
       // ... and x-bar = sums / N split into the three bf16 planes of the MFMA projections, fragment-major: what
-      // colsum_finish_split_kernel would compute from the sums ((0 + sum) / N, the same bits), one launch less
+      // colsum_finish_split_kernel would compute from the sums ((0 + sum) / N, the same bits), one launch less.  A lane's V
+      // columns are consecutive elements e of ONE fragment row (V divides 8).
       const float fn = (float)n;
       const int mt = (n_seg + 31) >> 5, ksteps = d >> 4;
-      // (a lane's V columns are the consecutive elements e of ONE fragment row: one 16- / 8-byte store per plane)
-      uint32_t bits[3][V];
-#pragma unroll
-      for (int i = 0; i < V; ++i) split3((0.f + tot[i]) / fn, bits[0][i], bits[1][i], bits[2][i]);
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
         uint16_t* dstp = xs + frag_off(pl, s, col, mt, ksteps);
-        if constexpr (V == 8) {
-          u32x4 pk;
 #pragma unroll
-          for (int z = 0; z < 4; ++z) pk[z] = bits[pl][2 * z] | (bits[pl][2 * z + 1] << 16);
-          *reinterpret_cast<u32x4*>(dstp) = pk;
-        } else {
-          uint2 pk;
-          pk.x = bits[pl][0] | (bits[pl][1] << 16);
-          pk.y = bits[pl][2] | (bits[pl][3] << 16);
-          *reinterpret_cast<uint2*>(dstp) = pk;
+        for (int i = 0; i < V; ++i) {
+          uint32_t bt[3];
+          split3((0.f + tot[i]) / fn, bt[0], bt[1], bt[2]);
+          dstp[i] = (uint16_t)bt[pl];
         }
       }
     }
@@ -936,15 +947,16 @@ inline int launch_score(hipStream_t st, const T* h, const SegView& sv, const vse
   return VSEL_OK;
 }
 
-// sweep 1 as colsum_seg_kernel (the segments' sums, one "chunk") instead of per-chunk partials: from knob LIS_SEG_SUMS (segment,
-// slab) pairs = waves (default 640: B >= 92 at the 7B geometry; measured B = 64 483 vs 442 us per call, 96 649 vs 670, 128 831 vs
-// 858; 0 = never), never for the <= 8 segments the small-batch form may take (its kernels rebuild x-bar from chunk partials), more
-// than one chunk, 16-byte column vectors, and no segment far longer than the average (its waves would finish last).  Same sums
-// bit for bit either way: batch invariance is untouched.
+// sweep 1 as colsum_seg_kernel (the segments' sums, one "chunk") instead of per-chunk partials: when some slab width (512 / 256 /
+// 128 bf16 columns) gives knob LIS_SEG_SUMS (segment, slab) pairs = waves (default 896 = 3.5 per CU; 0 = never; measured per call at
+// the 7B geometry, chunked vs this: B = 32 231 vs 228 us, 64 446 vs 428, 96 721 vs 685, 128 848-895 vs 826-830; with 672 pairs no
+// gain, with one 512-column slab per wave at B = 64 a loss: 483 vs 442), never for the <= 8 segments the small-batch form may take
+// (its kernels rebuild x-bar from chunk partials), more than one chunk, and no segment far longer than the average (its waves
+// would finish last).  Same sums bit for bit either way: batch invariance is untouched.
 inline bool seg_sums_form(const LisPlan& p, const vsel_segments* seg) {
   const int mn = knob(VSEL_KNOB_LIS_SEG_SUMS);
-  // (pairs counted as for bf16 tokens, 512 columns per slab, whatever the token type: the projection stage does not know it)
-  return mn > 0 && p.S > 8 && p.S * cdiv(p.d, 512) >= mn && p.row_splits > 1 && p.d % 8 == 0 && seg->total_rows * 2 >= p.S * p.maxn;
+  // (pairs counted for the narrowest slab of bf16 tokens, 128 columns, whatever the token type: the projection stage does not know it)
+  return mn > 0 && p.S > 8 && p.S * cdiv(p.d, 128) >= mn && p.row_splits > 1 && p.d % 8 == 0 && seg->total_rows * 2 >= p.S * p.maxn;
 }
 
 template <typename T>
@@ -952,12 +964,21 @@ inline int launch_colsum(hipStream_t st, const T* h, const SegView& sv, int d, i
                          int64_t total_rows, bool seg_sums = false, uint16_t* xs = nullptr) {
   constexpr int V = Elem<T>::kVec;
   if (seg_sums) {
-    const int col_tiles = (int)cdiv(d, 64 * V);
+    // the widest slab (16- / 8- / 4-byte loads per lane) that still gives knob LIS_SEG_SUMS (segment, slab) pairs
+    const int mn = std::max(1, knob(VSEL_KNOB_LIS_SEG_SUMS));
+    const int epw = sizeof(T) == 2 ? 2 : 1;                       // elements per 32-bit word
+    int nw = 4;
+    while (nw > 1 && ((int64_t)S * cdiv(d, 64 * nw * epw) < mn || d % (nw * epw) != 0)) nw >>= 1;
+    const int col_tiles = (int)cdiv(d, 64 * nw * epw);
     const dim3 g2((unsigned)cdiv((int64_t)col_tiles * S, 4));
-    if (stream_policy(total_rows, d, sizeof(T)))
-      hipLaunchKernelGGL((colsum_seg_kernel<T, true>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial, xs);
-    else
-      hipLaunchKernelGGL((colsum_seg_kernel<T, false>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial, xs);
+    const bool nt = stream_policy(total_rows, d, sizeof(T));
+#define VSEL_SEG_LAUNCH(NWV)                                                                                                    \
+    do {                                                                                                                        \
+      if (nt) hipLaunchKernelGGL((colsum_seg_kernel<T, true, NWV>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial, xs); \
+      else hipLaunchKernelGGL((colsum_seg_kernel<T, false, NWV>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial, xs);   \
+    } while (0)
+    if (nw == 4) VSEL_SEG_LAUNCH(4); else if (nw == 2) VSEL_SEG_LAUNCH(2); else VSEL_SEG_LAUNCH(1);
+#undef VSEL_SEG_LAUNCH
     VSEL_AFTER_LAUNCH(st, "colsum_seg_kernel");
     return VSEL_OK;
   }

@@ -664,7 +664,9 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   // 8-wave workgroups (256 queries) when there is enough work to fill the chip with them, else 4-wave (128 queries)
   const int64_t items8 = cdiv(max_seqlen_q, 256) * hq * n_seq;
   // measured on MI355X (tools/exp_attn_nw.py): 8 waves +12-16 % at L >= 4096, +4 % at 16 x 2368, -20 % at L = 524
-  const bool big = g_attn_nw == 8 || (g_attn_nw == 0 && max_seqlen_q >= 2048 && items8 >= 1024);
+  // ... and for one or two long sequences (same-box scan, 4 vs 8 waves: 1 x 4096 151 vs 133 us, 1 x 8192 498 vs 463, 2 x 4096 266 vs 253;
+  // at 2368-3000 tokens per sequence the two forms are within 2 %)
+  const bool big = g_attn_nw == 8 || (g_attn_nw == 0 && ((max_seqlen_q >= 2048 && items8 >= 1024) || (max_seqlen_q >= 4096 && items8 >= 400)));
   // decode / short chunks against a cache with d = 128: one wave per (kv head, sequence) serving the whole GQA group
   // (measured, tools/bench_decode.py, 28 / 4 heads, Lk = 524: 2.1x at 64 sequences, 2.75x at 256; but a lone wave stages whole
   // tiles by itself, so below one round of per-head workgroups -- n_seq * hq <= 512 -- the per-head form is faster: 24 vs 41 us)

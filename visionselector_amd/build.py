@@ -31,6 +31,9 @@ def _stale() -> bool:
 
 # Kernels that issue LDS reads from inline asm and wait for them later (csrc/attn_common.h): a register copy or spill between
 # issue and wait would read stale data, so these must compile without spilled VGPRs.  (source file, mangled-name fragment)
+# (attn_bwd.hip's 8-wave dK/dV kernel issues its transposed reads from asm too, but its non-split instantiation spills 32 VGPRs
+# AROUND the item loop -- accumulators at the pair hand-over, none between a read's issue and its wait; the backward parity and
+# determinism tests are its guard)
 ASM_READ_KERNELS = (("attn.hip", "varlen_attn_fwd_kernelILb1E"),)
 
 

@@ -311,8 +311,8 @@ extern "C" int vsel_colsum_linear(void* stream, const float* col_sums_in, const 
   hipLaunchKernelGGL(colsum_finish_split_kernel, dim3((unsigned)cdiv(cin, 256), S), dim3(256), 0, st, col_sums_in, sv, (int)cin, 1, S,
                      planes);
   VSEL_AFTER_LAUNCH(st, "colsum_finish_split_kernel");
-  hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, dim3((unsigned)cdiv(cout, 64), mtiles, p.ks), dim3(64), 0, st, planes,
-                     (const uint16_t*)weight, S, (int)cout, (int)cin, p.kslice, slabs);
+  hipLaunchKernelGGL(gemm_nt_bf16x3_kernel<kProjWaves>, dim3((unsigned)cdiv(cout, 64), (unsigned)cdiv(mtiles, kProjWaves), p.ks), dim3(64 * kProjWaves), 0, st, planes,
+                     (const uint16_t*)weight, S, (int)cout, (int)cin, p.kslice, slabs, (int)mtiles);
   VSEL_AFTER_LAUNCH(st, "gemm_nt_bf16x3_kernel");
   hipLaunchKernelGGL(colsum_linear_finish_kernel, dim3(mtiles, (unsigned)cdiv(cout, 8)), dim3(256), 0, st, slabs, p.ks, S, (int)cout,
                      p.m_pad, (const uint16_t*)bias, sv, col_sums_out);

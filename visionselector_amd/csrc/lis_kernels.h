@@ -12,6 +12,9 @@
 // bit-for-bit with the fp32 CPU oracle on tie-free inputs).
 #pragma once
 #include "common.h"
+#ifndef VSEL_PROJ_WAVES
+#define VSEL_PROJ_WAVES 4
+#endif
 #include "proj_bf16x3.h"
 #include <algorithm>
 #include <type_traits>
@@ -20,6 +23,7 @@
 namespace vsel {
 
 // =================================================================================================
+constexpr int kProjWaves = VSEL_PROJ_WAVES;   // waves per workgroup of the bf16x3 projection GEMMs (independent waves sharing one operand tile through L1)
 constexpr int kRowsPerChunk = 128;   // sweep-1 row chunk (batch-invariant summation order)
 constexpr int kSliceNT = 256;        // split-K slice of the kbar projection (fixed => batch-invariant)
 constexpr int kSliceNN = 128;        // split-K slice of the w projection
@@ -1030,14 +1034,14 @@ inline int run_proj(hipStream_t st, const vsel_segments* seg, const vsel_scorer*
       }
       const unsigned mtiles = (unsigned)cdiv(S, 32);
       const int m_pad = 32 * (int)mtiles;
-      hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, dim3((unsigned)cdiv(hd, 64), mtiles, p.ks1), dim3(64), 0, st, xs,
-                         (const uint16_t*)sc->wk, S, hd, d, p.kslice1, part1);
+      hipLaunchKernelGGL(gemm_nt_bf16x3_kernel<kProjWaves>, dim3((unsigned)cdiv(hd, 64), (unsigned)cdiv(mtiles, kProjWaves), p.ks1), dim3(64 * kProjWaves), 0, st, xs,
+                         (const uint16_t*)sc->wk, S, hd, d, p.kslice1, part1, (int)mtiles);
       VSEL_AFTER_LAUNCH(st, "gemm_nt_bf16x3_kernel");
       hipLaunchKernelGGL(kbar_finish_split_kernel, dim3(mtiles, p.n_cpart), dim3(256), 0, st, part1, p.ks1, S, hd, m_pad,
                          (const uint16_t*)sc->bk, (const uint16_t*)sc->bq, kbar, ksp, cpart);
       VSEL_AFTER_LAUNCH(st, "kbar_finish_split_kernel");
-      hipLaunchKernelGGL(gemm_nn_bf16x3_kernel, dim3((unsigned)cdiv(d, 256), mtiles, p.ks2), dim3(64), 0, st, ksp,
-                         (const uint16_t*)sc->wq, S, d, hd, p.kslice2, part2);
+      hipLaunchKernelGGL(gemm_nn_bf16x3_kernel<kProjWaves>, dim3((unsigned)cdiv(d, 256), (unsigned)cdiv(mtiles, kProjWaves), p.ks2), dim3(64 * kProjWaves), 0, st, ksp,
+                         (const uint16_t*)sc->wq, S, d, hd, p.kslice2, part2, (int)mtiles);
       VSEL_AFTER_LAUNCH(st, "gemm_nn_bf16x3_kernel");
       hipLaunchKernelGGL(w_finish_kernel, dim3(mtiles, (unsigned)cdiv(d, 8)), dim3(256), 0, st, part2, p.ks2, S, d, m_pad,
                          cpart, p.n_cpart, w, c);

@@ -75,12 +75,16 @@ static __attribute__((unused)) __global__ __launch_bounds__(256) void colsum_fin
 
 // NT: part[ks][n][m_pad] = sum_{k in slice} x[m][k] w[n][k].  grid (ceil(N/64), m_tiles, KS), one wave per block:
 // two 32-row weight tiles x one 32-column activation tile.  Requires K % 16 == 0.  m_pad = 32 * m_tiles.
-static __attribute__((unused)) __global__ __launch_bounds__(64) void gemm_nt_bf16x3_kernel(const uint16_t* __restrict__ xs,
+template <int WPB>
+static __attribute__((unused)) __global__ __launch_bounds__(64 * WPB) void gemm_nt_bf16x3_kernel(const uint16_t* __restrict__ xs,
                                                                    const uint16_t* __restrict__ w, int /*M*/, int N, int K,
-                                                                   int kslice, float* __restrict__ part) {
-  const int lane = threadIdx.x;
+                                                                   int kslice, float* __restrict__ part, int m_tiles) {
+  // WPB independent waves per workgroup on WPB m-tiles and the SAME weight tile: fetched from L2 once per CU.  Each wave's
+  // arithmetic is what it was: bit-identical slabs.
+  const int lane = threadIdx.x & 63;
   const int i = lane & 31, kg = lane >> 5;
-  const int mt = blockIdx.y, m_tiles = gridDim.y, ksteps = K >> 4;
+  const int mt = blockIdx.y * WPB + (int)(threadIdx.x >> 6), ksteps = K >> 4;
+  if (mt >= m_tiles) return;
   const int n0 = blockIdx.x * 64;
   const int row0 = min(n0 + i, N - 1), row1 = min(n0 + 32 + i, N - 1);
   const int ks = blockIdx.z;
@@ -182,12 +186,16 @@ static __attribute__((unused)) __global__ __launch_bounds__(256) void kbar_finis
 // Lane (i, kg) owns 8 consecutive n (n0 + 8i .. +7) and k rows k0 + 8kg .. +7: eight 16-byte row loads, then a
 // register transpose (v_perm_b32) builds, for each t in 0..7, the A fragment {w[k0+8kg+e][n0+8i+t]}_e of the
 // 32x32 tile "n = n0 + 8*i' + t".  Requires K % 16 == 0 and N % 8 == 0.
-static __attribute__((unused)) __global__ __launch_bounds__(64) void gemm_nn_bf16x3_kernel(const uint16_t* __restrict__ xs,
+template <int WPB>
+static __attribute__((unused)) __global__ __launch_bounds__(64 * WPB) void gemm_nn_bf16x3_kernel(const uint16_t* __restrict__ xs,
                                                                    const uint16_t* __restrict__ w, int /*M*/, int N, int K,
-                                                                   int kslice, float* __restrict__ part) {
-  const int lane = threadIdx.x;
+                                                                   int kslice, float* __restrict__ part, int m_tiles) {
+  // WPB independent waves per workgroup on WPB m-tiles and the SAME weight tile (72 % of this kernel's L2 traffic): fetched from
+  // L2 once per CU.  Each wave's arithmetic is what it was: bit-identical slabs.
+  const int lane = threadIdx.x & 63;
   const int i = lane & 31, kg = lane >> 5;
-  const int mt = blockIdx.y, m_tiles = gridDim.y, ksteps = K >> 4;
+  const int mt = blockIdx.y * WPB + (int)(threadIdx.x >> 6), ksteps = K >> 4;
+  if (mt >= m_tiles) return;
   const int nb = min(blockIdx.x * 256 + 8 * i, N - 8);
   const int ks = blockIdx.z;
   const int k_begin = ks * kslice;

@@ -10,7 +10,9 @@
 // Deterministic by construction (no float atomics, reruns are bit-identical): two kernels, each owning its outputs.
 //   attn_bwd_dq_kernel    item = (128-query tile, q head, sequence), loops over 64-key K/V tiles in LDS:
 //                         S^T = K Q^T, dP^T = V dO^T (lane = query, so lse / D are per-lane scalars),
-//                         dQ^T += K^T dS^T (K^T fragments by ds_read_b64_tr_b16 from the same tile).
+//                         dQ^T += K^T dS^T (K^T fragments by ds_read_b64_tr_b16 from the same tile).  Runs FIRST and also leaves
+//                         D and the exp2-domain log-sum-exp of its rows in the workspace for the dK / dV kernel (no separate
+//                         pass over dO and O).
 //   attn_bwd_dkdv_kernel  item = (128-key block, kv head, sequence), K / V fragments stay in registers, loops over the q heads
 //                         of the group and over 64-query Q / dO tiles in LDS: S = Q K^T, dP = dO V^T (lane = key),
 //                         dV^T += dO^T P, dK^T += Q^T dS (transposed fragments by ds_read_b64_tr_b16).
@@ -34,34 +36,6 @@ constexpr int kTile = kTileRows;   // rows per LDS tile
 constexpr int kTileB = kTileBytes;
 constexpr float kLog2e = 1.4426950408889634f;
 
-// D[t, h] = sum_d dO[t,h,d] * O[t,h,d]  (fp32).  16 lanes per (t, h) row, 4 rows per wave.
-// Also rescales the forward's log-sum-exp to the exp2 domain once (lse2 = lse * log2(e)) for both backward kernels.
-__global__ __launch_bounds__(256) void attn_bwd_dot_kernel(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ out,
-                                                           const float* __restrict__ lse, int64_t rows,
-                                                           float* __restrict__ dvec, float* __restrict__ lse2) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
-  float acc = 0.f;
-  if (row < rows) {
-    const u32x4 a = *reinterpret_cast<const u32x4*>(dout + row * kD + (lane & 15) * 8);
-    const u32x4 b = *reinterpret_cast<const u32x4*>(out + row * kD + (lane & 15) * 8);
-    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      acc = fmaf(__uint_as_float(aw[i] << 16), __uint_as_float(bw[i] << 16), acc);
-      acc = fmaf(__uint_as_float(aw[i] & 0xffff0000u), __uint_as_float(bw[i] & 0xffff0000u), acc);
-    }
-  }
-  acc += __shfl_xor(acc, 1, 64);
-  acc += __shfl_xor(acc, 2, 64);
-  acc += __shfl_xor(acc, 4, 64);
-  acc += __shfl_xor(acc, 8, 64);
-  if (row < rows && (lane & 15) == 0) {
-    dvec[row] = acc;
-    lse2[row] = lse[row] * kLog2e;
-  }
-}
-
 __device__ int g_bwd_counter[64];
 
 #ifdef VSEL_TRACE
@@ -82,7 +56,8 @@ __device__ unsigned long long g_bwd_tile_trace[8][8];
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
-    const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dvec,
+    const uint16_t* __restrict__ dout, const uint16_t* __restrict__ out_fwd, const float* __restrict__ lse,
+    float* __restrict__ dvec, float* __restrict__ lse2_out,
     const int32_t* __restrict__ cu, int hq, int hkv, float scale, int causal, uint16_t* __restrict__ dq, int q_tiles, int n_seq,
     int slot) {
   // ONE __shared__ object (a second one makes hipcc drain the direct-to-LDS prefetch with s_waitcnt vmcnt(0) before the first
@@ -145,8 +120,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
         dof[st] = *reinterpret_cast<const u32x4*>(dout + ro + 16 * st);
       }
     }
-    const float lse2 = lse[(int64_t)(qs + my_q) * hq + head];          // already in the exp2 domain (attn_bwd_dot_kernel)
-    const float dsum = dvec[(int64_t)(qs + my_q) * hq + head];
+    // D = sum_d dO * O of this lane's query and its log-sum-exp in the exp2 domain, computed HERE (every valid query row belongs to
+    // exactly one dQ item) and left in the workspace for the dK / dV kernel, which runs after this one: the separate pass over
+    // dO and O (attn_bwd_dot_kernel, 2.4 % of the backward at 16 x 4096) is gone.  Lane (j, hh) holds 64 of the row's 128
+    // features; the two halves are added in the order (features 8 hh' .. of hh' = 0) + (hh' = 1) in both lanes.
+    float dpart = 0.f;
+    {
+      const int64_t ro = ((int64_t)(qs + my_q) * hq + head) * kD + 8 * hh;
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const u32x4 ov = *reinterpret_cast<const u32x4*>(out_fwd + ro + 16 * st);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          dpart = fmaf(__uint_as_float(dof[st][i] << 16), __uint_as_float(ov[i] << 16), dpart);
+          dpart = fmaf(__uint_as_float(dof[st][i] & 0xffff0000u), __uint_as_float(ov[i] & 0xffff0000u), dpart);
+        }
+      }
+    }
+    const float dother = __shfl_xor(dpart, 32, 64);
+    const float dsum = hh == 0 ? dpart + dother : dother + dpart;
+    const float lse2 = lse[(int64_t)(qs + my_q) * hq + head] * kLog2e;
+    if (q_valid && hh == 0) {
+      dvec[(int64_t)(qs + my_q) * hq + head] = dsum;
+      lse2_out[(int64_t)(qs + my_q) * hq + head] = lse2;
+    }
     f32x16 acc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -887,10 +884,6 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
   const size_t d_bytes = ((size_t)rows * sizeof(float) + 255) & ~(size_t)255;
   float* dvec = (float*)workspace;
   float* lse2 = (float*)((char*)workspace + d_bytes);
-  hipLaunchKernelGGL(bwd::attn_bwd_dot_kernel, dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, st, (const uint16_t*)dout,
-                     (const uint16_t*)out, lse, rows, dvec, lse2);
-  VSEL_AFTER_LAUNCH(st, "attn_bwd_dot_kernel");
-
   int* counters = nullptr;
   VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(bwd::g_bwd_counter)));
   static unsigned next_slot = 0;
@@ -902,6 +895,19 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
     }
     return VSEL_OK;
   };
+  // dQ first: it also leaves D = rowsum(dO * O) and the exp2-domain log-sum-exp in the workspace for the dK / dV kernel
+  {
+    const int q_tiles = (int)cdiv(max_seqlen, 128);
+    const int64_t n_items = (int64_t)q_tiles * hq * n_seq;
+    if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
+    int slot;
+    if (int rc = take_slot(n_items, 512, slot)) return rc;
+    hipLaunchKernelGGL(bwd::attn_bwd_dq_kernel, dim3((unsigned)std::min<int64_t>(n_items, 512)), dim3(256), 0, st,
+                       (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, (const uint16_t*)out, lse, dvec, lse2,
+                       cu_seqlens,
+                       (int)hq, (int)hkv, scale, causal, (uint16_t*)dq, q_tiles, (int)n_seq, slot);
+    VSEL_AFTER_LAUNCH(st, "attn_bwd_dq_kernel");
+  }
   {
     const bool split = bwd_use_split(n_seq, max_seqlen, hq, hkv);
     const int k_blocks = (int)cdiv(max_seqlen, 128);
@@ -930,17 +936,6 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
                          dv_part, total, (int)hq, (int)hkv, scale, (uint16_t*)dk, (uint16_t*)dv);
       VSEL_AFTER_LAUNCH(st, "attn_bwd_group_sum_kernel");
     }
-  }
-  {
-    const int q_tiles = (int)cdiv(max_seqlen, 128);
-    const int64_t n_items = (int64_t)q_tiles * hq * n_seq;
-    if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
-    int slot;
-    if (int rc = take_slot(n_items, 512, slot)) return rc;
-    hipLaunchKernelGGL(bwd::attn_bwd_dq_kernel, dim3((unsigned)std::min<int64_t>(n_items, 512)), dim3(256), 0, st,
-                       (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu_seqlens,
-                       (int)hq, (int)hkv, scale, causal, (uint16_t*)dq, q_tiles, (int)n_seq, slot);
-    VSEL_AFTER_LAUNCH(st, "attn_bwd_dq_kernel");
   }
   return VSEL_OK;
 }

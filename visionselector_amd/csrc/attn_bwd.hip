@@ -155,9 +155,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     // K / V tiles go global -> LDS directly (global_load_lds_dwordx4), swizzle applied to the source address (see the
     // dK / dV kernel below); the mask is evaluated only on tiles that touch the causal diagonal or the end of the keys.
     const int ld_part = slice_src_part(lane, wave) * 8;
+    const uint32_t lane_off_kv = (uint32_t)(((lane >> 4) * hkv * kD + ld_part) * 2);     // bytes from a slice's first row, this lane
+    const int64_t slice_step_kv = (int64_t)16 * hkv * kD * 2;                             // bytes from slice i to slice i + 4
     auto load_tile = [&](int t, int buf) {
       typedef const __attribute__((address_space(1))) void* gptr_t;
       typedef __attribute__((address_space(3))) void* lptr_t;
+      if (t * kTile + kTile <= len) {
+        // full tile: wave-uniform 64-bit row base (scalar ALU) + per-lane 32-bit offset computed once per item (the clamped form
+        // below costs every load its own min and 64-bit multiply on the vector ALU)
+        const int64_t row0 = ((int64_t)(qs + t * kTile + 4 * wave) * hkv + kvh) * kD;
+        const char* kp = reinterpret_cast<const char*>(k + row0);
+        const char* vp = reinterpret_cast<const char*>(v + row0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = wave + 4 * u;
+          __builtin_amdgcn_global_load_lds((gptr_t)(kp + lane_off_kv), (lptr_t)(k_sm + buf * kTileB + i * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gptr_t)(vp + lane_off_kv), (lptr_t)(v_sm + buf * kTileB + i * 1024), 16, 0, 0);
+          kp += slice_step_kv;
+          vp += slice_step_kv;
+        }
+        return;
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = wave + 4 * u;

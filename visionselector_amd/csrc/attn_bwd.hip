@@ -863,7 +863,10 @@ extern "C" int vsel_debug_read_bwd_trace(unsigned long long* out) {
 
 // Items of the in-kernel-group dK/dV pass below which the per-q-head split (fp32 partials + group sum) is used instead:
 // measured (tools/bench_attn_bwd.py): the split wins up to ~300 items (4 x 2368: 635 vs 802 us) and loses at 576 (16 x 1100).
-static constexpr int64_t kSplitBelowItems = 512;
+// Re-measured with the 8-wave dK/dV kernel (whole backward, us, auto / no split / split): 1 x 2368 (76 items) 210 / 505 / 216,
+// 2 x 2368 (152) 377 / 552 / 369, 8 x 524 (160) 175 / 173 / 165, 8 x 1100 (288) 443 / 383 / 438, 4 x 2368 (304) 728 / 738 / 725,
+// 3 x 4096 (384) 1426 / 1398 / 1414, 6 x 2368 (456) 1086 / 940 / 1099: the crossover is below 288 items now.
+static constexpr int64_t kSplitBelowItems = 288;
 // knob VSEL_KNOB_ATTN_BWD_SPLIT (include/vsel_debug.h): -1 = choose by item count, 0 / 1 = force (tests)
 
 static bool bwd_use_split(int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv) {

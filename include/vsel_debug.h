@@ -23,7 +23,7 @@ extern "C" {
 typedef enum vsel_debug_knob {
   VSEL_KNOB_LIS_PIPELINE = 0,     /* 0 / 1: two-half aux-stream pipeline for >= 32 segments (env VSEL_PIPELINE, default 0); bit-identical */
   VSEL_KNOB_LIS_SMALL_PATH = 1,   /* small-batch LIS form up to this many segments (env VSEL_SMALL_PATH, default 4, 0 = never); bit-identical */
-  VSEL_KNOB_LIS_FUSED_SELECT = 2, /* radix select fused into the gather up to this many segments (env VSEL_FUSED_SELECT, default 32); bit-identical */
+  VSEL_KNOB_LIS_FUSED_SELECT = 2, /* radix select fused into the gather up to this many segments (env VSEL_FUSED_SELECT, default 48); bit-identical */
   VSEL_KNOB_ATTN_USE_TR = 3,      /* 0 / 1: V fragments by ds_read_b64_tr_b16 (default 1) or by plain LDS reads; bit-identical */
   VSEL_KNOB_ATTN_WAVES = 4,       /* 0 = by grid size (default), 4 / 8 = force the forward workgroup size; bit-identical */
   VSEL_KNOB_ATTN_PACK = 5,        /* GQA-packed decode form: 0 never, 1 whenever it applies, 2 (default) by grid size; bit-identical */

@@ -32,7 +32,7 @@ struct KnobSpec { const char* env; int def, lo, hi; };
 constexpr KnobSpec kKnobs[VSEL_KNOB_COUNT] = {
     {"VSEL_PIPELINE", 0, 0, 1},        // VSEL_KNOB_LIS_PIPELINE
     {"VSEL_SMALL_PATH", 4, 0, 8},      // VSEL_KNOB_LIS_SMALL_PATH (8 = lis_small.h's kSmallMaxSeg)
-    {"VSEL_FUSED_SELECT", 32, 0, 1 << 30},
+    {"VSEL_FUSED_SELECT", 48, 0, 1 << 30},
     {nullptr, 1, 0, 1},                // VSEL_KNOB_ATTN_USE_TR
     {nullptr, 0, 0, 8},                // VSEL_KNOB_ATTN_WAVES
     {nullptr, 2, 0, 2},                // VSEL_KNOB_ATTN_PACK

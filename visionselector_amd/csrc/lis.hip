@@ -76,7 +76,8 @@ extern "C" int vsel_debug_read_trace(unsigned long long* out, int clear) {
 
 // select fused into the gather (select_gather_small_kernel) for mid-size batches of the nine-launch form.  Measured (7B geometry,
 // us per call, fused vs two launches): 8 images 82.0 vs 83.3, 16 135.3 vs 137.0, 32 233.4 vs 238.8, 48 350.9 vs 347.1, 128 900.8 vs
-// 877.0 -> up to 32 segments.  VSEL_FUSED_SELECT=<n> / knob VSEL_KNOB_LIS_FUSED_SELECT.
+// 877.0 -> up to 32 segments; re-measured at the end of round 3: 16 136.9 vs 138.5, 32 227.7 vs 232.9, 48 347.4 vs 353.7, 64 428.4 vs
+// 428.7 -> up to 48.  VSEL_FUSED_SELECT=<n> / knob VSEL_KNOB_LIS_FUSED_SELECT.
 static inline int fused_select_max_seg() { return knob(VSEL_KNOB_LIS_FUSED_SELECT); }
 
 static bool use_small_path(const vsel_segments* seg, const vsel_scorer* sc, const LisPlan& p) {

@@ -322,6 +322,51 @@ def test_select_splice_fusion_is_transparent(selector_model):
     m.fuse_select_splice = True
 
 
+def test_fused_prefill_honours_tower_hooks_and_instance_forward(selector_model):
+    """The fused prefill bypasses `nn.Module.__call__` on the tower, so it is taken only when that call would do nothing
+    else: with a forward / pre-forward hook or an instance-level `forward` (accelerate's device_map hook, MethodType
+    patches) the prefill goes through `self.visual(...)`, the hook fires, and the logits are the fused path's."""
+    import types
+    from visionselector_amd import _native as N
+    m = selector_model
+    m.visual.budgets = 0.25
+    inp, _ = make_inputs(grid=(1, 32, 32), seed=12)
+    with torch.no_grad():
+        ref = m(**inp).logits.clone()
+    calls = []
+
+    def run(expect_fused):
+        m.model.rope_deltas = None
+        N.profile_start()
+        with torch.no_grad():
+            o = m(**inp)
+        prof = N.profile_stop()
+        assert ("select_splice_small_kernel" in prof) == expect_fused, prof
+        assert torch.equal(o.logits, ref)
+
+    run(True)
+    h = m.visual.register_forward_hook(lambda mod, args, out: calls.append("post"))
+    run(False)
+    h.remove()
+    h = m.visual.register_forward_pre_hook(lambda mod, args: calls.append("pre"))
+    run(False)
+    h.remove()
+    assert calls == ["post", "pre"]
+    cls_forward = type(m.visual).forward
+
+    def patched(self, *a, **k):
+        calls.append("instance")
+        return cls_forward(self, *a, **k)
+
+    m.visual.forward = types.MethodType(patched, m.visual)
+    try:
+        run(False)
+    finally:
+        del m.visual.forward
+    assert calls[-1] == "instance"
+    run(True)
+
+
 def test_unreorder_fusion_is_transparent(selector_model):
     """The inference tower skips transformers' `merged[reverse_indices, :]` gather (vsel_lis_select_permuted): same kept
     tokens / indices / logits as with the gather executed."""
@@ -435,7 +480,7 @@ def test_merger_colsum_fusion_is_transparent(selector_model):
             o = m(**inp)
         prof = N.profile_stop()
         outs.append((o.logits.clone(), m.visual.last_selected_indices.clone(), m.visual.last_combined_scores.clone(), prof))
-    m.visual.fuse_merger_colsum = None            # back to automatic (on from 24 576 tokens per call)
+    m.visual.fuse_merger_colsum = None            # back to the default: off (opt-in: True or "auto")
     assert "gelu_colsum_kernel" in outs[0][3] and "colsum_partial_kernel" not in outs[0][3], outs[0][3].keys()
     assert "gelu_colsum_kernel" not in outs[1][3] and "colsum_partial_kernel" in outs[1][3]
     assert torch.equal(outs[0][1], outs[1][1])

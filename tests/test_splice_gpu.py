@@ -373,3 +373,43 @@ def test_lis_select_splice_permuted_presummed_and_mismatch(ops):
                 ops.lis_select_splice(h, wq, bq, wk, bk, bad, emb_t, IMAGE_TOKEN, [L], [n], [k], check=True)
     with pytest.raises(ValueError, match="same dtype and width"):
         ops.lis_select_splice(h, wq, bq, wk, bk, ids_t, emb_t.float(), IMAGE_TOKEN, [L], [n], [k])
+
+
+def test_select_splice_argument_hygiene(ops, monkeypatch):
+    """The raw pointers handed to the C-ABI are validated first: int32 / short row maps raise, a strided `input_ids` view is
+    read through a contiguous copy, and a caller whose `max_len_out` is below a prompt's true L' is REPORTED (stats[3], hence
+    ValueError under check=True) instead of leaving the uncovered rows of the outputs uninitialised."""
+    d, hd = 2048, 1024
+    seq_lens, visual_lens, ks = [700, 400], [640, 256], [128, 51]
+    rng = np.random.default_rng(9)
+    ids, _, emb, _, pos = _packed_case(rng, seq_lens, visual_lens, ks, d, torch.bfloat16)
+    n = sum(visual_lens)
+    c = oin.make_case(d, hd, n, 79)
+    h = torch.from_numpy(c["h"]).bfloat16().cuda()
+    wq, bq, wk, bk = (torch.from_numpy(c[x]).bfloat16().cuda() for x in ("wq", "bq", "wk", "bk"))
+    ids_t, emb_t = torch.from_numpy(ids).cuda(), emb.cuda()
+    ref = ops.lis_select_splice(h, wq, bq, wk, bk, ids_t, emb_t, IMAGE_TOKEN, seq_lens, visual_lens, ks, check=True)
+    strided = torch.stack([ids_t, ids_t + 1], dim=1)[:, 0]                # stride 2 view of the same ids
+    assert not strided.is_contiguous()
+    got = ops.lis_select_splice(h, wq, bq, wk, bk, strided, emb_t, IMAGE_TOKEN, seq_lens, visual_lens, ks, check=True)
+    for key in ("idx", "selected_indices", "input_ids", "inputs_embeds", "cu_seqlens"):
+        assert torch.equal(got[key], ref[key]), key
+    ident = torch.arange(n, device="cuda")
+    with pytest.raises(TypeError, match="int64"):
+        ops.lis_select_splice(h, wq, bq, wk, bk, ids_t, emb_t, IMAGE_TOKEN, seq_lens, visual_lens, ks,
+                              logical_to_physical=ident.int(), physical_to_logical=ident)
+    with pytest.raises(ValueError, match="one entry per token row"):
+        ops.topk_select_splice(ref["scores"], h, ids_t, emb_t, IMAGE_TOKEN, seq_lens, visual_lens, ks,
+                               logical_to_physical=ident[:-1])
+    common = ops._select_splice_common
+
+    def short_launch(*a, **k):
+        r = list(common(*a, **k))
+        r[8] = r[8] // 2                                                  # max_len_out: half the longest prompt's L'
+        return tuple(r)
+
+    monkeypatch.setattr(ops, "_select_splice_common", short_launch)
+    with pytest.raises(ValueError, match="do not match"):
+        ops.lis_select_splice(h, wq, bq, wk, bk, ids_t, emb_t, IMAGE_TOKEN, seq_lens, visual_lens, ks, check=True)
+    with pytest.raises(RuntimeError, match="max_len_out"):              # one prompt: must be exactly its L'
+        ops.lis_select_splice(h[:640], wq, bq, wk, bk, ids_t[:700], emb_t[:700], IMAGE_TOKEN, [700], [640], [128], check=True)

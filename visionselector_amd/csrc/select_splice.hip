@@ -247,7 +247,8 @@ __global__ __launch_bounds__(kSpliceThreads) void select_splice_small_kernel(
     if (b != 0 && (int)run_keep >= qe) break;         // uniform: later positions belong to other workgroups (block 0 counts on)
   }
   if (b == 0 && tid == 0) {
-    const bool bad = (int)run_vis != g.nvis || (int)run_keep != g.len_out || (int)run_kv != g.ko;
+    // nblk > gridDim.x: the caller's max_len_out is below this prompt's L', so the grid has no workgroup for its last rows
+    const bool bad = (int)run_vis != g.nvis || (int)run_keep != g.len_out || (int)run_kv != g.ko || nblk > (int)gridDim.x;
     if (single) {
       stats[0] = (int32_t)run_vis;
       stats[1] = (int32_t)run_keep;
@@ -381,6 +382,8 @@ static int splice_args_check(const void* h, vsel_dtype hdtype, const vsel_segmen
       max_len_out < 1 || max_len_out > *l_out)
     return fail(VSEL_ERR_INVALID, "bad sizes (T=%lld, visual=%lld, kept=%lld, max L'=%lld)", (long long)total_len,
                 (long long)seg->total_rows, (long long)seg->total_out, (long long)max_len_out);
+  if (seg->n_seg == 1 && max_len_out != *l_out)
+    return fail(VSEL_ERR_INVALID, "one prompt: max_len_out (%lld) must be its L' (%lld)", (long long)max_len_out, (long long)*l_out);
   if (seg->rows_per_seg > kMaxVisualBits) return fail(VSEL_ERR_UNSUPPORTED, "more than %d visual tokens in one prompt", kMaxVisualBits);
   if (((uintptr_t)h | (uintptr_t)inputs_embeds | (uintptr_t)new_inputs_embeds) & 15)
     return fail(VSEL_ERR_INVALID, "h / embeddings must be 16-byte aligned");

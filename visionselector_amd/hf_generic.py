@@ -14,7 +14,15 @@ from . import ops
 from .selector import lis_select_block, lis_train_block
 
 
-kFuseMinTokens = 24576      # merged visual tokens per call from which the merger-side column sums pay (see tower_tokens_for_selection)
+# `visual.fuse_merger_colsum = "auto"`: merged visual tokens per call from which the merger-side column sums pay.
+#
+# The presummed path feeds the LIS fp32 `sum(G) W^T + N b`, NOT the sum of the bf16-rounded merged rows the reference
+# averages (EV/token_compression/selector_model.py:182-186 on the merger's stored output): scores move by <= 3e-4 x their
+# scale (tests/test_property_gpu.py), so the token at the k-th boundary can differ from the two-sweep path, and whether a
+# given image takes this path would depend on how many tokens share the call.  The default is therefore OFF (indices
+# bit-exact against the reference whatever the batch composition); eval / serving runs that accept the tolerance opt in
+# with `visual.fuse_merger_colsum = "auto"` (on from kFuseMinTokens tokens per call) or `True` (always).
+kFuseMinTokens = 24576
 
 
 class _LazyRows(torch.Tensor):
@@ -102,16 +110,16 @@ def tower_tokens_for_selection(self, base_forward: Callable, hidden_states: torc
     fused_gelu, slot = None, None
     if merger is not None and not torch.is_grad_enabled() and getattr(self, "fuse_unreorder", True):
         handle = merger.register_forward_hook(lambda mod, inp, out: _LazyRows(out) if out.dim() == 2 else out)
-        # visual.fuse_merger_colsum: True / False, or None (default) = automatic: on from kFuseMinTokens merged tokens per
-        # call.  Measured on MI355X (tools/exp_merger_fusion.py, profiles/r03_merger_fusion.jsonl; round 3: non-temporal GELU
-        # streams, vsel_colsum_linear on the stored bf16 weight instead of an fp32 addmm): GELU + LIS 1408 -> 1185 us at
-        # 147 456 tokens (-15.9 %), 400 -> 367 us at 36 864 (-8.2 %), 219.3 -> 218.4 at 18 432 (break-even), 111 -> 123 at 9 216
-        # and 52 -> 63 us at one image (the fused GELU costs 7-20 us more than torch's below 40 k tokens, the sum's trip through
+        # visual.fuse_merger_colsum: False / None (default: off, see kFuseMinTokens), True, or "auto" = on from kFuseMinTokens
+        # merged tokens per call.  Measured on MI355X (tools/exp_merger_fusion.py, profiles/r03_merger_fusion.jsonl): GELU +
+        # LIS 1408 -> 1185 us at 147 456 tokens (-15.9 %), 400 -> 367 us at 36 864 (-8.2 %), break-even at 18 432, and a loss
+        # below (one image 52 -> 63 us: the fused GELU costs 7-20 us more than torch's below 40 k tokens, the sum's trip through
         # the last Linear 10-19 us; the sweep it removes is 1.1 us per 1 000 tokens)
         fuse = getattr(self, "fuse_merger_colsum", None)
-        if fuse is None:
+        if fuse == "auto":
             merge = int(getattr(self, "spatial_merge_unit", 0) or getattr(self, "spatial_merge_size", 2) ** 2)
             fuse = hidden_states.shape[0] // max(1, merge) >= kFuseMinTokens
+        fuse = bool(fuse)
         slot = _merger_gelu_slot(merger) if fuse else None
         if slot is not None:
             fused_gelu = _GeluColsum()

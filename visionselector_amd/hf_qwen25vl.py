@@ -102,6 +102,19 @@ class Qwen2_5_VisionTransformerPretrainedModel_Selector(_BaseTower):
         return _tower_forward_eval(self, hidden_states, grid_thw, **kwargs)
 
 
+def _tower_call_is_plain(visual) -> bool:
+    """True when `visual(...)` would do nothing but run our tower forward, so the fused prefill may call the tower's
+    pieces directly.  `nn.Module.__call__` also runs forward / pre-forward hooks (accelerate's device_map hook, profilers)
+    and an instance-level `forward` (accelerate's `add_hook_to_module`, `types.MethodType` patches) overrides the class one:
+    with any of those present the caller must go through `self.visual(...)`."""
+    if type(visual).forward is not Qwen2_5_VisionTransformerPretrainedModel_Selector.forward:
+        return False
+    if "forward" in visual.__dict__:
+        return False
+    return not (visual._forward_hooks or visual._forward_pre_hooks
+                or torch.nn.modules.module._global_forward_hooks or torch.nn.modules.module._global_forward_pre_hooks)
+
+
 class Qwen2_5_VLForConditionalGeneration_Selector(_BaseCausal):
     """EV/token_compression/selector_model.py:196-387: prefill splices the kept visual tokens into the sequence
     (ids / embeds / M-RoPE positions / attention mask are index-selected), decode uses the cached rope deltas."""
@@ -152,7 +165,7 @@ class Qwen2_5_VLForConditionalGeneration_Selector(_BaseCausal):
             check = getattr(self, "check_token_count", True)     # ValueError on a placeholder / feature count mismatch (FT :210-213)
             am = None if attention_mask is None else attention_mask.contiguous()
             fused, tokens = None, None
-            if getattr(self, "fuse_select_splice", True) and type(self.visual).forward is Qwen2_5_VisionTransformerPretrainedModel_Selector.forward:
+            if getattr(self, "fuse_select_splice", True) and _tower_call_is_plain(self.visual):
                 # tower -> scores -> hard top-k -> splice with the kept rows written ONCE, from the merger's output straight into
                 # inputs_embeds' (vsel_lis_select_splice); bit-identical to visual() + vsel_splice below
                 fused, tokens = select_and_splice(self.visual, _BaseTower.forward, pix, grid, input_ids.contiguous(),

@@ -576,6 +576,17 @@ def _select_splice_common(h, input_ids, inputs_embeds, seq_lens, visual_lens, ks
     return seg, (cu_r, cu_o), cu_s, pos, rows, am, out, l_out, max_len_out, n_tot, k_tot
 
 
+def _row_map(m, name: str, rows: int):
+    """A row permutation map as the C-ABI reads it: int64, contiguous, one entry per token row (or None)."""
+    if m is None:
+        return None
+    if m.dtype != torch.int64:
+        raise TypeError(f"{name} must be int64 (got {m.dtype})")
+    if m.numel() != rows:
+        raise ValueError(f"{name} must have one entry per token row ({rows}), got {m.numel()}")
+    return m.contiguous()
+
+
 def _select_splice_finish(o, check, n_tot, l_out, k_tot, attention_mask):
     if check:
         found, written, kept, bad = o["stats"].tolist()
@@ -608,13 +619,17 @@ def lis_select_splice(h, wq, bq, wk, bk, input_ids, inputs_embeds, visual_token_
         raise ValueError("give both permutation maps or neither")
     if col_sums is not None and (col_sums.dtype != torch.float32 or col_sums.numel() != len(seq_lens) * sc.d):
         raise ValueError("col_sums must be float32 with one row of D sums per prompt")
+    col_sums = None if col_sums is None else col_sums.contiguous()
+    logical_to_physical = _row_map(logical_to_physical, "logical_to_physical", n_tot)
+    physical_to_logical = _row_map(physical_to_logical, "physical_to_logical", n_tot)
+    ids = input_ids.contiguous()
     lib = N.lib()
     ws = _workspace(lib.vsel_lis_workspace_bytes(C.byref(seg), sc.d, sc.hd), dev)
     scores = torch.empty(n_tot, dtype=torch.float32, device=dev)
     hc, emb = h.contiguous(), inputs_embeds.contiguous()
     N.check(lib.vsel_lis_select_splice(
         _stream(), hc.data_ptr(), _code(hc), C.byref(seg), C.byref(sc), ws.data_ptr(), ws.numel(), _p(col_sums),
-        _p(logical_to_physical), _p(physical_to_logical), input_ids.data_ptr(), input_ids.numel(), _p(cu_s), max_len_out,
+        _p(logical_to_physical), _p(physical_to_logical), ids.data_ptr(), ids.numel(), _p(cu_s), max_len_out,
         int(visual_token_id), emb.data_ptr(), _p(pos), rows, _p(am), o["idx"].data_ptr(), scores.data_ptr(), o["sel"].data_ptr(),
         o["new_ids"].data_ptr(), o["new_emb"].data_ptr(), _p(o["new_pos"]), _p(o["new_am"]), o["cu_out"].data_ptr(),
         o["src"].data_ptr(), o["stats"].data_ptr()))
@@ -632,10 +647,11 @@ def topk_select_splice(scores, h, input_ids, inputs_embeds, visual_token_id: int
         raise TypeError("scores must be float32 with one entry per token row")
     seg, _keep, cu_s, pos, rows, am, o, l_out, max_len_out, n_tot, k_tot = _select_splice_common(
         h, input_ids, inputs_embeds, seq_lens, visual_lens, ks, position_ids, attention_mask, dev)
-    hc, emb, scc = h.contiguous(), inputs_embeds.contiguous(), scores.contiguous()
+    hc, emb, scc, ids = h.contiguous(), inputs_embeds.contiguous(), scores.contiguous(), input_ids.contiguous()
+    logical_to_physical = _row_map(logical_to_physical, "logical_to_physical", n_tot)
     N.check(N.lib().vsel_topk_select_splice(
         _stream(), hc.data_ptr(), _code(hc), h.shape[1], C.byref(seg), scc.data_ptr(), _p(logical_to_physical),
-        input_ids.data_ptr(), input_ids.numel(), _p(cu_s), max_len_out, int(visual_token_id), emb.data_ptr(), _p(pos), rows,
+        ids.data_ptr(), ids.numel(), _p(cu_s), max_len_out, int(visual_token_id), emb.data_ptr(), _p(pos), rows,
         _p(am), o["idx"].data_ptr(), o["sel"].data_ptr(), o["new_ids"].data_ptr(), o["new_emb"].data_ptr(), _p(o["new_pos"]),
         _p(o["new_am"]), o["cu_out"].data_ptr(), o["src"].data_ptr(), o["stats"].data_ptr()))
     new_am = _select_splice_finish(o, check, n_tot, l_out, k_tot, attention_mask)

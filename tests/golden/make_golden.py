@@ -198,7 +198,9 @@ def gen_lis_bf16_case(name, d, hd, n, seed, ft, ev, TransformerScorer):
     loads and trains in bf16; `_find_ts` runs in the dtype of its input, FT/compression_method/selector_model.py:72-86).
     Same seeded inputs as lis_<name>.npz (bf16-representable), every module op rounding to bf16 as torch CPU does.
     Stored: bf16 scores, EV selection (indices, soft mask `last_combined_scores`) for the three budgets, `_find_ts` in bf16,
-    the training forward (soft mask, constraint mask, BCE), and the tie census at each k boundary."""
+    the training forward (soft mask, constraint mask, BCE), the tie census at each k boundary, and the bf16 BACKWARD:
+    `TopK.backward` for a seeded g and the training block's autograd gradients (dWq, dWk, dx as the projections the fp32
+    fixtures use; db in full)."""
     case = oin.make_case(d, hd, n, seed)
     scorer = build_scorer(TransformerScorer, case).bfloat16()
     h = torch.from_numpy(case["h"]).bfloat16()
@@ -239,6 +241,42 @@ def gen_lis_bf16_case(name, d, hd, n, seed, ft, ev, TransformerScorer):
     out["train_y_bf16"] = cmask.float().numpy()
     out["train_bce_bf16"] = np.float32(bce.item())
     out["train_hnew_rowsum_bf16"] = h_new.double().sum(1).numpy()
+    # ---- bf16 BACKWARD (the reference trains in bf16: train_qwen_selector.py:175-180 loads bf16 and DeepSpeed's bf16 engine
+    # casts the scorer added at :190-197; selector_model.py:60-70 TopK.backward, :158-173 block, :308-313 BCE) -------------
+    xs = scores[None].clone().requires_grad_(True)
+    ps_t = ft.topk(xs, k)                                           # TopK.apply on bf16 scores
+    gvec = torch.from_numpy(oin.make_vec(n, seed + 1000))[None].bfloat16()
+    ps_t.backward(gvec)
+    assert xs.grad.dtype == torch.bfloat16
+    out["topk_grad_bf16"] = xs.grad[0].float().numpy()
+    reg_w = 0.7
+    stub = StubTower(scorer, 0.2, n, training=True)
+    for p in scorer.parameters():
+        p.grad = None
+    hg = h.clone().requires_grad_(True)
+    h_new, img_mask, cmask = ft.qwen25vl_vision_tower_forward_selector(stub, hg, grid)
+    gmat = torch.from_numpy(
+        np.random.default_rng(seed + 2000).standard_normal((n, d), dtype=np.float32) / np.float32(d) ** 0.5).bfloat16()
+    bce_b = F.binary_cross_entropy(img_mask, cmask)                 # bf16 in, bf16 out, as the reference's line :310 runs
+    loss = (h_new * gmat).sum() + reg_w * bce_b
+    loss.backward()
+    assert hg.grad.dtype == torch.bfloat16 and scorer.q_proj.weight.grad.dtype == torch.bfloat16
+    out["bwd_reg_w"] = np.float32(reg_w)
+    out["bwd_bce_bf16"] = np.float32(bce_b.float().item())
+    u_d = oin.make_vec(d, seed + 3000).astype(np.float64)
+    v_h = oin.make_vec(hd, seed + 3001).astype(np.float64)
+    v_n = oin.make_vec(n, seed + 3002).astype(np.float64)
+    gq = scorer.q_proj.weight.grad.double().numpy()
+    gk = scorer.k_proj.weight.grad.double().numpy()
+    gx = hg.grad.double().numpy()
+    out["bwd_dbq"] = scorer.q_proj.bias.grad.float().numpy()
+    out["bwd_dbk"] = scorer.k_proj.bias.grad.float().numpy()
+    out["bwd_dwq_u"], out["bwd_v_dwq"] = gq @ u_d, v_h @ gq
+    out["bwd_dwk_u"], out["bwd_v_dwk"] = gk @ u_d, v_h @ gk
+    out["bwd_dx_u"], out["bwd_v_dx"] = gx @ u_d, v_n @ gx
+    out["bwd_max_abs"] = np.array([np.abs(gq).max(), np.abs(gk).max(), np.abs(gx).max()], np.float64)
+    if n * d <= 4096:
+        out["bwd_dwq"], out["bwd_dwk"], out["bwd_dx"] = gq.astype(np.float32), gk.astype(np.float32), gx.astype(np.float32)
     g32 = np.load(os.path.join(HERE, f"lis_{name}.npz"))
     d32 = np.abs(sf - g32["scores"]).max()
     sym = {t: len(set(out[f"idx_bf16_{t}"]) ^ set(g32[f"idx_{t}"])) for t in ("0p1", "0p2", "0p5")}

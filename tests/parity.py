@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = "r03"
+ROUND = "r04"
 LOG = os.path.join(ROOT, "gpurun_out", "parity", f"{ROUND}_parity.jsonl")
 
 MAX_ULP_FWD = 1.0        # gate: every element within 1 bf16 ulp (ulp at its row's scale) of the bf16-rounded oracle
@@ -30,8 +30,17 @@ MEAN_ABS_FWD = 1e-3      # gate: mean |err| vs the un-rounded fp64 oracle
 # against the build's bf16-storage / fp32-accumulate path.  north_star: "soft scores ... within 1e-3 bf16".
 BF16_SCORE_TOL = 1e-3    # |score - reference bf16 score| <= 1e-3 * max(1, max|score|)
 BF16_IDX_FRAC = 0.01     # |idx (sym.diff) reference bf16 idx| <= max(2 * ties at the k-th value, 1 % of k)
-BF16_PS_TOL = 6e-3       # soft mask: the reference's bf16 bisection stalls at bf16 spacing of t (|dt| <= 2^-7 -> |dp| <= 2e-3)
-                         # and its p is rounded to bf16 (<= 2^-9 relative = 2e-3 near 1); observed worst logged
+BF16_PS_TOL = 3e-3       # soft mask: the reference's bf16 bisection stalls at bf16 spacing of t (|dt| <= 2^-7 -> |dp| <= 2e-3)
+                         # and its p is rounded to bf16 (<= 2^-9 relative = 2e-3 near 1); observed worst 2.2e-3
+                         # (profiles/r03_parity.json), logged every run
+
+# The reference's bf16 BACKWARD (lisbf16_*.npz `topk_grad_bf16`, `bwd_*`: TopK.backward and the training block's autograd with
+# bf16 modules / tokens, every op and every accumulated gradient rounded to bf16) against the build's bf16-storage /
+# fp32-accumulate backward.  Errors are max |got - ref| / max |ref| per quantity; the reference's own bf16 run sits 0.5-3 %
+# (one projection of the rank-1 dWq at N = 5832: 15 %) from its fp32 run, which is what these gates have to admit.
+# Gates = 2 x the worst margin observed on MI355X (profiles/r04_parity.json).
+BF16_BWD_TOL = {"topk_grad": 0.05, "dbk": 0.05, "dwq_u": 0.10, "v_dwq": 0.35, "dwk_u": 0.05, "v_dwk": 0.10, "dx_u": 0.05,
+                "v_dx": 0.05, "dwq": 0.05, "dwk": 0.05, "dx": 0.05, "dbq_over_dbk": 0.05}
 
 
 def bf16_round(x: np.ndarray) -> np.ndarray:
@@ -120,4 +129,38 @@ def check_lis_bf16(case: str, scores, idx_by_budget: dict, g) -> dict:
         assert m[f"symdiff_{tag}"] <= max(2 * m[f"ties_at_kth_{tag}"], 2, int(BF16_IDX_FRAC * k)), (case, tag, m)
         # every disagreement sits at the k boundary: within the score tolerance of the reference's k-th bf16 score
         assert m[f"symdiff_max_dist_to_kth_{tag}"] <= 2 * BF16_SCORE_TOL * scale, (case, tag, m)
+    return m
+
+
+def bf16_bwd_metrics(got: dict, g) -> dict:
+    """got: {'topk_grad' [N], 'dwq' [H,D], 'dbq' [H], 'dwk', 'dbk', 'dx' [N,D]} (any float arrays) of the build, g: one
+    lisbf16_*.npz.  The dense gradients are compared through the same seeded projections the fixtures store."""
+    from oracle import inputs as oin
+    d, hd, n, seed = int(g["d"]), int(g["hd"]), int(g["n"]), int(g["seed"])
+    u_d = oin.make_vec(d, seed + 3000).astype(np.float64)
+    v_h = oin.make_vec(hd, seed + 3001).astype(np.float64)
+    v_n = oin.make_vec(n, seed + 3002).astype(np.float64)
+    a = {k: np.asarray(v, dtype=np.float64) for k, v in got.items()}
+
+    def rel(x, ref):
+        ref = np.asarray(ref, dtype=np.float64)
+        return float(np.abs(x - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+    out = {"n": n, "topk_grad": rel(a["topk_grad"], g["topk_grad_bf16"]), "dbk": rel(a["dbk"], g["bwd_dbk"]),
+           "dwq_u": rel(a["dwq"] @ u_d, g["bwd_dwq_u"]), "v_dwq": rel(v_h @ a["dwq"], g["bwd_v_dwq"]),
+           "dwk_u": rel(a["dwk"] @ u_d, g["bwd_dwk_u"]), "v_dwk": rel(v_h @ a["dwk"], g["bwd_v_dwk"]),
+           "dx_u": rel(a["dx"] @ u_d, g["bwd_dx_u"]), "v_dx": rel(v_n @ a["dx"], g["bwd_v_dx"]),
+           # dbq is ~0 analytically (rs * kbar * sum(dscores), the soft top-k gradient sums to 0): both sides hold rounding noise
+           "dbq_over_dbk": float(max(np.abs(a["dbq"]).max(), np.abs(g["bwd_dbq"]).max()) / max(np.abs(g["bwd_dbk"]).max(), 1e-30))}
+    if "bwd_dwq" in getattr(g, "files", ()):
+        out.update(dwq=rel(a["dwq"], g["bwd_dwq"]), dwk=rel(a["dwk"], g["bwd_dwk"]), dx=rel(a["dx"], g["bwd_dx"]))
+    return out
+
+
+def check_bf16_bwd(case: str, got: dict, g, kind: str = "lis_bwd_bf16") -> dict:
+    m = bf16_bwd_metrics(got, g)
+    record(case, kind, m)
+    for key, tol in BF16_BWD_TOL.items():
+        if key in m:
+            assert m[key] <= tol, (case, key, m)
     return m

@@ -345,3 +345,27 @@ def test_ov_model_splice(golden_dir, name):
     pos, am = splice.slice_positions(pos_in, np.ones((1, L), np.int64), sel)
     assert np.array_equal(pos, g["position_ids"]) and np.array_equal(am, g["attention_mask"])
     assert np.array_equal(np.arange(L)[sel], g["cache_position"])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_fp64_oracle_vs_reference_bf16_backward(golden_dir, cases, name):
+    """The reference's bf16 BACKWARD (TopK.backward + the training block's autograd in bfloat16,
+    FT/compression_method/selector_model.py:60-70, :158-173, :308-313) against the fp64 closed form on the same
+    bf16-representable inputs: how much of the gate tests/parity.BF16_BWD_TOL is the reference's own bf16 rounding."""
+    import parity
+    g = load_bf16(golden_dir, name)
+    c = cases(name)
+    n, d = int(g["n"]), int(g["d"])
+    k = int(g["topk_k"])
+    sc = g["scores_bf16"]
+    ts, _ = lis.find_ts(sc[None], k)
+    gvec = parity.bf16_round(oin.make_vec(n, int(g["seed"]) + 1000)).astype(np.float32)
+    tg = lis.soft_topk_backward(gvec[None], sc[None], np.float32(ts[0, 0]))[0]
+    gmat = parity.bf16_round(np.random.default_rng(int(g["seed"]) + 2000).standard_normal((n, d), dtype=np.float32)
+                             / np.float32(d) ** 0.5)
+    ref = lis.train_backward(c["h"], c["wq"], c["bq"], c["wk"], c["bk"], 0.2, gmat, float(g["bwd_reg_w"]))
+    m = parity.bf16_bwd_metrics({"topk_grad": tg, "dwq": ref["dwq"], "dbq": ref["dbq"], "dwk": ref["dwk"], "dbk": ref["dbk"],
+                                 "dx": ref["dx"]}, g)
+    for key, tol in parity.BF16_BWD_TOL.items():
+        if key in m:
+            assert m[key] <= tol, (name, key, m)

@@ -203,3 +203,32 @@ def test_train_bwd_factors_rebuild_the_dense_gradients(ops):
     sync.sync()
     for p, ref in zip(params, (dwq, dbq, dwk, dbk)):
         assert float((p.grad - 2 * ref).abs().max()) <= 2e-6 * max(1e-30, float(ref.abs().max())) + 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------
+# against the reference's OWN bf16 backward (tests/golden/lisbf16_*.npz `topk_grad_bf16`, `bwd_*`): the reference trains with
+# bf16 modules and tokens (FT/qwenvl/train/train_qwen_selector.py:175-180; TopK.backward FT/compression_method/
+# selector_model.py:60-70; block :158-173; BCE :308-313).  TOLERANCE: tests/parity.BF16_BWD_TOL (2 x the observed margins,
+# dominated by the reference's own bf16 rounding -- tests/test_oracle_golden.py measures the same distances for the fp64 form).
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(CASES))
+def test_train_backward_vs_reference_bf16_run(ops, golden_dir, name):
+    import parity
+    g = np.load(os.path.join(golden_dir, f"lisbf16_{name}.npz"))
+    _, d, hd, n, seed = CASES[name]
+    c = oin.make_case(d, hd, n, seed)
+    h, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    k = int(g["topk_k"])
+    # TopK.backward on the reference's bf16 scores with the bf16-rounded seeded g
+    xs = dev(g["scores_bf16"])[None]
+    _, ts = ops.soft_topk_fwd(xs, k)
+    gvec = dev(oin.make_vec(n, seed + 1000)).bfloat16().float()[None]
+    topk_grad = ops.soft_topk_bwd(gvec, xs, ts)[0]
+    # the training block: bf16 tokens / weights / upstream gradient, BCE fused with the reference's weight
+    h_new, ps, y, scores, tts, bce = ops.lis_train_fwd(h, wq, bq, wk, bk, olis.budget_k_train(n, 0.2))
+    assert abs(float(bce[0]) - float(g["bwd_bce_bf16"])) <= 2.0 ** -8 * max(1.0, float(g["bwd_bce_bf16"])) + 1e-3
+    gmat = dev(np.random.default_rng(seed + 2000).standard_normal((n, d), dtype=np.float32) / np.float32(d) ** 0.5).bfloat16()
+    dwq, dbq, dwk, dbk, dh = ops.lis_train_bwd(gmat, h, wq, bq, wk, bk, ps, y, scores, tts, None, float(g["bwd_reg_w"]),
+                                               need_dh=True)
+    got = {"topk_grad": topk_grad, "dwq": dwq, "dbq": dbq, "dwk": dwk, "dbk": dbk, "dx": dh}
+    parity.check_bf16_bwd(f"lis_train_bwd[{name}]", {k_: v.double().cpu().numpy() for k_, v in got.items()}, g)

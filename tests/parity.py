@@ -38,9 +38,12 @@ BF16_PS_TOL = 3e-3       # soft mask: the reference's bf16 bisection stalls at b
 # bf16 modules / tokens, every op and every accumulated gradient rounded to bf16) against the build's bf16-storage /
 # fp32-accumulate backward.  Errors are max |got - ref| / max |ref| per quantity; the reference's own bf16 run sits 0.5-3 %
 # (one projection of the rank-1 dWq at N = 5832: 15 %) from its fp32 run, which is what these gates have to admit.
-# Gates = 2 x the worst margin observed on MI355X (profiles/r04_parity.json).
-BF16_BWD_TOL = {"topk_grad": 0.05, "dbk": 0.05, "dwq_u": 0.10, "v_dwq": 0.35, "dwk_u": 0.05, "v_dwk": 0.10, "dx_u": 0.05,
-                "v_dx": 0.05, "dwq": 0.05, "dwk": 0.05, "dx": 0.05, "dbq_over_dbk": 0.05}
+# Gates = 2 x the worst margin observed on MI355X over the five shapes (profiles/r04_parity.json: topk_grad 0.0093, dbk 0.0087,
+# dWq.u 0.029, v.dWq 0.142, dWk.u 0.015, v.dWk 0.038, dx.u 0.0090, v.dx 0.0063, dense dWq / dWk / dx (tiny) 0.0043 / 0.0055 / 0.0098,
+# |dbq| / max|dbk| 0.0008); the fp64 closed form sits at the same distances (tests/test_oracle_golden.py), i.e. the margins ARE
+# the reference's bf16 rounding.
+BF16_BWD_TOL = {"topk_grad": 0.02, "dbk": 0.02, "dwq_u": 0.06, "v_dwq": 0.30, "dwk_u": 0.03, "v_dwk": 0.08, "dx_u": 0.02,
+                "v_dx": 0.015, "dwq": 0.01, "dwk": 0.012, "dx": 0.02, "dbq_over_dbk": 0.002}
 
 
 def bf16_round(x: np.ndarray) -> np.ndarray:

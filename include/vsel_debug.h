@@ -40,7 +40,10 @@ typedef enum vsel_debug_knob {
   VSEL_KNOB_LIS_SEG_SUMS = 12,    /* sweep 1 by one wave per (segment, column slab), no per-chunk partials: the widest slab (512 / 256 / 128
                                      bf16 columns) that gives this many pairs, else the chunked form (default 896, 0 = never; env
                                      VSEL_SEG_SUMS); bit-identical sums */
-  VSEL_KNOB_COUNT = 13
+  VSEL_KNOB_ATTN_XCD_QUEUE = 13,  /* attention work items on XCD-local queues, one (sequence, kv head) pair's items on one XCD so that the
+                                     stream they share stays in that XCD's L2: -1 by sequence length and pair count per kernel (default), 0 / 1 force (env
+                                     VSEL_ATTN_XCD_QUEUE); placement only, outputs bit-identical */
+  VSEL_KNOB_COUNT = 14
 } vsel_debug_knob;
 
 /* Set knob to value (clamped to the knob's range).  *previous (may be NULL) receives the value it had.

@@ -159,6 +159,26 @@ def test_four_and_eight_wave_dkdv_agree(ops):
         assert float((a.float() - b.float()).abs().max()) <= 2 ** -7 * float(a.float().abs().max())
 
 
+def test_xcd_local_work_queues_do_not_change_results(ops):
+    """Work items on XCD-local queues (a (sequence, kv head) pair's items on one XCD, attn_common.h XcdQueue) or on the single
+    heaviest-first queue: placement only -- forward output, log-sum-exp, dQ, dK and dV are bit-identical, for ragged batches whose
+    queues empty at different times (stealing) and in both dK / dV forms."""
+    from visionselector_amd import _native as N
+    lens = [700, 130, 1500, 64, 900, 333, 1100, 257, 640, 1024, 12, 777, 1300]      # 13 x 4 pairs; > 512 forward / dQ items,
+    res = {}                                                                         # 13 x 12 x 4 = 624 dK / dV items
+    for mode in (0, 1):
+        for waves in (8, 4):
+            with N.debug_knob(attn_xcd_queue=mode, attn_bwd_waves=waves, attn_bwd_split=0):
+                N.profile_start()
+                _, out, lse, g = _run(ops, lens, 28, 4, True, seed=21)
+                prof = N.profile_stop()
+                assert prof["attn_bwd_dq_kernel"][1] == 1 and prof["attn_bwd_dkdv_kernel"][1] == 1
+                res[(mode, waves)] = (out, lse) + tuple(g)
+    for waves in (8, 4):
+        for a, b in zip(res[(0, waves)], res[(1, waves)]):
+            assert torch.equal(a, b)
+
+
 def test_flash_attn_compat_functions(ops):
     """flash_attn_varlen_func / flash_attn_func with the flash-attn call shapes: same packing (differentiable), different
     query / key packings (forward only, bottom-right causal) and the batched dense form."""

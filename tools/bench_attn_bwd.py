@@ -41,5 +41,8 @@ if __name__ == "__main__":
     shapes = [(1, 524), (1, 2368), (8, 524), (4, 2368), (16, 2368), (16, 4096), (4, 8192), (16, 1100)]
     if "--big" in sys.argv:
         shapes = [(16, 4096), (4, 8192), (16, 1100)]
+    if "--shape" in sys.argv:          # --shape N_SEQ L
+        i = sys.argv.index("--shape")
+        shapes = [(int(sys.argv[i + 1]), int(sys.argv[i + 2]))]
     for n_seq, L in shapes:
         run(n_seq, L)

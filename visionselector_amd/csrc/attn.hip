@@ -39,7 +39,7 @@ __device__ __forceinline__ bf16x8_t to_bf16x8(u32x4 v) { return __builtin_bit_ca
 // Persistent work-stealing grid: items = (q-tile, head, sequence), handed out heaviest-first (largest q-tile = most KV
 // tiles under the causal mask) through one atomic counter, so the causal triangle is load-balanced over the 2 x 256
 // resident workgroups instead of being bounded by the last q-tile (1.9x fewer tiles on the critical path at L = 2368).
-__device__ int g_attn_work_counter[64];
+__device__ int g_attn_work_counter[64 * 8];   // 64 launch slots x 8 XCD-local queues (attn_common.h, XcdQueue)
 
 #ifdef VSEL_TRACE
 // s_memtime (shader clock) stamps of ONE steady-state tile of workgroup 0's first item, one row per wave (tools/trace_attn_fwd.py)
@@ -164,19 +164,23 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
     return (src < kParts ? src : 0) * 8;
   };
 
+  // slot: -1 = one item per workgroup; else launch slot | 0x100 when the items sit on XCD-local queues (a (sequence, kv head) pair's
+  // query tiles, heaviest first, the group's q heads inner -- attn_common.h)
+  const bool xcd_local = !PACK && slot >= 0 && (slot & 0x100) != 0;
+  XcdQueue wq{&g_attn_work_counter[8 * (max(slot, 0) & 0xff)], n_seq * hkv, q_tiles * rep, xcc_id(), 0};
   for (int round = 0;; ++round) {
   int item;
   if (slot < 0) {                       // one item per workgroup (n_items <= resident slots): no counter needed
     if (round > 0) return;
     item = blockIdx.x;
+    if (item >= n_items) return;
+  } else if (xcd_local) {
+    item = xcd_queue_next(wq, &s_item, tid);
   } else {
-    if (tid == 0) s_item = atomicAdd(&g_attn_work_counter[slot], 1);
-    __syncthreads();
-    item = s_item;
-    __syncthreads();
+    item = global_queue_next(wq.counters, n_items, &s_item, tid);
   }
   item = __builtin_amdgcn_readfirstlane(item);      // (uniform by construction; lets the address arithmetic run on the scalar ALU)
-  if (item >= n_items) return;
+  if (item < 0) return;
   VSEL_STAMP(0, 0);
   int qtile, head, seq, kvh;
   if constexpr (PACK) {
@@ -184,6 +188,12 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
     kvh = item % hkv;
     seq = item / hkv;
     head = kvh * rep + (j % rep);                             // per lane
+  } else if (xcd_local) {
+    const int pair = item / wq.per_pair, r = item % wq.per_pair;
+    seq = pair / hkv;
+    kvh = pair % hkv;
+    qtile = r / rep;
+    head = kvh * rep + r % rep;
   } else {
     qtile = item / (hq * n_seq);                               // counted from the END of the sequence: 0 = its last (heaviest) tile
     const int rest = item % (hq * n_seq);
@@ -692,7 +702,10 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
     slot = (int)(next_slot++ & 63u);
     int* counters = nullptr;
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_attn_work_counter)));
-    VSEL_HIP_CHECK(hipMemsetAsync(counters + slot, 0, sizeof(int), st));
+    VSEL_HIP_CHECK(hipMemsetAsync(counters + 8 * slot, 0, 8 * sizeof(int), st));
+    // forward: +1.4 ... +3 % from 2048 tokens x 16 pairs (16 x 4096 982 -> 1011 TFLOP/s, 4 x 8192 1070 -> 1099, 16 x 2368 810 -> 822,
+    // 4 x 2368 746 -> 760); one sequence (4 pairs) -12 %, 524-token sequences -40 %: those keep the single queue
+    if (!pack && attn_use_xcd_queues(max_seqlen_q, n_seq * hkv, 2048, 16)) slot |= 0x100;
   }
   const dim3 grid((unsigned)std::min<int64_t>(n_items, slots));
   const float sl2 = scale * 1.4426950408889634f;

@@ -36,7 +36,16 @@ constexpr int kTile = kTileRows;   // rows per LDS tile
 constexpr int kTileB = kTileBytes;
 constexpr float kLog2e = 1.4426950408889634f;
 
-__device__ int g_bwd_counter[64];
+// two fp32 -> packed bf16 pair, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32; same rounding as f32_to_bf16_bits for
+// every finite value).  The software form keeps five rounding constants live in registers across the whole item loop, which is
+// what pushed the 8-wave dK/dV kernel past 256 registers.
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ int g_bwd_counter[64 * 8];        // 64 launch slots x 8 XCD-local queues (attn_common.h, XcdQueue)
 
 #ifdef VSEL_TRACE
 // s_memtime (shader clock) stamps of ONE steady-state dK/dV tile of workgroup 0, one row per wave (tools/trace_attn_bwd.py)
@@ -59,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     const uint16_t* __restrict__ dout, const uint16_t* __restrict__ out_fwd, const float* __restrict__ lse,
     float* __restrict__ dvec, float* __restrict__ lse2_out,
     const int32_t* __restrict__ cu, int hq, int hkv, float scale, int causal, uint16_t* __restrict__ dq, int q_tiles, int n_seq,
-    int slot) {
+    int slot, int xcd_local) {
   // ONE __shared__ object (a second one makes hipcc drain the direct-to-LDS prefetch with s_waitcnt vmcnt(0) before the first
   // ds_read of every tile: attn.hip)
   __shared__ __attribute__((aligned(16))) char smem[4 * kTileB + 16];  // K[2], V[2], work-item slot
@@ -75,22 +84,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
   make_row_addr<8>(row_addr, j, hh);
   make_tr_addr<4>(tr_addr, lane);
 
+  // work items: (sequence, kv head) pairs on XCD-local queues; a pair's items = query tiles heaviest first, the group's q heads inner
+  const int rep_q = hq / hkv;
+  XcdQueue wq{&g_bwd_counter[8 * max(slot, 0)], n_seq * hkv, q_tiles * rep_q, xcc_id(), 0};
   for (int round = 0;; ++round) {
-    int item;
-    if (slot < 0) {
-      if (round > 0) return;
-      item = blockIdx.x;
+    int t_end, head, seq;
+    if (slot < 0 || !xcd_local) {
+      if (slot < 0 && round > 0) return;
+      const int item = slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
+      if (item < 0 || item >= n_items) return;
+      t_end = item / (hq * n_seq);                               // query tile counted from the heaviest one
+      const int rest = item % (hq * n_seq);
+      head = rest % hq, seq = rest / hq;
     } else {
-      if (tid == 0) s_item = atomicAdd(&g_bwd_counter[slot], 1);
-      __syncthreads();
-      item = s_item;
-      __syncthreads();
+      const int item = xcd_queue_next(wq, &s_item, tid);
+      if (item < 0) return;
+      const int pair = item / wq.per_pair, r = item % wq.per_pair;
+      seq = pair / hkv;
+      t_end = r / rep_q;
+      head = (pair % hkv) * rep_q + r % rep_q;
     }
-    item = __builtin_amdgcn_readfirstlane(item);       // (uniform by construction: lets the per-item / per-tile address arithmetic run on the scalar ALU)
-    if (item >= n_items) return;
-    const int t_end = item / (hq * n_seq);                       // query tile counted from the heaviest one
-    const int rest = item % (hq * n_seq);
-    const int head = rest % hq, seq = rest / hq;
     const int qs = cu[seq];
     const int len = cu[seq + 1] - qs;
     // Under the causal mask the query tiles are aligned to the END of the sequence, so that its partial tile is the first one
@@ -256,8 +269,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
         for (int g4 = 0; g4 < 4; ++g4) {
           const int d0 = 32 * dt + 8 * g4 + 4 * hh;
           uint2 pk;
-          pk.x = f32_to_bf16_bits(acc[dt][4 * g4] * scale) | (f32_to_bf16_bits(acc[dt][4 * g4 + 1] * scale) << 16);
-          pk.y = f32_to_bf16_bits(acc[dt][4 * g4 + 2] * scale) | (f32_to_bf16_bits(acc[dt][4 * g4 + 3] * scale) << 16);
+          pk.x = pack_bf16x2(acc[dt][4 * g4] * scale, acc[dt][4 * g4 + 1] * scale);
+          pk.y = pack_bf16x2(acc[dt][4 * g4 + 2] * scale, acc[dt][4 * g4 + 3] * scale);
           *reinterpret_cast<uint2*>(op + d0) = pk;
         }
     }
@@ -276,7 +289,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
     const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dvec,
     const int32_t* __restrict__ cu, int hq, int hkv, float scale, int causal, uint16_t* __restrict__ dk,
-    uint16_t* __restrict__ dv, float* __restrict__ dk_part, float* __restrict__ dv_part, int k_blocks, int n_seq, int slot) {
+    uint16_t* __restrict__ dv, float* __restrict__ dk_part, float* __restrict__ dv_part, int k_blocks, int n_seq, int slot,
+    int xcd_local) {
   // ONE __shared__ object (see attn_bwd_dq_kernel): Q[2], dO[2], lse[2][kTile], D[2][kTile], work-item slot
   __shared__ __attribute__((aligned(16))) char smem[4 * kTileB + 4 * kTile * sizeof(float) + 16];
   float (*lse_sm)[kTile] = reinterpret_cast<float (*)[kTile]>(smem + 4 * kTileB);
@@ -295,22 +309,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
   make_row_addr<8>(row_addr, j, hh);
   make_tr_addr<4>(tr_addr, lane);
 
+  // work items: (sequence, kv head) pairs on XCD-local queues; a pair's items = (SPLIT: q head of the group, outer) key blocks,
+  // block 0 first -- under the causal mask it is seen by the most queries
+  XcdQueue wq{&g_bwd_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * (SPLIT ? rep : 1), xcc_id(), 0};
   for (int round = 0;; ++round) {
-    int item;
-    if (slot < 0) {
-      if (round > 0) return;
-      item = blockIdx.x;
+    int kblock, hsel, seq;
+    if (slot < 0 || !xcd_local) {
+      if (slot < 0 && round > 0) return;
+      const int item = slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
+      if (item < 0 || item >= n_items) return;
+      kblock = item / (heads_per_item_dim * n_seq);
+      const int rest = item % (heads_per_item_dim * n_seq);
+      hsel = rest % heads_per_item_dim, seq = rest / heads_per_item_dim;
     } else {
-      if (tid == 0) s_item = atomicAdd(&g_bwd_counter[slot], 1);
-      __syncthreads();
-      item = s_item;
-      __syncthreads();
+      const int item = xcd_queue_next(wq, &s_item, tid);
+      if (item < 0) return;
+      const int pair = item / wq.per_pair, r = item % wq.per_pair;
+      seq = pair / hkv;
+      kblock = r % k_blocks;
+      hsel = SPLIT ? (pair % hkv) * rep + r / k_blocks : pair % hkv;
     }
-    item = __builtin_amdgcn_readfirstlane(item);       // (uniform by construction: lets the per-item / per-tile address arithmetic run on the scalar ALU)
-    if (item >= n_items) return;
-    const int kblock = item / (heads_per_item_dim * n_seq);   // block 0 first: under the causal mask it is seen by the most queries
-    const int rest = item % (heads_per_item_dim * n_seq);
-    const int hsel = rest % heads_per_item_dim, seq = rest / heads_per_item_dim;
     const int kvh = SPLIT ? hsel / rep : hsel;
     const int qs = cu[seq];
     const int len = cu[seq + 1] - qs;
@@ -490,11 +508,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
         for (int g4 = 0; g4 < 4; ++g4) {
           const int d0 = 32 * dt + 8 * g4 + 4 * hh;
           uint2 pk;
-          pk.x = f32_to_bf16_bits(dka[dt][4 * g4] * scale) | (f32_to_bf16_bits(dka[dt][4 * g4 + 1] * scale) << 16);
-          pk.y = f32_to_bf16_bits(dka[dt][4 * g4 + 2] * scale) | (f32_to_bf16_bits(dka[dt][4 * g4 + 3] * scale) << 16);
+          pk.x = pack_bf16x2(dka[dt][4 * g4] * scale, dka[dt][4 * g4 + 1] * scale);
+          pk.y = pack_bf16x2(dka[dt][4 * g4 + 2] * scale, dka[dt][4 * g4 + 3] * scale);
           *reinterpret_cast<uint2*>(dk + ro + d0) = pk;
-          pk.x = f32_to_bf16_bits(dva[dt][4 * g4]) | (f32_to_bf16_bits(dva[dt][4 * g4 + 1]) << 16);
-          pk.y = f32_to_bf16_bits(dva[dt][4 * g4 + 2]) | (f32_to_bf16_bits(dva[dt][4 * g4 + 3]) << 16);
+          pk.x = pack_bf16x2(dva[dt][4 * g4], dva[dt][4 * g4 + 1]);
+          pk.y = pack_bf16x2(dva[dt][4 * g4 + 2], dva[dt][4 * g4 + 3]);
           *reinterpret_cast<uint2*>(dv + ro + d0) = pk;
         }
     }
@@ -520,7 +538,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
     const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dvec,
     const int32_t* __restrict__ cu, int hq, int hkv, float scale, int causal, uint16_t* __restrict__ dk,
-    uint16_t* __restrict__ dv, float* __restrict__ dk_part, float* __restrict__ dv_part, int k_blocks, int n_seq, int slot) {
+    uint16_t* __restrict__ dv, float* __restrict__ dk_part, float* __restrict__ dv_part, int k_blocks, int n_seq, int slot,
+    int xcd_local) {
   constexpr int kKV = 2 * kTileB;                               // one 128-key tile
   __shared__ __attribute__((aligned(16))) char smem[2 * kKV + 4 * kTileB + 4 * kTile * sizeof(float) + 16];
   char* const k_sm = smem;
@@ -557,22 +576,26 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
   auto q_addr = [&](int st) { return q_base + ((32 * st) ^ q_x); };
   auto kv_addr = [&](int st) { return kv_base + ((32 * st) ^ kv_x); };
 
+  // work items: (sequence, kv head) pairs on XCD-local queues; a pair's items = (SPLIT: q head of the group, outer) key blocks,
+  // block 0 first -- under the causal mask it is seen by the most queries
+  XcdQueue wq{&g_bwd_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * (SPLIT ? rep : 1), xcc_id(), 0};
   for (int round = 0;; ++round) {
-    int item;
-    if (slot < 0) {
-      if (round > 0) return;
-      item = blockIdx.x;
+    int kblock, hsel, seq;
+    if (slot < 0 || !xcd_local) {
+      if (slot < 0 && round > 0) return;
+      const int item = slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
+      if (item < 0 || item >= n_items) return;
+      kblock = item / (heads_per_item_dim * n_seq);
+      const int rest = item % (heads_per_item_dim * n_seq);
+      hsel = rest % heads_per_item_dim, seq = rest / heads_per_item_dim;
     } else {
-      if (tid == 0) s_item = atomicAdd(&g_bwd_counter[slot], 1);
-      __syncthreads();
-      item = s_item;
-      __syncthreads();
+      const int item = xcd_queue_next(wq, &s_item, tid);
+      if (item < 0) return;
+      const int pair = item / wq.per_pair, r = item % wq.per_pair;
+      seq = pair / hkv;
+      kblock = r % k_blocks;
+      hsel = SPLIT ? (pair % hkv) * rep + r / k_blocks : pair % hkv;
     }
-    item = __builtin_amdgcn_readfirstlane(item);       // (uniform by construction: lets the per-item / per-tile address arithmetic run on the scalar ALU)
-    if (item >= n_items) return;
-    const int kblock = item / (heads_per_item_dim * n_seq);
-    const int rest = item % (heads_per_item_dim * n_seq);
-    const int hsel = rest % heads_per_item_dim, seq = rest / heads_per_item_dim;
     const int kvh = SPLIT ? hsel / rep : hsel;
     const int qs = cu[seq];
     const int len = cu[seq + 1] - qs;
@@ -663,8 +686,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
           const bf16x8_t aq = as_bf16x8(*reinterpret_cast<const u32x4*>(qtile + q_addr(st)));
-          const bf16x8_t kf = as_bf16x8(*reinterpret_cast<const u32x4*>(k_sm + kv_addr(st)));
           const bf16x8_t ad = as_bf16x8(*reinterpret_cast<const u32x4*>(dotile + q_addr(st)));
+          const bf16x8_t kf = as_bf16x8(*reinterpret_cast<const u32x4*>(k_sm + kv_addr(st)));
           const bf16x8_t vf = as_bf16x8(*reinterpret_cast<const u32x4*>(v_sm + kv_addr(st)));
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf, s, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf, dp, 0, 0, 0);
@@ -810,11 +833,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
           for (int g4 = 0; g4 < 4; ++g4) {
             const int d0 = 32 * dt + 8 * g4 + 4 * hh;
             uint2 pk;
-            pk.x = f32_to_bf16_bits(dka[dt][4 * g4] * scale) | (f32_to_bf16_bits(dka[dt][4 * g4 + 1] * scale) << 16);
-            pk.y = f32_to_bf16_bits(dka[dt][4 * g4 + 2] * scale) | (f32_to_bf16_bits(dka[dt][4 * g4 + 3] * scale) << 16);
+            pk.x = pack_bf16x2(dka[dt][4 * g4] * scale, dka[dt][4 * g4 + 1] * scale);
+            pk.y = pack_bf16x2(dka[dt][4 * g4 + 2] * scale, dka[dt][4 * g4 + 3] * scale);
             *reinterpret_cast<uint2*>(dk + ro + d0) = pk;
-            pk.x = f32_to_bf16_bits(dva[dt][4 * g4]) | (f32_to_bf16_bits(dva[dt][4 * g4 + 1]) << 16);
-            pk.y = f32_to_bf16_bits(dva[dt][4 * g4 + 2]) | (f32_to_bf16_bits(dva[dt][4 * g4 + 3]) << 16);
+            pk.x = pack_bf16x2(dva[dt][4 * g4], dva[dt][4 * g4 + 1]);
+            pk.y = pack_bf16x2(dva[dt][4 * g4 + 2], dva[dt][4 * g4 + 3]);
             *reinterpret_cast<uint2*>(dv + ro + d0) = pk;
           }
       }
@@ -842,11 +865,11 @@ __global__ __launch_bounds__(256) void attn_bwd_group_sum_kernel(const float* __
     b += *reinterpret_cast<const f32x4*>(dv_part + o);
   }
   uint2 pk;
-  pk.x = f32_to_bf16_bits(a.x * scale) | (f32_to_bf16_bits(a.y * scale) << 16);
-  pk.y = f32_to_bf16_bits(a.z * scale) | (f32_to_bf16_bits(a.w * scale) << 16);
+  pk.x = pack_bf16x2(a.x * scale, a.y * scale);
+  pk.y = pack_bf16x2(a.z * scale, a.w * scale);
   *reinterpret_cast<uint2*>(dk + tg * kD + 4 * c) = pk;
-  pk.x = f32_to_bf16_bits(b.x) | (f32_to_bf16_bits(b.y) << 16);
-  pk.y = f32_to_bf16_bits(b.z) | (f32_to_bf16_bits(b.w) << 16);
+  pk.x = pack_bf16x2(b.x, b.y);
+  pk.y = pack_bf16x2(b.z, b.w);
   *reinterpret_cast<uint2*>(dv + tg * kD + 4 * c) = pk;
 }
 
@@ -912,10 +935,15 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
     slot = -1;
     if (n_items > resident) {
       slot = (int)(next_slot++ & 63u);
-      if (hipMemsetAsync(counters + slot, 0, sizeof(int), st) != hipSuccess) return fail(VSEL_ERR_HIP, "hipMemsetAsync(counter)");
+      if (hipMemsetAsync(counters + 8 * slot, 0, 8 * sizeof(int), st) != hipSuccess) return fail(VSEL_ERR_HIP, "hipMemsetAsync(counter)");
     }
     return VSEL_OK;
   };
+  // dQ: on from 2048 tokens x 32 pairs (16 x 2368 1078 -> 1041 us, 16 x 4096 2912 -> 2866; 4 x 2368 +8 %, 4 x 8192 +0.7 % stay off);
+  // dK / dV: from 4096 tokens x 16 pairs (16 x 4096 3950 -> 3865 us, 4 x 8192 3820 -> 3810; 16 x 2368 -- 19 key blocks per pair, a
+  // ragged fit on 32 CUs -- +8.5 % stays off)
+  const int xcd_local_dq = attn_use_xcd_queues(max_seqlen, n_seq * hkv, 2048, 32);
+  const int xcd_local_dkdv = attn_use_xcd_queues(max_seqlen, n_seq * hkv, 4096, 16);
   // dQ first: it also leaves D = rowsum(dO * O) and the exp2-domain log-sum-exp in the workspace for the dK / dV kernel
   {
     const int q_tiles = (int)cdiv(max_seqlen, 128);
@@ -926,7 +954,7 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
     hipLaunchKernelGGL(bwd::attn_bwd_dq_kernel, dim3((unsigned)std::min<int64_t>(n_items, 512)), dim3(256), 0, st,
                        (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, (const uint16_t*)out, lse, dvec, lse2,
                        cu_seqlens,
-                       (int)hq, (int)hkv, scale, causal, (uint16_t*)dq, q_tiles, (int)n_seq, slot);
+                       (int)hq, (int)hkv, scale, causal, (uint16_t*)dq, q_tiles, (int)n_seq, slot, xcd_local_dq);
     VSEL_AFTER_LAUNCH(st, "attn_bwd_dq_kernel");
   }
   {
@@ -941,7 +969,7 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
     const dim3 grid((unsigned)std::min<int64_t>(n_items, 256));
     const bool w8 = knob(VSEL_KNOB_ATTN_BWD_WAVES) == 8;
 #define VSEL_DKDV_ARGS (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu_seqlens, (int)hq, \
-                       (int)hkv, scale, causal, (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, k_blocks, (int)n_seq, slot
+                       (int)hkv, scale, causal, (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, k_blocks, (int)n_seq, slot, xcd_local_dkdv
     if (w8) {
       if (split) hipLaunchKernelGGL((bwd::attn_bwd_dkdv2_kernel<true>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS);
       else hipLaunchKernelGGL((bwd::attn_bwd_dkdv2_kernel<false>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS);

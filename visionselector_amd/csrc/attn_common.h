@@ -72,6 +72,60 @@ __device__ __forceinline__ void load_slice_lds(const uint16_t* src_row_ptr, int 
 // 4 i + (l >> 4) holds part (l & 15) ^ swz(row), and swz(row) = ((l >> 4) << 2) | (w & 3) for every such slice.
 __device__ __forceinline__ int slice_src_part(int lane, int wave) { return (lane & 15) ^ (((lane >> 4) << 2) | (wave & 3)); }
 
+// ---- XCD-local work queues (round 4) ------------------------------------------------------------------------------------------
+// Every attention kernel streams one operand pair (K / V in the forward and the dQ pass, Q / dO in the dK / dV pass) that ALL the
+// work items of a (sequence, kv head) pair share.  With one global queue the workgroups resident on an XCD belong to 8+ different
+// pairs and the shared stream misses that XCD's 4 MB L2 (measured at 16 x 4096: L2 hit rate 19 % in the dK / dV pass, 63 % dQ,
+// 69 % forward; 4.6 TB/s of memory-side reads in the dK / dV pass -- it ran at the fabric limit, not at the matrix pipe).
+// Pair p is therefore queued on XCD p % 8: a workgroup takes items from the queue of the XCD it runs on (HW_REG_XCC_ID) and, when
+// that queue is empty, helps the next one (p % 8 + 1, ...), so ragged batches still balance.  Placement only changes speed: which
+// workgroup computes an item never changes the item's arithmetic (outputs stay bit-identical).
+//   counters: int[8], zeroed by the host before the launch.  -> item index in [0, n_pairs * per_pair), or -1 when all is done.
+//   item index = pair * per_pair + r, r = the pair's items heaviest first.
+struct XcdQueue {
+  int* counters;
+  int n_pairs, per_pair;
+  int cur, tried;            // queue being drained, queues found empty so far
+};
+// one global queue in the legacy item order (short sequences: a pair's stream is small and heaviest-first over ALL pairs balances
+// better than per-XCD lists): -> item in [0, n_items) or -1
+__device__ __forceinline__ int global_queue_next(int* counter, int n_items, int* s_item, int tid) {
+  if (tid == 0) {
+    const int idx = atomicAdd(counter, 1);
+    *s_item = idx < n_items ? idx : -1;
+  }
+  __syncthreads();
+  const int item = *s_item;
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane(item);
+}
+__device__ __forceinline__ int xcc_id() {
+  int v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+  return v & 7;
+}
+// thread 0 of the workgroup fetches, the result travels through *s_item (LDS); two barriers per item, as the single queue had
+__device__ __forceinline__ int xcd_queue_next(XcdQueue& q, int* s_item, int tid) {
+  if (tid == 0) {
+    int item = -1;
+    while (q.tried < 8) {
+      const int mine = q.cur < q.n_pairs ? (q.n_pairs - q.cur + 7) >> 3 : 0;      // pairs cur, cur + 8, ...
+      const int idx = mine > 0 ? atomicAdd(&q.counters[q.cur], 1) : 0;
+      if (idx < mine * q.per_pair) {
+        item = (q.cur + 8 * (idx / q.per_pair)) * q.per_pair + idx % q.per_pair;
+        break;
+      }
+      q.cur = (q.cur + 1) & 7;
+      ++q.tried;
+    }
+    *s_item = item;
+  }
+  __syncthreads();
+  const int item = *s_item;
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane(item);
+}
+
 // ---- LDS reads the compiler does not schedule ----------------------------------------------------------------------------
 // hipcc turns the tile body into "ds_read; s_waitcnt lgkmcnt(0); v_mfma" triples (every MFMA behind a full LDS round trip,
 // MFMA-busy 34 %) and, for the transpose-read builtin, puts s_waitcnt vmcnt(0) in front of the first V read, which drains the
@@ -81,7 +135,8 @@ __device__ __forceinline__ int slice_src_part(int lane, int wave) { return (lane
 // The asm outputs are "ready" for the compiler at once although the data lands only at the lds_wait* that names them: a
 // compiler-inserted COPY or SPILL of such a register between issue and wait would read a stale value.  Guards: the outputs are
 // early-clobber (never share a register with the address), every user kernel must compile with 0 spilled VGPRs -- checked at
-// build time by visionselector_amd/build.py (-Rpass-analysis=kernel-resource-usage on attn.hip; the build fails otherwise) --
+// build time by visionselector_amd/build.py (-Rpass-analysis=kernel-resource-usage on attn.hip and attn_bwd.hip, kernels listed
+// in build.ASM_READ_KERNELS: 0 spilled VGPRs and 0 bytes of scratch or the build fails) --
 // and VSEL_HIPCC_FLAGS refuses optimisation-level / debug flags that would change the register allocation wholesale.
 __device__ __forceinline__ uint32_t lds_u32(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;

@@ -46,6 +46,11 @@ static __device__ unsigned long long g_trace[kTraceKernels][kTraceBlocks][kTrace
 
 // ---- diagnostic knobs (include/vsel_debug.h): one process-global table, relaxed atomic reads -------------------------
 int knob(int id);
+// XCD-local work queues of the attention kernels (attn_common.h, XcdQueue): knob VSEL_KNOB_ATTN_XCD_QUEUE forces them on / off;
+// -1 (default) = on from min_len tokens in the longest sequence and min_pairs (sequence, kv head) pairs.  The thresholds are per
+// kernel (same-binary A/B on MI355X, profiles/r04_attn_xcd_queue.txt): a pair-major list is a worse load balance than heaviest-
+// first over all pairs when a pair has few items, so short / few sequences keep the single queue.
+int attn_use_xcd_queues(int64_t max_seqlen, int64_t n_pairs, int64_t min_len, int64_t min_pairs);
 
 // ---- error plumbing --------------------------------------------------------------------------
 void set_error(const std::string& msg);

@@ -43,6 +43,7 @@ constexpr KnobSpec kKnobs[VSEL_KNOB_COUNT] = {
     {"VSEL_ATTN_BWD_WAVES", 8, 4, 8},  // VSEL_KNOB_ATTN_BWD_WAVES
     {nullptr, -1, -1, 1},              // VSEL_KNOB_ATTN_TAIL_FIRST
     {"VSEL_SEG_SUMS", 896, 0, 1 << 30},  // VSEL_KNOB_LIS_SEG_SUMS
+    {"VSEL_ATTN_XCD_QUEUE", -1, -1, 1},  // VSEL_KNOB_ATTN_XCD_QUEUE
 };
 int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 int knob_default(int id) {
@@ -60,6 +61,10 @@ KnobTable& knobs() {
 }
 }  // namespace
 int knob(int id) { return knobs().v[id].load(std::memory_order_relaxed); }
+int attn_use_xcd_queues(int64_t max_seqlen, int64_t n_pairs, int64_t min_len, int64_t min_pairs) {
+  const int k = knob(VSEL_KNOB_ATTN_XCD_QUEUE);
+  return k >= 0 ? k : ((max_seqlen >= min_len && n_pairs >= min_pairs) ? 1 : 0);
+}
 }  // namespace vsel
 
 extern "C" int vsel_debug_set(int id, int value, int* previous) {

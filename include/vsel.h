@@ -197,7 +197,9 @@ int vsel_splice(void* stream, const int64_t* input_ids, int64_t seq_len, int64_t
  * and the scorer needs their row mean first (selector_scorer.py:47-53 collapsed: DESIGN.md section 3).  The last Linear is
  * linear, so  sum_rows(H) = sum_rows(G) W2^T + N b2  with G the GELU output:
  *   vsel_gelu_colsum  replaces the merger's GELU launch: y = GELU(x) (erf form, fp32 math, as nn.GELU()) and
- *     col_sums [n_seg, cols] fp32 = per-segment column sums of y as rounded to `dtype` -- no extra HBM traffic;
+ *     col_sums [n_seg, cols] fp32 = per-segment column sums of y as rounded to `dtype` -- no extra HBM traffic
+ *     (col_sums == NULL: y only, workspace unused -- the same streaming GELU without its sums, which is what a
+ *     benchmark must subtract to price the sums);
  *   vsel_lis_select_presummed  = vsel_lis_select (row maps NULL) / vsel_lis_select_permuted (row maps given) with the
  *     column sums of the tokens supplied by the caller (col_sums [n_seg, D] fp32), skipping the first sweep over H.
  * The caller forms sum_rows(H) from sum_rows(G) with one skinny fp32 GEMM (a library call).                          */

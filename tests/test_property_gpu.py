@@ -128,6 +128,9 @@ def test_gelu_colsum_matches_torch(rows, cols, n_seg, dt):
     # deterministic
     y2, sums2 = ops.gelu_colsum(x, n_seg)
     assert torch.equal(sums, sums2)
+    # the sums-free form of the same kernel (col_sums == NULL; bench.py's baseline for pricing the sums): same y
+    y3, none = ops.gelu_colsum(x, n_seg, sums=False)
+    assert none is None and torch.equal(y3, ref)
 
 
 @pytest.mark.parametrize("storage", ["bf16", "f32"])

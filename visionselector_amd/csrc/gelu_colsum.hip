@@ -29,7 +29,9 @@ inline int gelu_rows_per_wg(const vsel_segments* seg, int64_t cols, int vec) {
 
 // NT: the activation is far larger than the caches and both x and y are touched once here -> non-temporal loads and stores
 // (chosen from 384 MB of activation up, as the LIS sweeps do): 1355 vs 1402 us (torch) at 294 912 x 5120, before 1.07x torch's.
-template <typename T, bool NT>
+// SUMS = false: the same streaming GELU without the column sums (col_sums == NULL at the entry point): the merger's GELU as this
+// library would run it anyway -- what bench.py subtracts when it charges the LIS for the sums (not torch's slower kernel).
+template <typename T, bool NT, bool SUMS = true>
 __global__ __launch_bounds__(256) void gelu_colsum_kernel(const T* __restrict__ x, SegView sv, int c, int row_splits, int rows_per_wg,
                                                           T* __restrict__ y, float* __restrict__ partial) {
   constexpr int V = Elem<T>::kVec;
@@ -78,26 +80,28 @@ __global__ __launch_bounds__(256) void gelu_colsum_kernel(const T* __restrict__ 
         if constexpr (NT) __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(y + base + (int64_t)r * c));
         else *reinterpret_cast<u32x4*>(y + base + (int64_t)r * c) = pk;
 #pragma unroll
-        for (int i = 0; i < V; ++i) acc[i] += __uint_as_float(bits[i] << 16);
+        for (int i = 0; i < V; ++i) if constexpr (SUMS) acc[i] += __uint_as_float(bits[i] << 16);
       } else {
         f32x4 o = {v[0], v[1], v[2], v[3]};
         if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(y + base + (int64_t)r * c));
         else *reinterpret_cast<f32x4*>(y + base + (int64_t)r * c) = o;
 #pragma unroll
-        for (int i = 0; i < V; ++i) acc[i] += v[i];
+        for (int i = 0; i < V; ++i) if constexpr (SUMS) acc[i] += v[i];
       }
       cur = nx1;
       nx1 = nx2;
     }
   }
-  __shared__ float red[4][64][V + 1];
+  if constexpr (SUMS) {
+    __shared__ float red[4][64][V + 1];
 #pragma unroll
-  for (int i = 0; i < V; ++i) red[wave][lane][i] = acc[i];
-  __syncthreads();
-  if (wave == 0 && col < c) {
-    float* dst = partial + ((int64_t)(s * row_splits + rs) * c + col);
+    for (int i = 0; i < V; ++i) red[wave][lane][i] = acc[i];
+    __syncthreads();
+    if (wave == 0 && col < c) {
+      float* dst = partial + ((int64_t)(s * row_splits + rs) * c + col);
 #pragma unroll
-    for (int i = 0; i < V; ++i) dst[i] = (red[0][lane][i] + red[1][lane][i]) + (red[2][lane][i] + red[3][lane][i]);
+      for (int i = 0; i < V; ++i) dst[i] = (red[0][lane][i] + red[1][lane][i]) + (red[2][lane][i] + red[3][lane][i]);
+    }
   }
 }
 
@@ -232,14 +236,14 @@ extern "C" size_t vsel_gelu_colsum_workspace_bytes(const vsel_segments* seg, int
 
 extern "C" int vsel_gelu_colsum(void* stream, const void* x, vsel_dtype dtype, const vsel_segments* seg, int64_t cols, void* y,
                                 float* col_sums, void* workspace, size_t workspace_bytes) {
-  if (!x || !y || !col_sums || !workspace) return fail(VSEL_ERR_INVALID, "NULL pointer");
+  if (!x || !y || (col_sums && !workspace)) return fail(VSEL_ERR_INVALID, "NULL pointer");
   int rc = check_segments_impl(seg, false);
   if (rc) return rc;
   if (dtype != VSEL_BF16 && dtype != VSEL_F32) return fail(VSEL_ERR_INVALID, "bad dtype");
   const int vec = dtype == VSEL_BF16 ? 8 : 4;
   if (cols < vec || cols % vec) return fail(VSEL_ERR_UNSUPPORTED, "cols must be a multiple of %d", vec);
   if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(VSEL_ERR_INVALID, "x / y must be 16-byte aligned");
-  if (workspace_bytes < vsel_gelu_colsum_workspace_bytes(seg, cols)) return fail(VSEL_ERR_WORKSPACE, "workspace too small");
+  if (col_sums && workspace_bytes < vsel_gelu_colsum_workspace_bytes(seg, cols)) return fail(VSEL_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
   VSEL_PROF_BEGIN(st);
   const SegView sv = make_view(seg);
@@ -249,14 +253,20 @@ extern "C" int vsel_gelu_colsum(void* stream, const void* x, vsel_dtype dtype, c
   float* partial = (float*)workspace;
   const bool nt = seg->total_rows * cols * (dtype == VSEL_BF16 ? 2 : 4) >= kStreamBytes;   // (from 16 / 64 MB up: no difference)
   const dim3 grid((unsigned)cdiv(cols, 64 * vec), row_splits, S);
+#define VSEL_GELU_LAUNCH(T, NTV, SUMSV)                                                                                          \
+  hipLaunchKernelGGL((gelu_colsum_kernel<T, NTV, SUMSV>), grid, dim3(256), 0, st, (const T*)x, sv, (int)cols, row_splits, rows_per_wg, \
+                     (T*)y, partial)
+  const bool sums = col_sums != nullptr;
   if (dtype == VSEL_BF16) {
-    if (nt) hipLaunchKernelGGL((gelu_colsum_kernel<bf16_t, true>), grid, dim3(256), 0, st, (const bf16_t*)x, sv, (int)cols, row_splits, rows_per_wg, (bf16_t*)y, partial);
-    else hipLaunchKernelGGL((gelu_colsum_kernel<bf16_t, false>), grid, dim3(256), 0, st, (const bf16_t*)x, sv, (int)cols, row_splits, rows_per_wg, (bf16_t*)y, partial);
+    if (sums) { if (nt) VSEL_GELU_LAUNCH(bf16_t, true, true); else VSEL_GELU_LAUNCH(bf16_t, false, true); }
+    else { if (nt) VSEL_GELU_LAUNCH(bf16_t, true, false); else VSEL_GELU_LAUNCH(bf16_t, false, false); }
   } else {
-    if (nt) hipLaunchKernelGGL((gelu_colsum_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, sv, (int)cols, row_splits, rows_per_wg, (float*)y, partial);
-    else hipLaunchKernelGGL((gelu_colsum_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, sv, (int)cols, row_splits, rows_per_wg, (float*)y, partial);
+    if (sums) { if (nt) VSEL_GELU_LAUNCH(float, true, true); else VSEL_GELU_LAUNCH(float, false, true); }
+    else { if (nt) VSEL_GELU_LAUNCH(float, true, false); else VSEL_GELU_LAUNCH(float, false, false); }
   }
-  VSEL_AFTER_LAUNCH(st, "gelu_colsum_kernel");
+#undef VSEL_GELU_LAUNCH
+  VSEL_AFTER_LAUNCH(st, sums ? "gelu_colsum_kernel" : "gelu_kernel");
+  if (!sums) return VSEL_OK;
   hipLaunchKernelGGL(gelu_colsum_finish_kernel, dim3((unsigned)cdiv(cols, 64), S), dim3(1024), 0, st, partial, (int)cols, row_splits,
                      col_sums);
   VSEL_AFTER_LAUNCH(st, "gelu_colsum_finish_kernel");

@@ -173,9 +173,10 @@ def lis_select_permuted(h_physical, logical_to_physical, physical_to_logical, wq
     return out, idx, scores
 
 
-def gelu_colsum(x: torch.Tensor, n_seg: int = 1):
+def gelu_colsum(x: torch.Tensor, n_seg: int = 1, sums: bool = True):
     """y = GELU(x) (erf form, as nn.GELU()) and the per-segment column sums of y, in one pass.  x [R, C] (n_seg equal
-    segments of R / n_seg rows) -> (y [R, C] same dtype, col_sums fp32 [n_seg, C])."""
+    segments of R / n_seg rows) -> (y [R, C] same dtype, col_sums fp32 [n_seg, C]).  sums=False: the same kernel without the
+    sums -> (y, None)."""
     dev = _dev(x)
     if x.dim() != 2 or not x.is_contiguous():
         raise ValueError("gelu_colsum takes a contiguous [rows, cols] tensor")
@@ -184,12 +185,15 @@ def gelu_colsum(x: torch.Tensor, n_seg: int = 1):
         raise ValueError(f"rows {r} do not split into {n_seg} equal segments")
     seg = _uniform_segments(n_seg, r // n_seg, 1)
     lib = N.lib()
-    ws = _workspace(lib.vsel_gelu_colsum_workspace_bytes(C.byref(seg), c), dev)
     y = torch.empty_like(x)
-    sums = torch.empty(n_seg, c, dtype=torch.float32, device=dev)
-    N.check(lib.vsel_gelu_colsum(_stream(), x.data_ptr(), _code(x), C.byref(seg), c, y.data_ptr(), sums.data_ptr(),
+    if not sums:
+        N.check(lib.vsel_gelu_colsum(_stream(), x.data_ptr(), _code(x), C.byref(seg), c, y.data_ptr(), None, None, 0))
+        return y, None
+    ws = _workspace(lib.vsel_gelu_colsum_workspace_bytes(C.byref(seg), c), dev)
+    col_sums = torch.empty(n_seg, c, dtype=torch.float32, device=dev)
+    N.check(lib.vsel_gelu_colsum(_stream(), x.data_ptr(), _code(x), C.byref(seg), c, y.data_ptr(), col_sums.data_ptr(),
                                  ws.data_ptr(), ws.numel()))
-    return y, sums
+    return y, col_sums
 
 
 def colsum_linear(col_sums_in: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], rows_per_seg: int):

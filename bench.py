@@ -295,6 +295,11 @@ def main():
             res["single_sweep"] = bench_single_sweep(ops, h, wq, bq, wk, bk, k, idx, path_bytes)
         except Exception as e:  # optional leg: never lose the headline line over it
             res["single_sweep"] = {"error": str(e)[:300]}
+    # ---- the reference's real evaluation call: ONE image per call (EV/token_compression/selector_model.py:182-194, assert :270) ---
+    try:
+        res["batch1"] = bench_batch1(ops, h, wq, bq, wk, bk, k)
+    except Exception as e:  # optional leg: never lose the headline line over it
+        res["batch1"] = {"error": str(e)[:300]}
     # ---- prefill attention at the compressed vs the full length (second half of the metric) ----------
     if not args.no_attn:
         try:
@@ -371,6 +376,42 @@ def bench_single_sweep(ops, h, wq, bq, wk, bk, k, idx_two_sweep, path_bytes, ite
                               "frac_of_8TBps": path_bytes / (charged_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
             "chain_minus_torch_gelu_us": t_chain - t_gelu_torch,
             "idx_equal_two_sweep_with_true_sums": bool(torch.equal(idx1, idx_two_sweep))}
+
+
+def bench_batch1(ops, h, wq, bq, wk, bk, k, n_text=64, iters=200):
+    """One image per call, what the reference's evaluation harness issues (batch 1): (a) vsel_lis_select alone and (b) everything the
+    *_Selector prefill enqueues for the image -- scores, hard top-k, splice of ids / embeddings / M-RoPE positions AND the soft top-k
+    that fills visual.last_combined_scores (EV :190) -- vsel_lis_select_splice with its soft outputs.  us per call, back to back
+    on one stream (HIP events around `iters` calls); path roofline of (a) on the section-8(d) bytes of one image."""
+    n, d = h.shape[1], h.shape[2]
+    img = 151655
+    h1 = h[0].contiguous()
+    ids = torch.cat((torch.arange(10, 10 + n_text // 2), torch.full((n,), img), torch.arange(50, 50 + n_text - n_text // 2))).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    emb = torch.randn(ids.numel(), d, device="cuda", generator=gen).bfloat16()
+    pos = torch.arange(ids.numel(), device="cuda").repeat(3, 1).contiguous()
+
+    def ev_time(fn):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3
+
+    t_sel = ev_time(lambda: ops.lis_select(h1, wq, bq, wk, bk, k))
+    t_call = ev_time(lambda: ops.lis_select_splice(h1, wq, bq, wk, bk, ids, emb, img, [ids.numel()], [n], [k], position_ids=pos,
+                                                   soft=True))
+    bytes1 = algorithmic_bytes(1, n, d, wq.shape[0], k)
+    return {"what": "one image per call (the reference's evaluation call): lis_select_us = vsel_lis_select; eval_call_us = "
+                    "vsel_lis_select_splice with soft outputs (scores + hard top-k + splice + the soft top-k of last_combined_scores)",
+            "lis_select_us": t_sel, "eval_call_us": t_call, "tokens_per_s": n / (t_sel * 1e-6),
+            "roofline_path": {"algorithmic_bytes_per_call": bytes1, "achieved_GBps": bytes1 / (t_sel * 1e-6) / 1e9,
+                              "frac_of_8TBps": bytes1 / (t_sel * 1e-6) / 1e9 / HBM_PEAK_GBS}}
 
 
 def bench_train_step(ops, dist, world, rank, iters=20):

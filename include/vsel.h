@@ -259,6 +259,11 @@ int vsel_splice_batched(void* stream, const int64_t* input_ids, int64_t total_le
  *        new_input_ids int64 [T']; new_inputs_embeds [T', D]; new_position_ids [pos_rows, T']; new_attention_mask [T'] or NULL;
  *        cu_seqlens_out int32 [S + 1] (may be NULL when S == 1); src_scratch int32 [T']; stats int32 [4] = {visual tokens
  *        found, rows written, kept visual rows, prompts whose token counts disagree (0 on success)}.  T' = T - sum N + sum k.
+ *        soft_ps fp32 [sum N], soft_ts fp32 [S] (both or neither; NULL = not wanted): the soft top-k of the same scores, i.e.
+ *        vsel_soft_topk_fwd(scores, k) bit for bit -- what the reference's eval forward publishes next to the selection as
+ *        visual.last_combined_scores (EV/token_compression/selector_model.py:190).  For one prompt of <= 4096 visual tokens
+ *        (the reference's call) it is computed by one extra workgroup of the select-splice launch instead of a launch of its own;
+ *        uniform segments only, written only when 0 < k < N (the reference asserts that, :75).
  * Workspace: vsel_lis_workspace_bytes(seg, D, Hd).                                                                        */
 int vsel_lis_select_splice(void* stream, const void* h, vsel_dtype hdtype, const vsel_segments* seg,
                            const vsel_scorer* scorer, void* workspace, size_t workspace_bytes, const float* col_sums,
@@ -267,7 +272,8 @@ int vsel_lis_select_splice(void* stream, const void* h, vsel_dtype hdtype, const
                            int64_t visual_token_id, const void* inputs_embeds, const int64_t* position_ids, int64_t pos_rows,
                            const int64_t* attention_mask, int64_t* idx, float* scores, int64_t* selected_indices,
                            int64_t* new_input_ids, void* new_inputs_embeds, int64_t* new_position_ids,
-                           int64_t* new_attention_mask, int32_t* cu_seqlens_out, int32_t* src_scratch, int32_t* stats);
+                           int64_t* new_attention_mask, int32_t* cu_seqlens_out, int32_t* src_scratch, int32_t* stats,
+                           float* soft_ps, float* soft_ts);
 
 /* The same on GIVEN scores (fp32 [sum N], logical order; an input here): hard top-k (vsel_topk_select's tie rule) + splice with
  * the kept rows read from h [sum N, d] (through logical_to_physical when not NULL).  EV :187-189 + :246-262.             */
@@ -277,7 +283,7 @@ int vsel_topk_select_splice(void* stream, const void* h, vsel_dtype hdtype, int6
                             const void* inputs_embeds, const int64_t* position_ids, int64_t pos_rows,
                             const int64_t* attention_mask, int64_t* idx, int64_t* selected_indices, int64_t* new_input_ids,
                             void* new_inputs_embeds, int64_t* new_position_ids, int64_t* new_attention_mask,
-                            int32_t* cu_seqlens_out, int32_t* src_scratch, int32_t* stats);
+                            int32_t* cu_seqlens_out, int32_t* src_scratch, int32_t* stats, float* soft_ps, float* soft_ts);
 
 /* -------- var-len causal attention (compressed-sequence prefill) --------------------------------
  * Replaces flash_attn_varlen_func as called by FT/qwenvl/train/trainer.py:101-113 and the FA2 prefill

@@ -412,3 +412,35 @@ def test_select_splice_argument_hygiene(ops, monkeypatch):
         ops.lis_select_splice(h, wq, bq, wk, bk, ids_t, emb_t, IMAGE_TOKEN, seq_lens, visual_lens, ks, check=True)
     with pytest.raises(RuntimeError, match="max_len_out"):              # one prompt: must be exactly its L'
         ops.lis_select_splice(h[:640], wq, bq, wk, bk, ids_t[:700], emb_t[:700], IMAGE_TOKEN, [700], [640], [128], check=True)
+
+
+@pytest.mark.parametrize("n,k,L", [(2304, 460, 2368), (576, 115, 640), (256, 51, 300), (4096, 819, 4200), (5000, 1000, 5100), (640, 640, 700)])
+def test_select_splice_soft_outputs_equal_soft_topk(ops, n, k, L):
+    """soft=True: the soft top-k the reference's eval forward publishes as last_combined_scores (EV/token_compression/
+    selector_model.py:190) comes out of the select-splice call -- one extra workgroup of the same launch up to 4096 tokens, own
+    launch beyond -- and equals vsel_soft_topk_fwd on the same scores bit for bit, in both forms of the call; nothing else
+    changes; k == N publishes nothing (the reference asserts 0 < k < n)."""
+    from visionselector_amd import _native as N
+    d, hd = 2048, 1024
+    rng = np.random.default_rng(n)
+    ids, _, emb, _, pos = _packed_case(rng, [L], [n], [k], d, torch.bfloat16)
+    c = oin.make_case(d, hd, n, 80)
+    h = torch.from_numpy(c["h"]).bfloat16().cuda()
+    wq, bq, wk, bk = (torch.from_numpy(c[x]).bfloat16().cuda() for x in ("wq", "bq", "wk", "bk"))
+    ids_t, emb_t, pos_t = torch.from_numpy(ids).cuda(), emb.cuda(), pos.cuda()
+    base = ops.lis_select_splice(h, wq, bq, wk, bk, ids_t, emb_t, IMAGE_TOKEN, [L], [n], [k], position_ids=pos_t, check=True)
+    for knob in (1, 0):
+        with N.debug_knob("lis_splice_fused", knob):
+            N.profile_start()
+            o = ops.lis_select_splice(h, wq, bq, wk, bk, ids_t, emb_t, IMAGE_TOKEN, [L], [n], [k], position_ids=pos_t, check=True,
+                                      soft=True)
+            prof = N.profile_stop()
+        for key in ("idx", "scores", "selected_indices", "input_ids", "inputs_embeds", "position_ids"):
+            assert torch.equal(o[key], base[key]), key
+        if k == n:
+            assert o["soft_ps"] is None and "soft_topk_fwd_kernel" not in prof
+            continue
+        ps, ts = ops.soft_topk_fwd(o["scores"][None], k)
+        assert torch.equal(o["soft_ps"], ps[0]) and torch.equal(o["soft_ts"], ts)
+        assert ("soft_topk_fwd_kernel" in prof) == (knob == 0 or n > 4096), prof.keys()      # inside the launch when it can be
+        assert abs(float(ps.sum()) - k) <= 1e-2

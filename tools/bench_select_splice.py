@@ -66,6 +66,14 @@ def case(visual_lens, n_text=64, budget=0.2):
         N.profile_start()
         fused()
         res["fused_launches"] = {k_: c for k_, (_, c) in N.profile_stop().items()}
+        if single and 0 < ks[0] < visual_lens[0]:
+            # what the *_Selector prefill enqueues per image (hf_generic.select_and_splice): the fused select-splice AND the soft
+            # top-k that fills visual.last_combined_scores (EV/token_compression/selector_model.py:190)
+            sc = fused()["scores"]
+            res["soft_topk_alone_us"] = round(timed(lambda: ops.soft_topk_fwd(sc[None], ks[0])), 2)
+            res["eval_call_two_launches_us"] = round(timed(lambda: ops.soft_topk_fwd(fused()["scores"][None], ks[0])), 2)
+            res["eval_call_us"] = round(timed(lambda: ops.lis_select_splice(h, wq, bq, wk, bk, ids, emb, IMG, seq_lens, visual_lens, ks,
+                                                                            position_ids=pos, soft=True)), 2)
     with N.debug_knob("lis_splice_fused", 0):
         res["fused_general_form_us"] = round(timed(fused), 2)
     N.profile_start()

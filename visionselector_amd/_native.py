@@ -58,9 +58,9 @@ SIGNATURES = {
     "vsel_splice_batched": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, C.c_int, _I64, _P, _I64,
                                       _P, _P, _P, _P, _P, _P, _P]),
     "vsel_lis_select_splice": (C.c_int, [_P, _P, C.c_int, _SEG, _SC, _P, _SZ, _P, _P, _P, _P, _I64, _P, _I64, _I64, _P, _P, _I64, _P,
-                                         _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                         _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vsel_topk_select_splice": (C.c_int, [_P, _P, C.c_int, _I64, _SEG, _P, _P, _P, _I64, _P, _I64, _I64, _P, _P, _I64, _P, _P, _P,
-                                          _P, _P, _P, _P, _P, _P, _P]),
+                                          _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vsel_varlen_attn_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, C.c_int, _P]),
     "vsel_varlen_attn_fwd_lse": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, C.c_int, _P, _P]),
     "vsel_varlen_attn_bwd_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64, _I64]),

@@ -13,6 +13,7 @@
 //   otherwise: topk_select -> splice_index_seg_kernel (one workgroup per prompt, descriptors point into H) -> splice_embed_kernel.
 // Integer arithmetic and raw 16-byte copies only: bit-identical to vsel_lis_select + vsel_splice(_batched) in every output.
 #include "lis_kernels.h"
+#include "softtopk.h"
 #include "lis_small.h"
 #include "proj_bf16x3.h"
 #include "splice_kernels.h"
@@ -75,6 +76,13 @@ static __global__ __launch_bounds__(kSpliceThreads) void splice_index_seg_kernel
   }
 }
 
+// soft top-k of one row (softtopk.hip)
+int launch_soft_topk_fwd(hipStream_t st, const float* xs, int64_t b, int64_t n, int64_t k, float* ps, float* ts);
+
+// optional extra outputs of the select-splice entries: the soft top-k of the scores the reference's eval forward also publishes
+// (visual.last_combined_scores, EV/token_compression/selector_model.py:190): ps fp32 [sum N], ts fp32 [n_seg]; NULL = not wanted
+struct SoftOut { float* ps; float* ts; };
+
 // ---- one-launch form ---------------------------------------------------------------------------------------------------
 // grid (ceil(max len_out / rows_per_block), n_seq), block 1024.  single != 0: one prompt, stats are stored (no memset / atomics).
 template <typename T, int KPT>
@@ -84,12 +92,20 @@ __global__ __launch_bounds__(kSpliceThreads) void select_splice_small_kernel(
     const T* __restrict__ embeds, const int64_t* __restrict__ pos, int pos_rows, const int64_t* __restrict__ mask,
     int64_t* __restrict__ idx, int64_t* __restrict__ sel, int64_t* __restrict__ new_ids, T* __restrict__ new_embeds,
     int64_t* __restrict__ new_pos, int64_t* __restrict__ new_mask, int32_t* __restrict__ cu_out, int32_t* __restrict__ stats,
-    int l_out, int rows_per_block, int h_rows, int single) {
+    int l_out, int rows_per_block, int h_rows, int single, SoftOut soft) {
   constexpr int V = Elem<T>::kVec;
   constexpr int NW = kSpliceThreads / 64;
   const int s = blockIdx.y, b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const PromptGeom g = prompt_geom(sv, cu_seqlens, s, total_len, l_out);
+  if (soft.ps && b == (int)gridDim.x - 1) {
+    // one EXTRA workgroup per launch (single prompt, <= 4096 visual tokens, 0 < k < n: launch_select_splice): the soft top-k of the
+    // same scores, with vsel_soft_topk_fwd's arithmetic (bit-identical), beside the select / splice workgroups instead of in a
+    // launch of its own behind them (24 us of one CU at 2304 tokens before round 4, then 2 launches -> 1)
+    __shared__ float soft_red[6][NW];
+    if (g.sane) soft_topk_row_256x16<NW>(scores + g.rb, g.nvis, g.ko, soft.ps + g.rb, soft.ts + s, soft_red);
+    return;
+  }
   if (b == 0 && tid == 0 && cu_out) {
     cu_out[s] = g.q0;
     if (s == n_seq - 1) cu_out[n_seq] = g.q0 + g.len_out;
@@ -248,7 +264,7 @@ __global__ __launch_bounds__(kSpliceThreads) void select_splice_small_kernel(
   }
   if (b == 0 && tid == 0) {
     // nblk > gridDim.x: the caller's max_len_out is below this prompt's L', so the grid has no workgroup for its last rows
-    const bool bad = (int)run_vis != g.nvis || (int)run_keep != g.len_out || (int)run_kv != g.ko || nblk > (int)gridDim.x;
+    const bool bad = (int)run_vis != g.nvis || (int)run_keep != g.len_out || (int)run_kv != g.ko || nblk > (int)gridDim.x - (soft.ps ? 1 : 0);
     if (single) {
       stats[0] = (int32_t)run_vis;
       stats[1] = (int32_t)run_keep;
@@ -300,27 +316,37 @@ static int launch_select_splice(hipStream_t st, const T* h, int d, const vsel_se
                                 int64_t max_len_out, int64_t visual_id, const T* embeds, const int64_t* pos, int pos_rows,
                                 const int64_t* mask, int64_t* idx, int64_t* sel, int64_t* new_ids, T* new_embeds,
                                 int64_t* new_pos, int64_t* new_mask, int32_t* cu_out, int32_t* src_scratch, int32_t* stats,
-                                int64_t l_out) {
+                                int64_t l_out, SoftOut soft) {
   const SegView sv = make_view(seg);
   const int S = (int)seg->n_seg;
   const int64_t maxn = seg->rows_per_seg;
   const bool fused = knob(VSEL_KNOB_LIS_SPLICE_FUSED) != 0 && S <= kSelectSpliceMaxSeq && maxn <= 32 * kSpliceThreads;
+  // soft top-k wanted: inside the one-launch form for one prompt of <= 4096 tokens (the reference's call), else its own launches
+  const bool soft_wanted = soft.ps != nullptr;
+  const bool soft_inside = soft_wanted && fused && S == 1 && maxn <= 4096 && seg->k > 0 && seg->k < maxn;
+  auto soft_after = [&]() -> int {
+    if (!soft_wanted || soft_inside) return VSEL_OK;
+    if (seg->seg_rows != nullptr) return fail(VSEL_ERR_UNSUPPORTED, "soft top-k outputs need uniform segments (one prompt in the reference)");
+    if (seg->k <= 0 || seg->k >= maxn) return VSEL_OK;            // reference: assert 0 < k < n; nothing to publish
+    return launch_soft_topk_fwd(st, scores, S, maxn, seg->k, soft.ps, soft.ts);
+  };
+  const SoftOut soft_k = soft_inside ? soft : SoftOut{nullptr, nullptr};
   if (fused) {
     const int single = S == 1;
     if (!single && hipMemsetAsync(stats, 0, 4 * sizeof(int32_t), st) != hipSuccess) return fail(VSEL_ERR_HIP, "hipMemsetAsync(stats)");
     int64_t rpb = kSelectSpliceMaxRows;
     while (rpb > 2 && S * cdiv(max_len_out, rpb) < 128) rpb >>= 1;
-    const dim3 grid((unsigned)std::max<int64_t>(1, cdiv(max_len_out, rpb)), (unsigned)S);
+    const dim3 grid((unsigned)std::max<int64_t>(1, cdiv(max_len_out, rpb)) + (soft_inside ? 1u : 0u), (unsigned)S);
 #define VSEL_SS_LAUNCH(KPT)                                                                                                 \
     hipLaunchKernelGGL((select_splice_small_kernel<T, KPT>), grid, dim3(kSpliceThreads), 0, st, h, scores, sv, d, l2p, ids,   \
                        cu_seqlens, S, (int)total_len, visual_id, embeds, pos, pos_rows, mask, idx, sel, new_ids, new_embeds, \
-                       new_pos, new_mask, cu_out, stats, (int)l_out, (int)rpb, (int)seg->total_rows, single)
+                       new_pos, new_mask, cu_out, stats, (int)l_out, (int)rpb, (int)seg->total_rows, single, soft_k)
     if (maxn <= 4 * kSpliceThreads) VSEL_SS_LAUNCH(4);
     else if (maxn <= 8 * kSpliceThreads) VSEL_SS_LAUNCH(8);
     else VSEL_SS_LAUNCH(32);
 #undef VSEL_SS_LAUNCH
     VSEL_AFTER_LAUNCH(st, "select_splice_small_kernel");
-    return VSEL_OK;
+    return soft_after();
   }
   int rc = launch_select(st, scores, seg, idx, nullptr);
   if (rc) return rc;
@@ -338,7 +364,7 @@ static int launch_select_splice(hipStream_t st, const T* h, int d, const vsel_se
                        (int)total_len, (int)seg->total_rows, new_embeds);
     VSEL_AFTER_LAUNCH(st, "splice_embed_kernel");
   }
-  return VSEL_OK;
+  return soft_after();
 }
 
 template <typename T, typename TW>
@@ -398,16 +424,16 @@ static int select_splice_dispatch(hipStream_t st, const void* h, vsel_dtype hdty
                                   const int64_t* position_ids, int64_t pos_rows, const int64_t* attention_mask, int64_t* idx,
                                   int64_t* selected_indices, int64_t* new_input_ids, void* new_inputs_embeds,
                                   int64_t* new_position_ids, int64_t* new_attention_mask, int32_t* cu_seqlens_out,
-                                  int32_t* src_scratch, int32_t* stats, int64_t l_out) {
+                                  int32_t* src_scratch, int32_t* stats, int64_t l_out, SoftOut soft) {
   if (hdtype == VSEL_BF16)
     return launch_select_splice<bf16_t>(st, (const bf16_t*)h, (int)d, seg, scores, l2p, input_ids, cu_seqlens, total_len,
                                         max_len_out, visual_token_id, (const bf16_t*)inputs_embeds, position_ids, (int)pos_rows,
                                         attention_mask, idx, selected_indices, new_input_ids, (bf16_t*)new_inputs_embeds,
-                                        new_position_ids, new_attention_mask, cu_seqlens_out, src_scratch, stats, l_out);
+                                        new_position_ids, new_attention_mask, cu_seqlens_out, src_scratch, stats, l_out, soft);
   return launch_select_splice<float>(st, (const float*)h, (int)d, seg, scores, l2p, input_ids, cu_seqlens, total_len, max_len_out,
                                      visual_token_id, (const float*)inputs_embeds, position_ids, (int)pos_rows, attention_mask, idx,
                                      selected_indices, new_input_ids, (float*)new_inputs_embeds, new_position_ids,
-                                     new_attention_mask, cu_seqlens_out, src_scratch, stats, l_out);
+                                     new_attention_mask, cu_seqlens_out, src_scratch, stats, l_out, soft);
 }
 
 extern "C" int vsel_lis_select_splice(void* stream, const void* h, vsel_dtype hdtype, const vsel_segments* seg,
@@ -418,8 +444,9 @@ extern "C" int vsel_lis_select_splice(void* stream, const void* h, vsel_dtype hd
                                       const int64_t* position_ids, int64_t pos_rows, const int64_t* attention_mask, int64_t* idx,
                                       float* scores, int64_t* selected_indices, int64_t* new_input_ids, void* new_inputs_embeds,
                                       int64_t* new_position_ids, int64_t* new_attention_mask, int32_t* cu_seqlens_out,
-                                      int32_t* src_scratch, int32_t* stats) {
+                                      int32_t* src_scratch, int32_t* stats, float* soft_ps, float* soft_ts) {
   if (!scorer) return fail(VSEL_ERR_INVALID, "scorer is NULL");
+  if ((soft_ps == nullptr) != (soft_ts == nullptr)) return fail(VSEL_ERR_INVALID, "give both soft_ps and soft_ts or neither");
   int64_t l_out = 0;
   int rc = splice_args_check(h, hdtype, seg, input_ids, total_len, cu_seqlens, max_len_out, inputs_embeds, position_ids, pos_rows,
                              attention_mask, idx, scores, selected_indices, new_input_ids, new_inputs_embeds, new_position_ids,
@@ -445,7 +472,7 @@ extern "C" int vsel_lis_select_splice(void* stream, const void* h, vsel_dtype hd
   return select_splice_dispatch(st, h, hdtype, scorer->d, seg, scores, logical_to_physical, input_ids, cu_seqlens, total_len,
                                 max_len_out, visual_token_id, inputs_embeds, position_ids, pos_rows, attention_mask, idx,
                                 selected_indices, new_input_ids, new_inputs_embeds, new_position_ids, new_attention_mask,
-                                cu_seqlens_out, src_scratch, stats, l_out);
+                                cu_seqlens_out, src_scratch, stats, l_out, SoftOut{soft_ps, soft_ts});
 }
 
 extern "C" int vsel_topk_select_splice(void* stream, const void* h, vsel_dtype hdtype, int64_t d, const vsel_segments* seg,
@@ -454,7 +481,9 @@ extern "C" int vsel_topk_select_splice(void* stream, const void* h, vsel_dtype h
                                        const void* inputs_embeds, const int64_t* position_ids, int64_t pos_rows,
                                        const int64_t* attention_mask, int64_t* idx, int64_t* selected_indices,
                                        int64_t* new_input_ids, void* new_inputs_embeds, int64_t* new_position_ids,
-                                       int64_t* new_attention_mask, int32_t* cu_seqlens_out, int32_t* src_scratch, int32_t* stats) {
+                                       int64_t* new_attention_mask, int32_t* cu_seqlens_out, int32_t* src_scratch, int32_t* stats,
+                                       float* soft_ps, float* soft_ts) {
+  if ((soft_ps == nullptr) != (soft_ts == nullptr)) return fail(VSEL_ERR_INVALID, "give both soft_ps and soft_ts or neither");
   int64_t l_out = 0;
   int rc = splice_args_check(h, hdtype, seg, input_ids, total_len, cu_seqlens, max_len_out, inputs_embeds, position_ids, pos_rows,
                              attention_mask, idx, scores, selected_indices, new_input_ids, new_inputs_embeds, new_position_ids,
@@ -465,5 +494,5 @@ extern "C" int vsel_topk_select_splice(void* stream, const void* h, vsel_dtype h
   return select_splice_dispatch(st, h, hdtype, d, seg, scores, logical_to_physical, input_ids, cu_seqlens, total_len, max_len_out,
                                 visual_token_id, inputs_embeds, position_ids, pos_rows, attention_mask, idx, selected_indices,
                                 new_input_ids, new_inputs_embeds, new_position_ids, new_attention_mask, cu_seqlens_out, src_scratch,
-                                stats, l_out);
+                                stats, l_out, SoftOut{soft_ps, soft_ts});
 }

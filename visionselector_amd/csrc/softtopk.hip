@@ -4,42 +4,44 @@
 //            lo = -max(x) - 10, hi = -min(x) + 10; returns t and ps = sigmoid(x + t).
 // backward = TopK.backward (:60-70): v = sigmoid'(x + t), grad = g*v - (sum g*v) * v / sum v.
 //
-// The reference issues ~320 tiny launches for the forward; here one workgroup per row keeps lo/hi in
-// registers and does the 64 reductions with wave shuffles + one LDS hop.  All arithmetic is fp32 (the
-// reference's bf16 run stalls after ~10 steps at bf16 spacing -- SURVEY.md section 7 hard part 5).
+// The reference issues ~320 tiny launches for the forward; here one workgroup per row finds the same root with a bracketed Newton
+// iteration (softtopk.h, find_ts_newton: 3-5 block reductions instead of the 27 of a bisection to float resolution).  All
+// arithmetic is fp32 (the reference's bf16 run stalls after ~10 steps at bf16 spacing -- SURVEY.md section 7 hard part 5).
 #include "softtopk.h"
 
 namespace vsel {
 
 // EPT > 0: the row lives in registers (EPT elements per thread, n <= NT * EPT); EPT == 0: re-read from global (huge rows).
-// Early exit: once `mid` equals `lo` or `hi` (adjacent floats) the remaining iterations of the reference's fixed 64-step
-// loop cannot change (lo, hi) any more, so stopping there returns the same ts bit for bit.
 template <int NT, int EPT>
 __global__ __launch_bounds__(NT) void soft_topk_fwd_kernel(const float* __restrict__ xs, int n, int k,
                                                            float* __restrict__ ps, float* __restrict__ ts) {
   constexpr int NW = NT / 64;
-  constexpr int E = EPT > 0 ? EPT : 1;
   __shared__ float red[6][NW];
   const int row = blockIdx.x;
   const float* x = xs + (int64_t)row * n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
+  if constexpr (NT == 256 && EPT == 16) {
+    soft_topk_row_256x16<NW>(x, n, k, ps + (int64_t)row * n, ts + row, red);
+    return;
+  }
+  constexpr int E = EPT > 0 ? EPT : 1;
   float xr[E];
-  float mx = -INFINITY, mn = INFINITY;
+  float mx = -INFINITY, mn = INFINITY, sx = 0.f;
   if constexpr (EPT > 0) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int i = tid + e * NT;
       const bool ok = i < n;
       const float v = ok ? x[i] : 0.f;
-      xr[e] = ok ? v : -INFINITY;            // sigmoid(-inf + t) = 0: padding never contributes
-      if (ok) { mx = fmaxf(mx, v); mn = fminf(mn, v); }
+      xr[e] = ok ? v : -INFINITY;
+      if (ok) { mx = fmaxf(mx, v); mn = fminf(mn, v); sx += v; }
     }
   } else {
     for (int i = tid; i < n; i += NT) {
       const float v = x[i];
       mx = fmaxf(mx, v);
       mn = fminf(mn, v);
+      sx += v;
     }
   }
   mx = wave_max(mx);
@@ -49,40 +51,33 @@ __global__ __launch_bounds__(NT) void soft_topk_fwd_kernel(const float* __restri
   mx = red[4][0]; mn = red[5][0];
 #pragma unroll
   for (int w = 1; w < NW; ++w) { mx = fmaxf(mx, red[4][w]); mn = fminf(mn, red[5][w]); }
-
-  float lo = -mx - 10.0f;   // :78
-  float hi = -mn + 10.0f;   // :79
-  const float kf = (float)k;
-  // A step only needs the SIGN of (sum - k).  While the bracket is wide that sign is decided by a sum of 4-instruction sigmoids
-  // (error bound: 2e-6 per element incl. the summation, + 1e-3); the step is redone with the reference-accurate sigmoid when
-  // the cheap sum is within the bound of k -- the sequence of (lo, hi) is the all-accurate one, step for step, at a third of the
-  // arithmetic (the row sits on ONE CU: 26 steps x N accurate sigmoids were 31 us at N = 2304).
-  const float decisive = 2e-6f * (float)n + 1e-3f;
-  for (int it = 0; it < 64; ++it) {             // :80
-    const float mid = (hi + lo) / 2.0f;         // :81
-    float acc = 0.f;
-    if constexpr (EPT > 0) {
-#pragma unroll
-      for (int e = 0; e < E; ++e) acc += sigmoidf_fast(xr[e] + mid);
-    } else {
-      for (int i = tid; i < n; i += NT) acc += sigmoidf_fast(x[i] + mid);
-    }
-    float sum = block_sum<NW>(acc, red, (2 * it) & 3);
-    if (fabsf(sum - kf) <= decisive) {          // uniform
-      acc = 0.f;
-      if constexpr (EPT > 0) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) acc += sigmoidf_ref(xr[e] + mid);
-      } else {
-        for (int i = tid; i < n; i += NT) acc += sigmoidf_ref(x[i] + mid);
+  __syncthreads();
+  float t;
+  if constexpr (EPT > 0) {
+    t = find_ts_newton<NW, NW, E>(xr, sx, mx, mn, n, k, red);
+  } else {
+    // huge rows (n > 16384): the same iteration with the elements re-read from global (L2-resident: 64 KB+)
+    float lo = -mx - 10.0f, hi = -mn + 10.0f;
+    const float kf = (float)k, nf = (float)n;
+    const float xsum = block_sum<NW>(sx, red, 0);
+    t = fminf(fmaxf(logf(kf / (nf - kf)) - xsum / nf, lo), hi);
+    for (int it = 0; it < 48; ++it) {
+      float s = 0.f, d = 0.f;
+      for (int i = tid; i < n; i += NT) {
+        const float p = sigmoidf_ref(x[i] + t);
+        s += p;
+        d = fmaf(p, 1.0f - p, d);
       }
-      sum = block_sum<NW>(acc, red, (2 * it + 1) & 3);
+      const float st = block_sum<NW>(s, red, 1 + 2 * (it & 1));
+      const float dt = block_sum<NW>(d, red, 2 + 2 * (it & 1));
+      if (st < kf) lo = t; else hi = t;
+      float tn = t - (st - kf) / fmaxf(dt, 1e-30f);
+      if (!(tn >= lo && tn <= hi)) tn = 0.5f * (lo + hi);
+      const bool done = fabsf(tn - t) <= 1e-6f * fmaxf(1.0f, fabsf(t));
+      t = tn;
+      if (done) break;
     }
-    const bool fixed_point = (mid == lo) || (mid == hi);
-    if (sum < kf) lo = mid; else hi = mid;      // :82-84
-    if (fixed_point) break;
   }
-  const float t = (lo + hi) / 2.0f;             // :85
   if (tid == 0) ts[row] = t;
   if constexpr (EPT > 0) {
 #pragma unroll
@@ -125,9 +120,7 @@ __global__ __launch_bounds__(NT) void soft_topk_bwd_kernel(const float* __restri
 }
 
 int launch_soft_topk_fwd(hipStream_t st, const float* xs, int64_t b, int64_t n, int64_t k, float* ps, float* ts) {
-  if (n <= 1024)
-    hipLaunchKernelGGL((soft_topk_fwd_kernel<256, 4>), dim3((unsigned)b), dim3(256), 0, st, xs, (int)n, (int)k, ps, ts);
-  else if (n <= 4096)      // one wave per SIMD: a step is issue-bound (16 waves: 0.8 us per step at N = 2304, 4 waves: see bench_train)
+  if (n <= 4096)           // four waves, one per SIMD; the row routine picks 4 / 8 / 12 / 16 registers per thread from n
     hipLaunchKernelGGL((soft_topk_fwd_kernel<256, 16>), dim3((unsigned)b), dim3(256), 0, st, xs, (int)n, (int)k, ps, ts);
   else if (n <= 16384)
     hipLaunchKernelGGL((soft_topk_fwd_kernel<1024, 16>), dim3((unsigned)b), dim3(1024), 0, st, xs, (int)n, (int)k, ps, ts);

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ ps,
 }
 
 // The forward's tail for one row of N <= 256 KPT scores in ONE launch (three before: soft top-k, hard top-k mask, BCE):
-//   ts, ps = _find_ts(scores, k)                 (soft_topk_fwd_kernel's bisection, step for step)
+//   ts, ps = _find_ts(scores, k)                 (find_ts_newton, as soft_topk_fwd_kernel)
 //   y      = hard top-k mask of the scores       (topk_select_reg_kernel's integer select: larger key first, then lower index)
 //   bce    = mean_i BCE(ps_i, y_i)               (ATen's -100 clamp; fixed summation order: wave, then waves 0..3)
 // Wave w owns the contiguous elements [w span, (w + 1) span), element j of a lane = e0 + 64 j.
@@ -82,13 +82,13 @@ __global__ __launch_bounds__(256) void train_tail_kernel(const float* __restrict
   const int kpw = (n + NT - 1) / NT;                  // 64-element groups per wave (<= KPT)
   const int e0 = wave * kpw * 64 + lane;
   float xr[KPT];
-  float mx = -INFINITY, mn = INFINITY;
+  float mx = -INFINITY, mn = INFINITY, sx = 0.f;
 #pragma unroll
   for (int j = 0; j < KPT; ++j) xr[j] = xs[min(e0 + 64 * j, n - 1)];      // unconditional (clamped) loads
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
     const bool ok = j < kpw && e0 + 64 * j < n;
-    if (ok) { mx = fmaxf(mx, xr[j]); mn = fminf(mn, xr[j]); }
+    if (ok) { mx = fmaxf(mx, xr[j]); mn = fminf(mn, xr[j]); sx += xr[j]; }
     else xr[j] = -INFINITY;                           // sigmoid(-inf + t) = 0: padding never contributes
   }
 #pragma unroll
@@ -100,27 +100,9 @@ __global__ __launch_bounds__(256) void train_tail_kernel(const float* __restrict
   mx = red[4][0]; mn = red[5][0];
 #pragma unroll
   for (int w = 1; w < NW; ++w) { mx = fmaxf(mx, red[4][w]); mn = fminf(mn, red[5][w]); }
-  // ---- _find_ts (selector_model.py:72-86), see soft_topk_fwd_kernel for the decisive / accurate step rule --------------
-  float lo = -mx - 10.0f, hi = -mn + 10.0f;
-  const float kf = (float)k;
-  const float decisive = 2e-6f * (float)n + 1e-3f;
-  for (int it = 0; it < 64; ++it) {
-    const float mid = (hi + lo) / 2.0f;
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < KPT; ++j) acc += sigmoidf_fast(xr[j] + mid);
-    float sum = block_sum<NW>(acc, red, (2 * it) & 3);
-    if (fabsf(sum - kf) <= decisive) {
-      acc = 0.f;
-#pragma unroll
-      for (int j = 0; j < KPT; ++j) acc += sigmoidf_ref(xr[j] + mid);
-      sum = block_sum<NW>(acc, red, (2 * it + 1) & 3);
-    }
-    const bool fixed_point = (mid == lo) || (mid == hi);
-    if (sum < kf) lo = mid; else hi = mid;
-    if (fixed_point) break;
-  }
-  const float t = (lo + hi) / 2.0f;
+  // ---- _find_ts (selector_model.py:72-86): the same root by bracketed Newton steps (softtopk.h, find_ts_newton) ----------------
+  __syncthreads();                                  // red[4..5] are reused by the iteration
+  const float t = find_ts_newton<NW, NW, KPT>(xr, sx, mx, mn, n, k, red);
   if (tid == 0) ts[0] = t;
   // ---- hard top-k mask: 4-pass radix select on the ordered keys, then the ordered tie rule ------------------------------
   uint32_t key[KPT];

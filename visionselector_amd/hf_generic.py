@@ -168,10 +168,9 @@ def select_and_splice(self, base_forward: Callable, hidden_states: torch.Tensor,
         merged.contiguous(), *params, input_ids[0].contiguous(), inputs_embeds[0].contiguous(), visual_token_id, [L], [total], [k],
         position_ids=None if position_ids is None else position_ids.reshape(-1, L), col_sums=col_sums,
         attention_mask=None if attention_mask is None else attention_mask[0], logical_to_physical=l2p, physical_to_logical=p2l,
-        check=check)
-    combined = None
-    if 0 < k < total:                                                                        # EV :190 (visualisation only)
-        combined = ops.soft_topk_fwd(o["scores"][None], k)[0][0].to(merged.dtype)
+        check=check, soft=True)
+    # EV :190 (visualisation only): the soft top-k comes out of the same launch (one extra workgroup), not a launch of its own
+    combined = None if o["soft_ps"] is None else o["soft_ps"].to(merged.dtype)
     self.last_combined_scores = combined
     self.last_selected_indices = o["idx"]
     new_pos = None if o["position_ids"] is None else o["position_ids"][:, None, :]

@@ -604,14 +604,17 @@ def _select_splice_finish(o, check, n_tot, l_out, k_tot, attention_mask):
 
 def lis_select_splice(h, wq, bq, wk, bk, input_ids, inputs_embeds, visual_token_id: int, seq_lens: Sequence[int],
                       visual_lens: Sequence[int], ks: Sequence[int], position_ids=None, attention_mask=None, col_sums=None,
-                      logical_to_physical=None, physical_to_logical=None, check: bool = False):
+                      logical_to_physical=None, physical_to_logical=None, check: bool = False, soft: bool = False):
     """Scores + hard top-k + splice with the kept rows written once, from the token tensor into inputs_embeds'
     (vsel_lis_select_splice).  h [sum N, D] = the visual tokens of S prompts back to back (prompt s: visual_lens[s] rows, ONE
     jointly scored segment, ks[s] kept); input_ids [T] / inputs_embeds [T, D] = the prompts back to back (seq_lens);
     position_ids [R, T] or None; attention_mask [T] or None ->
     dict(idx [sum k] local ranks ascending, scores fp32 [sum N], selected_indices [T'], input_ids [T'], inputs_embeds [T', D],
          position_ids [R, T'] | None, attention_mask [T'] | None, cu_seqlens int32 [S+1]).
-    Bit-identical to lis_select(_varlen / _permuted / _presummed) followed by splice(_batched)."""
+    Bit-identical to lis_select(_varlen / _permuted / _presummed) followed by splice(_batched).
+    soft=True (uniform visual_lens / ks): also soft_ps fp32 [sum N], soft_ts fp32 [S] = soft_topk_fwd(scores, k) bit for bit (the
+    reference's last_combined_scores, EV :190); for one prompt of <= 4096 tokens without a launch of its own.  None when not
+    0 < k < N."""
     dev = _dev(h, wq, bq, wk, bk, input_ids, inputs_embeds, position_ids, attention_mask, col_sums, logical_to_physical,
                physical_to_logical)
     seg, _keep, cu_s, pos, rows, am, o, l_out, max_len_out, n_tot, k_tot = _select_splice_common(
@@ -631,15 +634,22 @@ def lis_select_splice(h, wq, bq, wk, bk, input_ids, inputs_embeds, visual_token_
     ws = _workspace(lib.vsel_lis_workspace_bytes(C.byref(seg), sc.d, sc.hd), dev)
     scores = torch.empty(n_tot, dtype=torch.float32, device=dev)
     hc, emb = h.contiguous(), inputs_embeds.contiguous()
+    soft_ps = soft_ts = None
+    if soft:
+        if len(set(visual_lens)) != 1 or len(set(ks)) != 1:
+            raise ValueError("soft=True needs uniform segments (the reference's call is one prompt)")
+        if 0 < ks[0] < visual_lens[0]:
+            both = torch.empty(n_tot + len(seq_lens), dtype=torch.float32, device=dev)      # one allocation: ps | ts
+            soft_ps, soft_ts = both[:n_tot], both[n_tot:]
     N.check(lib.vsel_lis_select_splice(
         _stream(), hc.data_ptr(), _code(hc), C.byref(seg), C.byref(sc), ws.data_ptr(), ws.numel(), _p(col_sums),
         _p(logical_to_physical), _p(physical_to_logical), ids.data_ptr(), ids.numel(), _p(cu_s), max_len_out,
         int(visual_token_id), emb.data_ptr(), _p(pos), rows, _p(am), o["idx"].data_ptr(), scores.data_ptr(), o["sel"].data_ptr(),
         o["new_ids"].data_ptr(), o["new_emb"].data_ptr(), _p(o["new_pos"]), _p(o["new_am"]), o["cu_out"].data_ptr(),
-        o["src"].data_ptr(), o["stats"].data_ptr()))
+        o["src"].data_ptr(), o["stats"].data_ptr(), _p(soft_ps), _p(soft_ts)))
     new_am = _select_splice_finish(o, check, n_tot, l_out, k_tot, attention_mask)
     return dict(idx=o["idx"], scores=scores, selected_indices=o["sel"], input_ids=o["new_ids"], inputs_embeds=o["new_emb"],
-                position_ids=o["new_pos"], attention_mask=new_am, cu_seqlens=o["cu_out"])
+                position_ids=o["new_pos"], attention_mask=new_am, cu_seqlens=o["cu_out"], soft_ps=soft_ps, soft_ts=soft_ts)
 
 
 def topk_select_splice(scores, h, input_ids, inputs_embeds, visual_token_id: int, seq_lens: Sequence[int],
@@ -657,7 +667,7 @@ def topk_select_splice(scores, h, input_ids, inputs_embeds, visual_token_id: int
         _stream(), hc.data_ptr(), _code(hc), h.shape[1], C.byref(seg), scc.data_ptr(), _p(logical_to_physical),
         ids.data_ptr(), ids.numel(), _p(cu_s), max_len_out, int(visual_token_id), emb.data_ptr(), _p(pos), rows,
         _p(am), o["idx"].data_ptr(), o["sel"].data_ptr(), o["new_ids"].data_ptr(), o["new_emb"].data_ptr(), _p(o["new_pos"]),
-        _p(o["new_am"]), o["cu_out"].data_ptr(), o["src"].data_ptr(), o["stats"].data_ptr()))
+        _p(o["new_am"]), o["cu_out"].data_ptr(), o["src"].data_ptr(), o["stats"].data_ptr(), None, None))
     new_am = _select_splice_finish(o, check, n_tot, l_out, k_tot, attention_mask)
     return dict(idx=o["idx"], selected_indices=o["sel"], input_ids=o["new_ids"], inputs_embeds=o["new_emb"],
                 position_ids=o["new_pos"], attention_mask=new_am, cu_seqlens=o["cu_out"])

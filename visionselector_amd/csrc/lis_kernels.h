@@ -805,24 +805,37 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
     if (j >= je) return;
     int64_t lsrc = rb + idx[ob + j];
     int64_t src = src_map ? src_map[lsrc] : lsrc;
-    for (; j < je; j += 4) {
-      const u32x4* sp = reinterpret_cast<const u32x4*>(h + src * d) + lane;
-      u32x4 x[ITERS];
+    // two rows in flight per wave: row j + 4 is loaded before row j is stored, so a wave never sits idle between the last store of
+    // one row and the first data of the next (the copy is latency-bound per wave: 7 KB per round trip)
+    auto load_row = [&](u32x4 (&x)[ITERS], int64_t srow) {
+      const u32x4* sp = reinterpret_cast<const u32x4*>(h + srow * d) + lane;
 #pragma unroll
       for (int i = 0; i < ITERS; ++i) {
         if constexpr (NT) x[i] = __builtin_nontemporal_load(sp + 64 * i);     // read once: do not displace the next sweep's lines
         else x[i] = sp[64 * i];
       }
-      if (j + 4 < je) {                                                        // next row's source under this row's copy
-        lsrc = rb + idx[ob + j + 4];
-        src = src_map ? src_map[lsrc] : lsrc;
-      }
-      u32x4* dp = reinterpret_cast<u32x4*>(out + (ob + j) * d) + lane;
+    };
+    auto store_row = [&](const u32x4 (&x)[ITERS], int jrow) {
+      u32x4* dp = reinterpret_cast<u32x4*>(out + (ob + jrow) * d) + lane;
 #pragma unroll
       for (int i = 0; i < ITERS; ++i) {
         if constexpr (NT) __builtin_nontemporal_store(x[i], dp + 64 * i);      // keeps the write-back from slowing the next sweep 1
         else dp[64 * i] = x[i];
       }
+    };
+    auto next_src = [&](int jrow) -> int64_t {
+      const int64_t l = rb + idx[ob + jrow];
+      return src_map ? src_map[l] : l;
+    };
+    u32x4 xa[ITERS], xb[ITERS];
+    load_row(xa, src);
+    for (; j < je; j += 8) {
+      const bool has_b = j + 4 < je;
+      if (has_b) load_row(xb, next_src(j + 4));
+      store_row(xa, j);
+      if (!has_b) break;
+      if (j + 8 < je) load_row(xa, next_src(j + 8));
+      store_row(xb, j + 4);
     }
   } else {
     for (int j = jb + wave; j < je; j += 4) {

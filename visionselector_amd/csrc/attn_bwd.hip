@@ -83,6 +83,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
   int row_addr[8], tr_addr[4][2];
   make_row_addr<8>(row_addr, j, hh);
   make_tr_addr<4>(tr_addr, lane);
+  uint32_t row_u[8], tr_u[4][2];                                 // the same as LDS byte addresses (asm reads: base VGPR + immediate)
+#pragma unroll
+  for (int st = 0; st < 8; ++st) row_u[st] = lds_u32(smem) + row_addr[st];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { tr_u[dt][0] = lds_u32(smem) + tr_addr[dt][0]; tr_u[dt][1] = lds_u32(smem) + tr_addr[dt][1]; }
 
   // work items: (sequence, kv head) pairs on XCD-local queues; a pair's items = query tiles heaviest first, the group's q heads inner
   const int rep_q = hq / hkv;
@@ -202,25 +207,50 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     __syncthreads();
 
     const int kmax = causal ? min(len - 1, my_q) : len - 1;      // last visible key of this lane's query
+    // LDS reads of the tile body are issued from inline asm in batches with counted waits (attn_common.h: with the builtins hipcc
+    // emits "2 ds_read, s_waitcnt lgkmcnt(0), 2 MFMAs" per k-step -- every MFMA pair behind a full LDS round trip -- and puts
+    // s_waitcnt vmcnt(0) in front of the first transposed read of every tile, which drains the direct-to-LDS prefetch of the NEXT
+    // tile in the middle of this one).  Same MFMAs in the same order as before: bit-identical dQ.
     auto tile_body = [&](auto cur_c, int t) {
       constexpr int CUR = decltype(cur_c)::value;
-      const char* kt = smem + CUR * kTileB;
-      const char* vt = smem + (2 + CUR) * kTileB;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const int key0 = t * kTile + 32 * kb;
+      auto block = [&](auto kb_c) {
+        constexpr int KB = decltype(kb_c)::value;
+        constexpr int kKOff = CUR * kTileB + KB * 32 * kRowB, kVOff = (2 + CUR) * kTileB + KB * 32 * kRowB;
+        const int key0 = t * kTile + 32 * KB;
         const bool active = __builtin_amdgcn_readfirstlane((int)(key0 < len && (!causal || key0 <= wave_qmax))) != 0;
-        if (!active) continue;
+        if (!active) return;
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        // S^T = K Q^T, dP^T = V dO^T: two batches of 8 row-fragment reads (K and V of 4 k-steps), each feeding 8 MFMAs
+        auto sdp_batch = [&](auto h_c) {
+          constexpr int H4 = decltype(h_c)::value;
+          u32x4 kv[8];
 #pragma unroll
-        for (int st = 0; st < 8; ++st) {
-          const bf16x8_t ak = as_bf16x8(*reinterpret_cast<const u32x4*>(kt + row_addr[st] + kb * 32 * kRowB));
-          const bf16x8_t av = as_bf16x8(*reinterpret_cast<const u32x4*>(vt + row_addr[st] + kb * 32 * kRowB));
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, as_bf16x8(qf[st]), s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, as_bf16x8(dof[st]), dp, 0, 0, 0);
-        }
+          for (int u = 0; u < 4; ++u) {
+            kv[2 * u] = lds_read_b128_asm<kKOff>(row_u[4 * H4 + u]);
+            kv[2 * u + 1] = lds_read_b128_asm<kVOff>(row_u[4 * H4 + u]);
+          }
+          lds_wait8<0>(kv);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kv[2 * u]), as_bf16x8(qf[4 * H4 + u]), s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kv[2 * u + 1]), as_bf16x8(dof[4 * H4 + u]), dp, 0, 0, 0);
+          }
+        };
+        sdp_batch(std::integral_constant<int, 0>{});
+        sdp_batch(std::integral_constant<int, 1>{});
+        // K^T fragments of the first 16-key half do not depend on dS: in flight under the P / dS arithmetic
+        u32x2 g0[8], g1[8];
+        auto issue = [&](auto m_c, u32x2 (&dst)[8]) {
+          constexpr int M = decltype(m_c)::value;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            dst[2 * dt] = lds_read_tr16_b64_asm<kKOff + 16 * M * kRowB>(tr_u[dt][0]);
+            dst[2 * dt + 1] = lds_read_tr16_b64_asm<kKOff + 16 * M * kRowB>(tr_u[dt][1]);
+          }
+        };
+        issue(std::integral_constant<int, 0>{}, g0);
         const bool need_mask = __builtin_amdgcn_readfirstlane(
             (int)(key0 + 32 > len || (causal && key0 + 31 > q0 + wave * 32))) != 0;
         bf16x8_t dsf[2];
@@ -238,18 +268,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
             dsf[r >> 3][r & 7] = (__bf16)(p * (dp[r] - dsum));
           }
         }
-#pragma unroll
-        for (int mm = 0; mm < 2; ++mm)
+        // dQ^T += K^T dS^T: the second half's reads go out behind the first half's wait, counted lgkmcnt
+        auto dq_mfma = [&](auto m_c, u32x2 (&src)[8]) {
+          constexpr int M = decltype(m_c)::value;
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
-            typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
-            const int off = (32 * kb + 16 * mm) * kRowB;
-            const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(kt + tr_addr[dt][0] + off));
-            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(kt + tr_addr[dt][1] + off));
-            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), dsf[mm],
-                                                              acc[dt], 0, 0, 0);
+            const u32x4 w = {src[2 * dt][0], src[2 * dt][1], src[2 * dt + 1][0], src[2 * dt + 1][1]};
+            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w), dsf[M], acc[dt], 0, 0, 0);
           }
-      }
+        };
+        issue(std::integral_constant<int, 1>{}, g1);
+        lds_wait8<8>(g0);
+        dq_mfma(std::integral_constant<int, 0>{}, g0);
+        lds_wait8<0>(g1);
+        dq_mfma(std::integral_constant<int, 1>{}, g1);
+      };
+      block(std::integral_constant<int, 0>{});
+      block(std::integral_constant<int, 1>{});
     };
     for (int t = 0; t < n_tiles; t += 2) {
       if (t + 1 < n_tiles) load_tile(t + 1, 1);

@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--no-llm", action="store_true", help="skip the whole-LLM prefill leg (7B random-init weights)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (config C3: fwd + bwd + grad all-reduce)")
     ap.add_argument("--no-single-sweep", action="store_true", help="skip the producer-side column-sum leg (SURVEY 8f N2)")
+    ap.add_argument("--no-batch1", action="store_true", help="skip the one-image-per-call leg")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -296,10 +297,11 @@ def main():
         except Exception as e:  # optional leg: never lose the headline line over it
             res["single_sweep"] = {"error": str(e)[:300]}
     # ---- the reference's real evaluation call: ONE image per call (EV/token_compression/selector_model.py:182-194, assert :270) ---
-    try:
-        res["batch1"] = bench_batch1(ops, h, wq, bq, wk, bk, k)
-    except Exception as e:  # optional leg: never lose the headline line over it
-        res["batch1"] = {"error": str(e)[:300]}
+    if not args.no_batch1:
+        try:
+            res["batch1"] = bench_batch1(ops, h, wq, bq, wk, bk, k)
+        except Exception as e:  # optional leg: never lose the headline line over it
+            res["batch1"] = {"error": str(e)[:300]}
     # ---- prefill attention at the compressed vs the full length (second half of the metric) ----------
     if not args.no_attn:
         try:

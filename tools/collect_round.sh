@@ -2,14 +2,14 @@
 # Round evidence on one MI355X box: bench JSON, rocprofv3 kernel stats of the same command, PMC traffic (separate FETCH_SIZE /
 # WRITE_SIZE passes), MFMA counters of the LIS projections, the batch table.  Everything lands in gpurun_out/$1/ ;
 # copy what is to be judged into profiles/.
-R=${1:-r03}
+R=${1:-r04}
 set -u
 ROOT="${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is set there)}"
 cd "$ROOT"
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-train --no-attn --no-llm --no-single-sweep"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-train --no-attn --no-llm --no-single-sweep --no-batch1"
 # 1. the default bench line (all legs)
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 # 2. rocprofv3 --kernel-trace --stats of the headline launches
@@ -18,7 +18,7 @@ python tools/summarize_rocprof.py $(find $OUT/prof_b128 -name '*kernel_stats.csv
 python tools/trace_gaps.py $(find $OUT/prof_b128 -name '*kernel_trace.csv' | head -1) 8 > $OUT/bench_b128_gaps.txt
 find $OUT/prof_b128 -name '*kernel_trace.csv' -delete
 # 2b. the same with the single-sweep leg: gelu_colsum / colsum_linear / presummed select in the kernel stats
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_ss -o lis -- python $ROOT/bench.py --no-cpu-baseline --no-train --no-attn --no-llm --steps 10 --warmup 3 > $OUT/bench_single_sweep_under_rocprof.json 2> $OUT/prof_ss.err)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_ss -o lis -- python $ROOT/bench.py --no-cpu-baseline --no-train --no-attn --no-llm --no-batch1 --steps 10 --warmup 3 > $OUT/bench_single_sweep_under_rocprof.json 2> $OUT/prof_ss.err)
 python tools/summarize_rocprof.py $(find $OUT/prof_ss -name '*kernel_stats.csv' | head -1) $OUT/bench_b128_single_sweep_kernel_stats.csv > /dev/null
 find $OUT/prof_ss -name '*kernel_trace.csv' -delete
 # 3. HBM traffic: separate PMC passes

@@ -1,19 +1,20 @@
 #!/bin/bash
-# Everything under profiles/r03_* in one gpurun call: the -m gpu suite (parity margins), bench + rocprofv3 + PMC (collect_round.sh),
-# timelines, sweeps.  Copy what is to be judged from gpurun_out/r03_final/ into profiles/.
+# Everything under profiles/r04_* in one gpurun call: the -m gpu suite (parity margins), bench + rocprofv3 + PMC (collect_round.sh),
+# timelines, sweeps.  Copy what is to be judged from gpurun_out/r04_final/ into profiles/.
 set -u
 ROOT="${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is set there)}"
 cd "$ROOT"
-O=gpurun_out/r03_final
+O=gpurun_out/r04_final
 mkdir -p $O
-rm -f gpurun_out/parity/r03_parity.jsonl
+rm -f gpurun_out/parity/r04_parity.jsonl
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/pytest_gpu.txt
-python tools/merge_parity.py gpurun_out/parity/r03_parity.jsonl $O/parity.json > /dev/null 2>&1
-timeout 1500 bash tools/collect_round.sh r03_final > $O/collect.log 2>&1
+python tools/merge_parity.py gpurun_out/parity/r04_parity.jsonl $O/parity.json > /dev/null 2>&1
+timeout 1500 bash tools/collect_round.sh r04_final > $O/collect.log 2>&1
 g() { grep -v amdgpu.ids; }
-timeout 200 python tools/trace_small.py 1 2>&1 | g > $O/small_batch_timeline.txt
-timeout 200 python tools/trace_attn.py 524 2>&1 | g > $O/attention_timeline.txt
-(for w in 4 8; do VSEL_ATTN_BWD_WAVES=$w timeout 200 python tools/trace_attn_bwd.py 2>&1 | g; done) > $O/attn_bwd_tile_timeline.txt
+# (the s_memtime timelines of round 3 need a -DVSEL_TRACE build: tools/trace_*.py; not part of the routine evidence)
+(for m in 0 1; do echo "== VSEL_ATTN_XCD_QUEUE=$m"; VSEL_ATTN_XCD_QUEUE=$m timeout 300 python tools/bench_attn.py --big 2>&1 | g; VSEL_ATTN_XCD_QUEUE=$m timeout 300 python tools/bench_attn_bwd.py --big 2>&1 | g; done) > $O/attn_xcd_queue_ab.txt
+timeout 900 bash tools/pmc_attn_mem.sh 16 4096 r04_final/pmc_attn_mem > /dev/null 2>&1
+cp gpurun_out/r04_final/pmc_attn_mem/summary.txt $O/attn_l2_counters.txt 2>/dev/null
 timeout 300 python tools/bench_attn.py 2>&1 | g > $O/bench_attn.txt
 timeout 300 python tools/bench_attn_bwd.py 2>&1 | g > $O/bench_attn_bwd.txt
 timeout 300 python tools/bench_sdpa_ref.py 2>&1 | g > $O/sdpa_ref.jsonl

@@ -368,3 +368,86 @@ def test_head_major_strided_entry_matches_packed(ops, b, hq, hkv, lq, lk, causal
     v_view = vp.view(b, lk, hkv, 128).transpose(1, 2)
     assert not v_view.is_contiguous() or lk == 1 or hkv == 1
     assert torch.equal(ops.attn_head_major(q, k, v_view, causal=causal), out)
+
+
+# ---- 64 rows per wave, one wave per SIMD, hand-scheduled tile loop (csrc/attn_fwd64.hip, knob attn_rows64) ----------------------
+def _rows64_pair(ops, q, k, v, cu, L, causal, lse=False):
+    """(4- / 8-wave form, 64-rows-per-wave form) on the same inputs; the profile proves which kernel ran"""
+    from visionselector_amd import _native as N
+    outs = []
+    for r64 in (0, 1):
+        with N.debug_knob(attn_rows64=r64, attn_split=0):      # (the two-KV-stream form sums in a different order)
+            N.profile_start()
+            outs.append(ops.varlen_attn_fwd_lse(q, k, v, cu, L, causal=causal) if lse else ops.varlen_attn(q, k, v, cu, L, causal=causal))
+            prof = N.profile_stop()
+            assert ("attn_fwd64_kernel" in prof) == bool(r64), prof
+    return outs
+
+
+@pytest.mark.parametrize("lens,hq,hkv", [([1], 2, 1), ([64], 4, 4), ([65], 4, 2), ([256], 4, 4), ([257], 4, 1), ([300, 129, 64], 4, 2),
+                                         ([37, 700, 256, 129], 28, 4), ([1230], 32, 8), ([2368], 4, 4)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_rows64_forward_matches_oracle_and_other_forms_bit_for_bit(ops, lens, hq, hkv, causal):
+    """Same arithmetic per query row as the 4- / 8-wave kernels (the software pipeline only moves WHEN things are computed): outputs
+    bit-identical, and within the usual gate of the fp64 oracle.  Ragged lengths exercise partial K / V tiles (row-clamped loads),
+    partial query tiles (padding lanes), waves without a visible key and masks on the diagonal and at the end of the keys."""
+    q, k, v = make_qkv(sum(lens), hq, hkv, 101 + len(lens))
+    cu = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    cu_t = torch.from_numpy(cu).cuda()
+    a, b = _rows64_pair(ops, q.cuda(), k.cuda(), v.cuda(), cu_t, max(lens), causal)
+    assert torch.equal(a, b)
+    ref = oattn.varlen_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu, causal=causal)
+    check(b.float().cpu().numpy(), ref)
+
+
+def test_rows64_forward_rescale_and_lazy_exponent(ops):
+    """Reference exponents that move in the middle of a row (spiked keys, ramped logits): the rescale of O sits behind the P V MFMAs
+    of the previous tile in the pipelined loop -- same results as the sequential forms, output and log-sum-exp."""
+    lens = [900, 333, 1500]
+    total = sum(lens)
+    q, k, v = make_qkv(total, 4, 2, 29, spike=True)
+    ramp = torch.linspace(0.2, 2.5, total).view(-1, 1, 1)
+    k = (k.float() * ramp).bfloat16()
+    k[700] *= 5
+    cu = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    cu_t = torch.from_numpy(cu).cuda()
+    for causal in (True, False):
+        (ao, al), (bo, bl) = _rows64_pair(ops, q.cuda(), k.cuda(), v.cuda(), cu_t, max(lens), causal, lse=True)
+        assert torch.equal(ao, bo) and torch.equal(al, bl)
+        ref = oattn.varlen_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu, causal=causal)
+        check(bo.float().cpu().numpy(), ref, f"[causal={causal}]")
+
+
+def test_rows64_forward_with_longer_key_sequences(ops):
+    """Queries against longer key sequences (chunked prefill: bottom-right aligned causal mask, shift = klen - qlen), keys at their own
+    offsets: the 64-rows-per-wave form through vsel_varlen_attn_fwd_kv agrees bit for bit with the per-head kernel."""
+    from visionselector_amd import _native as N
+    qlens, klens = [100, 256, 33], [700, 256, 512]
+    rng = np.random.default_rng(77)
+    f = lambda *sh: torch.from_numpy(rng.standard_normal(sh, dtype=np.float32)).bfloat16()  # noqa: E731
+    q, k, v = f(sum(qlens), 8, 128), f(sum(klens), 2, 128), f(sum(klens), 2, 128)
+    cu_q = torch.tensor(np.concatenate(([0], np.cumsum(qlens))), dtype=torch.int32).cuda()
+    cu_k = torch.tensor(np.concatenate(([0], np.cumsum(klens))), dtype=torch.int32).cuda()
+    outs = []
+    for r64 in (0, 1):
+        with N.debug_knob(attn_rows64=r64, attn_split=0, attn_pack=0):
+            outs.append(ops.varlen_attn_kv(q.cuda(), k.cuda(), v.cuda(), cu_q, cu_k, max(qlens), causal=True))
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_rows64_is_the_default_for_large_grids(ops):
+    """16 x 2368 tokens at 7B heads is the regime of the 8-wave form: the 64-rows-per-wave kernel takes it by default."""
+    from visionselector_amd import _native as N
+    L, n = 2368, 16
+    g = torch.Generator(device="cuda").manual_seed(3)
+    q = torch.randn(n * L, 28, 128, device="cuda", generator=g).bfloat16()
+    k = torch.randn(n * L, 4, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(n * L, 4, 128, device="cuda", generator=g).bfloat16()
+    cu = torch.arange(0, n * L + 1, L, dtype=torch.int32, device="cuda")
+    N.profile_start()
+    a = ops.varlen_attn(q, k, v, cu, L)
+    prof = N.profile_stop()
+    assert "attn_fwd64_kernel" in prof, prof
+    with N.debug_knob(attn_rows64=0):
+        b = ops.varlen_attn(q, k, v, cu, L)
+    assert torch.equal(a, b)

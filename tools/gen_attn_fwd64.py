@@ -1,0 +1,625 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled per-item body of attn_fwd64_kernel (visionselector_amd/csrc/attn_fwd64.hip).
+
+    python tools/gen_attn_fwd64.py            # rewrites visionselector_amd/csrc/attn_fwd64_body.inc
+
+hipcc cannot be talked into the register plan this kernel needs (one 512-register wave per SIMD: O and Q in accumulator registers,
+two score tiles in arch VGPRs, K / V fragments read from LDS straight into accumulator registers) nor into placing the softmax
+VALU between the MFMAs: the C++ form of the same loop compiled to 690 spilled VGPRs and 1400 v_accvgpr copies.  The per-item body is
+therefore ONE inline-asm statement with fixed registers, emitted by this script: an explicit register map, an instruction stream per
+phase, and a placement of "filler" instructions (VALU, LDS reads) into the gaps behind each MFMA.  The C++ kernel keeps the
+persistent item loop, the work queue, all address arithmetic and the log-sum-exp.
+
+Arithmetic = varlen_attn_fwd_kernel<true, 8, 128> (attn.hip) operation for operation per query row, so outputs are bit-identical.
+
+Register map (per lane)
+  a[0:127]    O^T accumulators, block b, d-tile dt: a[64 b + 16 dt .. +15]
+  a[128:191]  Q^T fragments, block b, k-step st: a[128 + 32 b + 4 st .. +3]
+  a[192:223]  K fragments (8 slots of 4)
+  a[224:255]  V^T fragments (2 batches x 4 d-tiles x 4)
+  v[32:95]    score tile SA, v[96:159] score tile SB (block b, key block kb: +32 b + 16 kb)
+  v[160:191]  P^T bf16 fragments, block b, key group g: v[160 + 16 b + 4 g .. +3]
+  v[192:199]  K row-fragment LDS addresses (k-step st), v[200:207] V transposed-fragment LDS addresses (2 dt + hi)
+  v208.. scalars of the online softmax and temporaries (below)
+Hazards handled by construction (cdna_hip_programming.md 5.7, LLVM GCNHazardRecognizer numbers for gfx940+):
+  MFMA result -> VALU / accvgpr read: >= 11 wait states (an s_nop 15 where nothing else separates them); v_exp result not used by
+  the next two instructions; VALU write -> v_permlane32_swap: 2 wait states; m0 write -> LDS-DMA: 1 wait state.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "visionselector_amd", "csrc", "attn_fwd64_body.inc")
+
+# ---- register map ---------------------------------------------------------------------------------------------------------------
+A_O, A_Q, A_K, A_V = 0, 128, 192, 224
+V_SA, V_SB, V_P = 32, 96, 160
+V_RA, V_TR = 192, 200
+V_M, V_L, V_PS, V_MX = 208, 210, 212, 214        # [2] each
+V_KMAX = 216                                      # [2]
+V_T = 218                                         # T0..T7 temporaries 218..225
+V_LOK, V_LOV = 226, 230                           # [4] each: per-lane byte offsets of the four slices a wave loads per tile
+V_P8, V_LANE4 = 234, 235                          # part8 * 2 bytes ; lane >> 4
+V_QA, V_QB, V_OA, V_OB = 236, 238, 240, 242       # 64-bit pointers
+V_VALID, V_NEGINF, V_KR = 244, 245, 246           # KR[2] = 246, 247
+V_HH8 = 248
+V_U = 249                                         # U0..U6 more temporaries 249..255
+FIRST_V, LAST_V = 32, 255
+
+S_T, S_NT, S_NW, S_MFIRST, S_LEN, S_C, S_LDSW, S_W4 = 40, 41, 42, 43, 44, 45, 46, 47
+S_KPTR, S_VPTR = 48, 50
+S_KSTEP, S_VSTEP, S_KRS2, S_VRS2 = 52, 53, 54, 55
+S_KB0, S_VB0 = 56, 58
+S_TMP = 60                                        # 60..63
+S_EXEC = 64
+S_VA, S_VB_ = 66, 68                              # valid-row exec masks of blocks A / B
+S_MV = 70                                         # 70..73: "moves" masks of blocks A / B
+S_M0SAVE, S_LENM1 = 74, 75
+S_TMP2 = 76                                       # 76..79
+FIRST_S, LAST_S = 40, 79
+
+KBUF = 16384
+
+
+def v(i):
+    return f"v{i}"
+
+
+def vr(i, n):
+    return f"v[{i}:{i + n - 1}]"
+
+
+def a(i):
+    return f"a{i}"
+
+
+def ar(i, n):
+    return f"a[{i}:{i + n - 1}]"
+
+
+def s(i):
+    return f"s{i}"
+
+
+def sr(i, n=2):
+    return f"s[{i}:{i + n - 1}]"
+
+
+class Gen:
+    def __init__(self):
+        self.lines = []
+        self.out = []          # outstanding LDS reads, oldest first (tags)
+        self.uid = 0
+
+    def e(self, text):
+        self.lines.append(text)
+
+    def label(self, name):
+        self.lines.append(f"{name}%=:")
+
+    def lref(self, name):
+        return f"{name}%="
+
+    # ---- LDS reads with counted waits ----
+    def lds(self, text, tag):
+        assert len(self.out) < 15, "lgkmcnt is a 4-bit counter"
+        self.out.append(tag)
+        self.e(text)
+
+    def need(self, tag):
+        if tag in self.out:
+            idx = self.out.index(tag)
+            self.e(f"s_waitcnt lgkmcnt({len(self.out) - idx - 1})")
+            self.out = self.out[idx + 1:]
+
+    def drain(self):
+        if self.out:
+            self.e("s_waitcnt lgkmcnt(0)")
+            self.out = []
+
+
+def s_regs(par):
+    """(score tile holding tile t, score tile receiving tile t + 1)"""
+    return (V_SA, V_SB) if par == 0 else (V_SB, V_SA)
+
+
+# ---- instruction streams ----------------------------------------------------------------------------------------------------------
+def k_read(g, f, ks):
+    """K fragment f (key block f // 8, k-step f % 8) of K slot ks into fragment slot f % 8"""
+    kb, st = f // 8, f % 8
+    g.lds(f"ds_read_b128 {ar(A_K + 4 * (f % 8), 4)}, {v(V_RA + st)} offset:{ks * KBUF + kb * 8192}", ("k", f))
+
+
+def s_mfma(g, i, sn):
+    """MFMA i of S = K Q^T: fragment i // 2, block i % 2"""
+    f, b = i // 2, i % 2
+    kb, st = f // 8, f % 8
+    g.need(("k", f))
+    dst = vr(sn + 32 * b + 16 * kb, 16)
+    g.e(f"v_mfma_f32_32x32x16_bf16 {dst}, {ar(A_K + 4 * (f % 8), 4)}, {ar(A_Q + 32 * b + 4 * st, 4)}, {'0' if st == 0 else dst}")
+
+
+def v_reads(g, grp, dt, vs):
+    """the two transposed reads of V^T fragment (key group grp, d-tile dt) of V slot vs"""
+    off = (2 + vs) * KBUF + (32 * (grp >> 1) + 16 * (grp & 1)) * 256
+    base = A_V + 16 * (grp & 1) + 4 * dt
+    return [(f"ds_read_b64_tr_b16 {ar(base + 2 * hi, 2)}, {v(V_TR + 2 * dt + hi)} offset:{off}", ("v", grp, dt, hi)) for hi in range(2)]
+
+
+def pv_mfma(g, i):
+    grp, dt, b = i // 8, (i % 8) // 2, i % 2
+    g.need(("v", grp, dt, 0))
+    g.need(("v", grp, dt, 1))
+    acc = ar(A_O + 64 * b + 16 * dt, 16)
+    g.e(f"v_mfma_f32_32x32x16_bf16 {acc}, {ar(A_V + 16 * (grp & 1) + 4 * dt, 4)}, {vr(V_P + 16 * b + 4 * grp, 4)}, {acc}")
+
+
+def finish_chunk(sc, b, kb, first):
+    """p = exp2(s c - m) in place, row sum in order, bf16 packing: 56 VALU, software-pipelined so that no result is used by
+    the two instructions behind its producer"""
+    base = sc + 32 * b + 16 * kb
+    ops = []
+    for i in range(16 + 6):
+        if i < 16:
+            ops.append(f"v_fma_f32 {v(base + i)}, {v(base + i)}, {s(S_C)}, -{v(V_M + b)}")
+        r = i - 2
+        if 0 <= r < 16:
+            ops.append(f"v_exp_f32 {v(base + r)}, {v(base + r)}")
+        r = i - 4
+        if 0 <= r < 16:
+            if first and r == 0:
+                ops.append(f"v_mov_b32 {v(V_PS + b)}, {v(base + r)}")           # 0 + p = p exactly (p >= 0)
+            else:
+                ops.append(f"v_add_f32 {v(V_PS + b)}, {v(V_PS + b)}, {v(base + r)}")
+        r = i - 5
+        if 0 <= r < 16 and r % 2 == 1:
+            half, w = r >> 3, (r & 7) >> 1
+            ops.append(f"v_cvt_pk_bf16_f32 {v(V_P + 16 * b + 4 * (2 * kb + half) + w)}, {v(base + r - 1)}, {v(base + r)}")
+    assert len(ops) == 56
+    return ops
+
+
+def max_chunk(sn, b, kb, first):
+    """running maximum of the 16 scores of (block b, key block kb) into MX[b]: v_max3 chain"""
+    base = sn + 32 * b + 16 * kb
+    ops = []
+    if first:
+        ops.append(f"v_max3_f32 {v(V_MX + b)}, {v(base)}, {v(base + 1)}, {v(base + 2)}")
+        rest = list(range(3, 16))
+    else:
+        rest = list(range(16))
+    while len(rest) >= 2:
+        ops.append(f"v_max3_f32 {v(V_MX + b)}, {v(V_MX + b)}, {v(base + rest[0])}, {v(base + rest[1])}")
+        rest = rest[2:]
+    if rest:
+        ops.append(f"v_max_f32 {v(V_MX + b)}, {v(V_MX + b)}, {v(base + rest[0])}")
+    return ops
+
+
+def decide_head():
+    """row maxima across the lane halves, candidate exponents, "moves" masks (s[S_MV..+1] block A, s[S_MV+2..+3] block B):
+    straight-line VALU, placed in the last gaps of phase Y"""
+    t = [V_T, V_T + 1]          # copies for the swap / candidates
+    u = [V_T + 2, V_T + 3]      # m_run + tau
+    ops = [f"v_mov_b32 {v(t[0])}, {v(V_MX)}", f"v_mov_b32 {v(t[1])}, {v(V_MX + 1)}", "s_nop 1",
+           f"v_permlane32_swap_b32 {v(t[0])}, {v(V_MX)}", f"v_permlane32_swap_b32 {v(t[1])}, {v(V_MX + 1)}",
+           f"v_add_f32 {v(u[0])}, 0x41000000, {v(V_M)}", f"v_add_f32 {v(u[1])}, 0x41000000, {v(V_M + 1)}",
+           f"v_max_f32 {v(V_MX)}, {v(V_MX)}, {v(t[0])}", f"v_max_f32 {v(V_MX + 1)}, {v(V_MX + 1)}, {v(t[1])}",
+           f"v_mul_f32 {v(t[0])}, {s(S_C)}, {v(V_MX)}", f"v_mul_f32 {v(t[1])}, {s(S_C)}, {v(V_MX + 1)}",
+           f"v_max_f32 {v(t[0])}, {v(V_M)}, {v(t[0])}", f"v_max_f32 {v(t[1])}, {v(V_M + 1)}, {v(t[1])}",
+           f"v_cmp_gt_f32 {sr(S_MV)}, {v(t[0])}, {v(u[0])}", f"v_cmp_gt_f32 {sr(S_MV + 2)}, {v(t[1])}, {v(u[1])}"]
+    return ops
+
+
+def decide_tail(g, name, first_tile=False):
+    """the wave-uniform branch and the rare rescale: m <- candidate where it moved, alpha = exp2(m_old - m_new), l *= alpha,
+    O *= alpha (skipped on an item's first tile, where l = O = 0)"""
+    g.e(f"s_or_b64 {sr(S_TMP)}, {sr(S_MV)}, {sr(S_MV + 2)}")
+    g.e(f"s_cbranch_scc0 {g.lref(name)}")
+    al = [V_T + 4, V_T + 5]
+    for b in range(2):
+        g.e(f"v_cndmask_b32 {v(V_T + 2 + b)}, {v(V_M + b)}, {v(V_T + b)}, {sr(S_MV + 2 * b)}")      # m_new
+    for b in range(2):
+        g.e(f"v_sub_f32 {v(al[b])}, {v(V_M + b)}, {v(V_T + 2 + b)}")
+    for b in range(2):
+        g.e(f"v_exp_f32 {v(al[b])}, {v(al[b])}")
+    for b in range(2):
+        g.e(f"v_mov_b32 {v(V_M + b)}, {v(V_T + 2 + b)}")
+    for b in range(2):
+        g.e(f"v_mul_f32 {v(V_L + b)}, {v(V_L + b)}, {v(al[b])}")
+    if not first_tile:
+        g.e("s_nop 15")                               # the P V MFMAs in flight write O
+        tmp = [V_U + i for i in range(6)]
+        regs = [(b, i) for b in range(2) for i in range(64)]
+        n = len(regs)
+        for i in range(n + 4):                        # read(i) | multiply(i - 2) | write(i - 4): a temporary is free again two steps
+            if i < n:                                 # before its next read
+                b, r = regs[i]
+                g.e(f"v_accvgpr_read_b32 {v(tmp[i % 6])}, {a(A_O + 64 * b + r)}")
+            j = i - 2
+            if 0 <= j < n:
+                g.e(f"v_mul_f32 {v(tmp[j % 6])}, {v(tmp[j % 6])}, {v(al[regs[j][0]])}")
+            k = i - 4
+            if 0 <= k < n:
+                b, r = regs[k]
+                g.e(f"v_accvgpr_write_b32 {a(A_O + 64 * b + r)}, {v(tmp[k % 6])}")
+        g.e("s_nop 4")
+    g.label(name)
+
+
+def rescale_selfcheck():
+    """the read / multiply / write pipeline above must touch every register exactly once in each role"""
+    g = Gen()
+    decide_tail(g, "x")
+    rd = [l for l in g.lines if l.startswith("v_accvgpr_read")]
+    wr = [l for l in g.lines if l.startswith("v_accvgpr_write")]
+    assert len(rd) == 128 and len(wr) == 128 and len(set(rd)) == 128 and len(set(wr)) == 128, (len(rd), len(wr))
+    # a temporary is rewritten only after its write-back has been issued
+    live = {}
+    temps = {v(V_U + i) for i in range(6)}
+    for l in g.lines:
+        w = l.replace(",", " ").split()
+        if w[0] == "v_accvgpr_read_b32":
+            assert live.get(w[1], "free") == "free", l
+            live[w[1]] = "read"
+        elif w[0] == "v_mul_f32" and w[1] in temps:
+            assert live[w[1]] == "read", l
+            live[w[1]] = "mul"
+        elif w[0] == "v_accvgpr_write_b32":
+            assert live[w[2]] == "mul", l
+            live[w[2]] = "free"
+    assert all(x == "free" for x in live.values())
+
+
+def mask_block(g, sx, tile_expr_reg):
+    """s <- -inf where the key lies beyond the lane's last visible key; tile index in SGPR tile_expr_reg"""
+    g.e("s_nop 15")
+    g.e(f"s_lshl_b32 {s(S_TMP)}, {s(tile_expr_reg)}, 6")
+    for b in range(2):
+        g.e(f"v_sub_u32 {v(V_KR + b)}, {v(V_KMAX + b)}, {s(S_TMP)}")
+    for b in range(2):
+        g.e(f"v_sub_u32 {v(V_KR + b)}, {v(V_KR + b)}, {v(V_HH8)}")
+    for b in range(2):
+        for kb in range(2):
+            for r in range(16):
+                const = 32 * kb + 16 * (r >> 3) + (r & 7)
+                reg = sx + 32 * b + 16 * kb + r
+                g.e(f"v_cmp_gt_i32 vcc, {const}, {v(V_KR + b)}")
+                g.e(f"v_cndmask_b32 {v(reg)}, {v(reg)}, {v(V_NEGINF)}, vcc")
+
+
+def dma_tile(g, tensor, slot, tile_reg, uniq):
+    """one 16 KiB tile of K or V into ring slot `slot`: four 1 KiB slices per wave.  tile_reg = SGPR holding the tile index (for the
+    partial-tile test).  Advances the running pointer."""
+    ptr, step, lo, rs2, b0 = (S_KPTR, S_KSTEP, V_LOK, S_KRS2, S_KB0) if tensor == "k" else (S_VPTR, S_VSTEP, V_LOV, S_VRS2, S_VB0)
+    lds0 = (0 if tensor == "k" else 2 * KBUF) + slot * KBUF
+    g.e(f"s_lshl_b32 {s(S_TMP2)}, {s(tile_reg)}, 6")
+    g.e(f"s_add_i32 {s(S_TMP2 + 1)}, {s(S_TMP2)}, 64")
+    g.e(f"s_cmp_gt_i32 {s(S_TMP2 + 1)}, {s(S_LEN)}")
+    g.e(f"s_cbranch_scc1 {g.lref('Ltail' + uniq)}")
+    for u in range(4):
+        g.e(f"s_add_u32 m0, {s(S_LDSW)}, {lds0 + u * 4096}")
+        g.e("s_nop 0")
+        g.e(f"global_load_lds_dwordx4 {v(lo + u)}, {sr(ptr)}")
+    g.e(f"s_branch {g.lref('Ldone' + uniq)}")
+    g.label("Ltail" + uniq)
+    g.e(f"s_add_i32 {s(S_TMP2)}, {s(S_TMP2)}, {s(S_W4)}")                 # first row of this wave's first slice
+    for u in range(4):
+        g.e(f"v_add_u32 {v(V_U)}, {s(S_TMP2)}, {v(V_LANE4)}")
+        g.e(f"v_min_i32 {v(V_U)}, {v(V_U)}, {s(S_LENM1)}")
+        g.e(f"v_mul_lo_u32 {v(V_U)}, {v(V_U)}, {s(rs2)}")
+        g.e(f"v_add_u32 {v(V_U)}, {v(V_U)}, {v(V_P8)}")
+        g.e(f"s_add_u32 m0, {s(S_LDSW)}, {lds0 + u * 4096}")
+        g.e(f"s_add_i32 {s(S_TMP2)}, {s(S_TMP2)}, 16")
+        g.e(f"global_load_lds_dwordx4 {v(V_U)}, {sr(b0)}")
+    g.label("Ldone" + uniq)
+    g.e(f"s_add_u32 {s(ptr)}, {s(ptr)}, {s(step)}")
+    g.e(f"s_addc_u32 {s(ptr + 1)}, {s(ptr + 1)}, 0")
+
+
+def place(gaps, stream, where):
+    """append the instructions of `stream` to the gaps listed in `where` (gap index per instruction, non-decreasing)"""
+    assert len(where) == len(stream), (len(where), len(stream))
+    for w, ins in zip(where, stream):
+        gaps[w].append(ins)
+
+
+def spread(n, lo, hi):
+    """n instructions spread evenly over gaps lo .. hi (inclusive)"""
+    width = hi - lo + 1
+    return [lo + (i * width) // n for i in range(n)]
+
+
+def emit_phase(g, n_mfma, mfma_fn, gaps):
+    for i in range(n_mfma):
+        mfma_fn(i)
+        for ins in gaps[i]:
+            if isinstance(ins, tuple):
+                g.lds(ins[0], ins[1])
+            else:
+                g.e(ins)
+
+
+MOVE_CHUNK = True      # exponentials of (block B, key block 1) run beside P V instead of beside K Q^T (balances the two phases)
+
+
+def gen_step(g, par):
+    sc, sn = s_regs(par)
+    ks, vs = 1 - par, par
+    P = f"p{par}"
+    g.label(f"Lstep{P}")
+    g.e("s_waitcnt vmcnt(0)")
+    g.e("s_barrier")
+    # K(t + 2) -> K slot par, V(t + 1) -> V slot 1 - par
+    g.e(f"s_add_i32 {s(S_TMP)}, {s(S_T)}, 2")
+    g.e(f"s_cmp_lt_i32 {s(S_TMP)}, {s(S_NT)}")
+    g.e(f"s_cbranch_scc0 {g.lref('LnoK' + P)}")
+    dma_tile(g, "k", par, S_TMP, "k" + P)
+    g.label("LnoK" + P)
+    g.e(f"s_add_i32 {s(S_TMP)}, {s(S_T)}, 1")
+    g.e(f"s_cmp_lt_i32 {s(S_TMP)}, {s(S_NT)}")
+    g.e(f"s_cbranch_scc0 {g.lref('LnoV' + P)}")
+    dma_tile(g, "v", 1 - par, S_TMP, "v" + P)
+    g.label("LnoV" + P)
+    g.e(f"s_cmp_ge_i32 {s(S_T)}, {s(S_NW)}")
+    g.e(f"s_cbranch_scc1 {g.lref('Lend' + P)}")
+    g.e(f"s_add_i32 {s(S_TMP)}, {s(S_T)}, 1")                 # stays t + 1 through the full step (mask test)
+    g.e(f"s_cmp_lt_i32 {s(S_TMP)}, {s(S_NW)}")
+    g.e(f"s_cbranch_scc0 {g.lref('Llast' + P)}")
+
+    # ---------------- full step ----------------
+    for f in range(8):
+        k_read(g, f, ks)
+    # phase X gaps
+    gx = [[] for _ in range(32)]
+    for f in range(8, 16):                                   # second K batch: slot f % 8 is free one MFMA after its last user
+        kb, st = f // 8, f % 8
+        gx[2 * (f - 8) + 2].append((f"ds_read_b128 {ar(A_K + 4 * (f % 8), 4)}, {v(V_RA + st)} offset:{ks * KBUF + kb * 8192}", ("k", f)))
+    fin = finish_chunk(sc, 0, 0, True) + finish_chunk(sc, 0, 1, False) + [f"v_add_f32 {v(V_L)}, {v(V_L)}, {v(V_PS)}"] + \
+        finish_chunk(sc, 1, 0, True)
+    fin_b1 = finish_chunk(sc, 1, 1, False) + [f"v_add_f32 {v(V_L + 1)}, {v(V_L + 1)}, {v(V_PS + 1)}"]
+    if not MOVE_CHUNK:
+        fin += fin_b1
+    place(gx, fin, spread(len(fin), 0, 31))
+    vg0 = [r for dt in range(4) for r in v_reads(g, 0, dt, vs)]
+    place(gx, vg0, spread(8, 22, 29))
+    emit_phase(g, 32, lambda i: s_mfma(g, i, sn), gx)
+    # mask of tile t + 1
+    g.e(f"s_cmp_ge_i32 {s(S_TMP)}, {s(S_MFIRST)}")
+    g.e(f"s_cbranch_scc0 {g.lref('Lnomask' + P)}")
+    mask_block(g, sn, S_TMP)
+    g.label("Lnomask" + P)
+    # phase Y gaps
+    gy = [[] for _ in range(32)]
+    vg1 = [r for dt in range(4) for r in v_reads(g, 1, dt, vs)]
+    place(gy, vg1, [0, 0, 1, 1, 2, 2, 3, 3])
+    for grp in (2, 3):
+        for dt in range(4):
+            where = 8 * (grp - 2) + 2 * dt + 2 + (2 if grp == 2 else 0)
+            for r in v_reads(g, grp, dt, vs):
+                gy[where].append(r)
+    mx = []
+    ca, cb = max_chunk(sn, 0, 0, True), max_chunk(sn, 1, 0, True)
+    for x, y in zip(ca, cb):
+        mx += [x, y]
+    ca, cb = max_chunk(sn, 0, 1, False), max_chunk(sn, 1, 1, False)
+    for x, y in zip(ca, cb):
+        mx += [x, y]
+    if MOVE_CHUNK:
+        place(gy, fin_b1, spread(len(fin_b1), 0, 13))        # P of (B, key block 1) feeds MFMA 17 at the earliest
+        place(gy, mx, spread(len(mx), 12, 27))
+    else:
+        place(gy, mx, spread(len(mx), 2, 25))
+    dh = decide_head()
+    place(gy, dh, spread(len(dh), 28, 31))
+    emit_phase(g, 32, lambda i: pv_mfma(g, i), gy)
+    assert not g.out
+    decide_tail(g, "Lkeep" + P)
+    g.e(f"s_branch {g.lref('Lend' + P)}")
+
+    # ---------------- the wave's last tile: nothing to overlap with ----------------
+    g.label("Llast" + P)
+    for ins in finish_chunk(sc, 0, 0, True) + finish_chunk(sc, 0, 1, False) + [f"v_add_f32 {v(V_L)}, {v(V_L)}, {v(V_PS)}"] + \
+            finish_chunk(sc, 1, 0, True) + finish_chunk(sc, 1, 1, False) + [f"v_add_f32 {v(V_L + 1)}, {v(V_L + 1)}, {v(V_PS + 1)}"]:
+        g.e(ins)
+    gl = [[] for _ in range(32)]
+    for text, tag in [r for dt in range(4) for r in v_reads(g, 0, dt, vs)]:
+        g.lds(text, tag)
+    place(gl, [r for dt in range(4) for r in v_reads(g, 1, dt, vs)], [0, 0, 1, 1, 2, 2, 3, 3])
+    for grp in (2, 3):
+        for dt in range(4):
+            where = 8 * (grp - 2) + 2 * dt + 2 + (2 if grp == 2 else 0)
+            for r in v_reads(g, grp, dt, vs):
+                gl[where].append(r)
+    emit_phase(g, 32, lambda i: pv_mfma(g, i), gl)
+    assert not g.out
+
+    g.label("Lend" + P)
+    g.e(f"s_add_i32 {s(S_T)}, {s(S_T)}, 1")
+    g.e(f"s_cmp_lt_i32 {s(S_T)}, {s(S_NT)}")
+    g.e(f"s_cbranch_scc0 {g.lref('Lepi')}")
+    if par == 1:
+        g.e(f"s_branch {g.lref('Lstepp0')}")
+
+
+def gen_body():
+    rescale_selfcheck()
+    g = Gen()
+    e = g.e
+    # ---- inputs into the fixed registers ----
+    e(f"s_mov_b64 {sr(S_EXEC)}, exec")
+    e(f"s_mov_b32 {s(S_M0SAVE)}, m0")
+    for dst, name in ((S_NT, "ntiles"), (S_NW, "nw"), (S_MFIRST, "mfirst"), (S_LEN, "len"), (S_C, "c"), (S_KRS2, "krs2"), (S_VRS2, "vrs2")):
+        e(f"s_mov_b32 {s(dst)}, %[{name}]")
+    e(f"s_lshl_b32 {s(S_W4)}, %[wave], 2")
+    e(f"s_lshl_b32 {s(S_TMP)}, %[wave], 10")
+    e(f"s_add_u32 {s(S_LDSW)}, %[ldsbase], {s(S_TMP)}")
+    e(f"s_add_i32 {s(S_LENM1)}, {s(S_LEN)}, -1")
+    e(f"s_mov_b64 {sr(S_KB0)}, %[kbase]")
+    e(f"s_mov_b64 {sr(S_VB0)}, %[vbase]")
+    # running pointers start at row 4 * wave of tile 0
+    e(f"s_mul_i32 {s(S_TMP)}, {s(S_W4)}, {s(S_KRS2)}")
+    e(f"s_add_u32 {s(S_KPTR)}, {s(S_KB0)}, {s(S_TMP)}")
+    e(f"s_addc_u32 {s(S_KPTR + 1)}, {s(S_KB0 + 1)}, 0")
+    e(f"s_mul_i32 {s(S_TMP)}, {s(S_W4)}, {s(S_VRS2)}")
+    e(f"s_add_u32 {s(S_VPTR)}, {s(S_VB0)}, {s(S_TMP)}")
+    e(f"s_addc_u32 {s(S_VPTR + 1)}, {s(S_VB0 + 1)}, 0")
+    e(f"s_lshl_b32 {s(S_KSTEP)}, {s(S_KRS2)}, 6")
+    e(f"s_lshl_b32 {s(S_VSTEP)}, {s(S_VRS2)}, 6")
+    for dst, name in ((V_QA, "qa"), (V_QB, "qb"), (V_OA, "oa"), (V_OB, "ob")):
+        e(f"v_lshl_add_u64 {vr(dst, 2)}, %[{name}], 0, 0")
+    e(f"v_lshrrev_b32 {v(V_LANE4)}, 4, %[lane]")
+    e(f"v_lshrrev_b32 {v(V_HH8)}, 5, %[lane]")
+    e(f"v_lshlrev_b32 {v(V_HH8)}, 3, {v(V_HH8)}")
+    e(f"v_mov_b32 {v(V_P8)}, %[p8]")
+    e(f"v_mov_b32 {v(V_KMAX)}, %[kmaxa]")
+    e(f"v_mov_b32 {v(V_KMAX + 1)}, %[kmaxb]")
+    e(f"v_mov_b32 {v(V_VALID)}, %[valid]")
+    e(f"v_mov_b32 {v(V_NEGINF)}, 0xff800000")
+    # slice offsets: lane_off + u * 16 rows
+    e(f"s_lshl_b32 {s(S_TMP)}, {s(S_KRS2)}, 4")
+    e(f"s_lshl_b32 {s(S_TMP + 1)}, {s(S_VRS2)}, 4")
+    e(f"v_mul_lo_u32 {v(V_LOK)}, {v(V_LANE4)}, {s(S_KRS2)}")
+    e(f"v_mul_lo_u32 {v(V_LOV)}, {v(V_LANE4)}, {s(S_VRS2)}")
+    e(f"v_add_u32 {v(V_LOK)}, {v(V_LOK)}, {v(V_P8)}")
+    e(f"v_add_u32 {v(V_LOV)}, {v(V_LOV)}, {v(V_P8)}")
+    for u in range(1, 4):
+        e(f"v_add_u32 {v(V_LOK + u)}, {v(V_LOK + u - 1)}, {s(S_TMP)}")
+        e(f"v_add_u32 {v(V_LOV + u)}, {v(V_LOV + u - 1)}, {s(S_TMP + 1)}")
+    # LDS fragment addresses: row_addr[st] = row_addr[0] ^ (st << 5); tr_addr[dt][0] = tr_addr[0][0] ^ (dt << 6),
+    # tr_addr[dt][1] = (tr_addr[dt][0] ^ 16) + 1024   (attn_common.h make_row_addr / make_tr_addr; checked by the C++ side)
+    e(f"v_mov_b32 {v(V_RA)}, %[ra0]")
+    for st in range(1, 8):
+        e(f"v_xor_b32 {v(V_RA + st)}, {st << 5}, {v(V_RA)}")
+    e(f"v_mov_b32 {v(V_TR)}, %[tr0]")
+    for dt in range(1, 4):
+        e(f"v_xor_b32 {v(V_TR + 2 * dt)}, {dt << 6}, {v(V_TR)}")
+    for dt in range(4):
+        e(f"v_xor_b32 {v(V_TR + 2 * dt + 1)}, 16, {v(V_TR + 2 * dt)}")
+        e(f"v_add_u32 {v(V_TR + 2 * dt + 1)}, 0x400, {v(V_TR + 2 * dt + 1)}")
+    for i in range(8):                                # (the relations hold for offsets inside a tile: the LDS base comes last)
+        e(f"v_add_u32 {v(V_RA + i)}, %[ldsbase], {v(V_RA + i)}")
+        e(f"v_add_u32 {v(V_TR + i)}, %[ldsbase], {v(V_TR + i)}")
+    # valid-row masks
+    e(f"v_and_b32 {v(V_T)}, 1, {v(V_VALID)}")
+    e(f"v_cmp_ne_u32 {sr(S_VA)}, 0, {v(V_T)}")
+    e(f"v_and_b32 {v(V_T)}, 2, {v(V_VALID)}")
+    e(f"v_cmp_ne_u32 {sr(S_VB_)}, 0, {v(V_T)}")
+    # ---- Q fragments straight into accumulator registers; O = 0; softmax state ----
+    for b, ptr in ((0, V_QA), (1, V_QB)):
+        for st in range(8):
+            e(f"global_load_dwordx4 {ar(A_Q + 32 * b + 4 * st, 4)}, {vr(ptr, 2)}, off offset:{32 * st}")
+    e(f"s_mov_b32 {s(S_T)}, 0")
+    dma_tile(g, "k", 0, S_T, "pk0")
+    dma_tile(g, "v", 0, S_T, "pv0")
+    e(f"s_cmp_gt_i32 {s(S_NT)}, 1")
+    e(f"s_cbranch_scc0 {g.lref('Lp1')}")
+    e(f"s_mov_b32 {s(S_TMP)}, 1")
+    dma_tile(g, "k", 1, S_TMP, "pk1")
+    g.label("Lp1")
+    for i in range(128):
+        e(f"v_accvgpr_write_b32 {a(A_O + i)}, 0")
+    for b in range(2):
+        e(f"v_mov_b32 {v(V_M + b)}, 0xf149f2ca")       # -1e30f
+        e(f"v_mov_b32 {v(V_L + b)}, 0")
+    e("s_waitcnt vmcnt(0)")
+    e("s_barrier")
+    e(f"s_cmp_gt_i32 {s(S_NW)}, 0")
+    e(f"s_cbranch_scc0 {g.lref('Lstepp0')}")
+    # ---- S(0) without overlap, mask, maxima, first reference exponents ----
+    for f in range(8):
+        k_read(g, f, 0)
+    g0 = [[] for _ in range(32)]
+    for f in range(8, 16):
+        kb, st = f // 8, f % 8
+        g0[2 * (f - 8) + 2].append((f"ds_read_b128 {ar(A_K + 4 * (f % 8), 4)}, {v(V_RA + st)} offset:{kb * 8192}", ("k", f)))
+    emit_phase(g, 32, lambda i: s_mfma(g, i, V_SA), g0)
+    e(f"s_cmp_ge_i32 {s(S_T)}, {s(S_MFIRST)}")
+    e(f"s_cbranch_scc0 {g.lref('Lnomask0')}")
+    mask_block(g, V_SA, S_T)
+    g.label("Lnomask0")
+    e("s_nop 15")
+    ca, cb = max_chunk(V_SA, 0, 0, True), max_chunk(V_SA, 1, 0, True)
+    for x, y in zip(ca, cb):
+        e(x)
+        e(y)
+    ca, cb = max_chunk(V_SA, 0, 1, False), max_chunk(V_SA, 1, 1, False)
+    for x, y in zip(ca, cb):
+        e(x)
+        e(y)
+    for ins in decide_head():
+        e(ins)
+    decide_tail(g, "Lkeep0", first_tile=True)
+    # ---- tile loop ----
+    gen_step(g, 0)
+    gen_step(g, 1)
+    # ---- epilogue: O^T / l as bf16, 8 bytes per store ----
+    g.label("Lepi")
+    e("s_nop 15")
+    T0, T1, X, D0, R, N, E1, Q_, INV = [V_T + i for i in range(8)] + [V_U]
+    for b in range(2):
+        e(f"v_mov_b32 {v(T0)}, {v(V_L + b)}")
+        e(f"v_mov_b32 {v(T1)}, {v(V_L + b)}")
+        e("s_nop 1")
+        e(f"v_permlane32_swap_b32 {v(T0)}, {v(T1)}")
+        e(f"v_add_f32 {v(X)}, {v(T0)}, {v(T1)}")
+        # 1.0f / x exactly as hipcc expands it (v_div_scale / v_rcp / Newton / v_div_fmas / v_div_fixup)
+        e(f"v_div_scale_f32 {v(D0)}, {sr(S_TMP)}, {v(X)}, {v(X)}, 1.0")
+        e(f"v_rcp_f32 {v(R)}, {v(D0)}")
+        e(f"v_div_scale_f32 {v(N)}, vcc, 1.0, {v(X)}, 1.0")
+        e("s_nop 0")
+        e(f"v_fma_f32 {v(E1)}, -{v(D0)}, {v(R)}, 1.0")
+        e(f"v_fmac_f32 {v(R)}, {v(E1)}, {v(R)}")
+        e(f"v_mul_f32 {v(Q_)}, {v(N)}, {v(R)}")
+        e(f"v_fma_f32 {v(E1)}, -{v(D0)}, {v(Q_)}, {v(N)}")
+        e(f"v_fmac_f32 {v(Q_)}, {v(E1)}, {v(R)}")
+        e(f"v_fma_f32 {v(D0)}, -{v(D0)}, {v(Q_)}, {v(N)}")
+        e(f"v_div_fmas_f32 {v(D0)}, {v(D0)}, {v(R)}, {v(Q_)}")
+        e(f"v_div_fixup_f32 {v(INV)}, {v(D0)}, {v(X)}, 1.0")
+        e(f"v_cmp_lt_f32 vcc, 0, {v(X)}")
+        e(f"v_cndmask_b32 {v(INV)}, 0, {v(INV)}, vcc")
+        e(f"s_mov_b64 exec, {sr(S_VA if b == 0 else S_VB_)}")
+        optr = V_OA if b == 0 else V_OB
+        tmp = [V_U + 1 + i for i in range(4)]
+        for dt in range(4):
+            for g4 in range(4):
+                base = A_O + 64 * b + 16 * dt + 4 * g4
+                for i in range(4):
+                    e(f"v_accvgpr_read_b32 {v(tmp[i])}, {a(base + i)}")
+                for i in range(4):
+                    e(f"v_mul_f32 {v(tmp[i])}, {v(tmp[i])}, {v(INV)}")
+                e(f"v_cvt_pk_bf16_f32 {v(tmp[0])}, {v(tmp[0])}, {v(tmp[1])}")
+                e(f"v_cvt_pk_bf16_f32 {v(tmp[1])}, {v(tmp[2])}, {v(tmp[3])}")
+                e(f"global_store_dwordx2 {vr(optr, 2)}, {vr(tmp[0], 2)}, off offset:{64 * dt + 16 * g4}")
+        e(f"s_mov_b64 exec, {sr(S_EXEC)}")
+    for b in range(2):
+        e(f"v_mov_b32 %[m{b}], {v(V_M + b)}")
+        e(f"v_mov_b32 %[l{b}], {v(V_L + b)}")
+    e(f"s_mov_b32 m0, {s(S_M0SAVE)}")
+    return g
+
+
+def clobbers():
+    names = [f"v{i}" for i in range(FIRST_V, LAST_V + 1)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(FIRST_S, LAST_S + 1)]
+    return names + ["vcc", "scc", "memory"]
+
+
+def main():
+    g = gen_body()
+    with open(OUT, "w") as f:
+        f.write("// GENERATED by tools/gen_attn_fwd64.py -- do not edit; the per-item body of attn_fwd64_kernel as one inline-asm statement.\n")
+        f.write(f"// {len(g.lines)} lines; MOVE_CHUNK = {MOVE_CHUNK}\n")
+        f.write("#define VSEL_FWD64_ASM_TEXT \\\n")
+        for ln in g.lines:
+            f.write(f'  "{ln}\\n\\t" \\\n')
+        f.write('  ""\n')
+        f.write("#define VSEL_FWD64_ASM_CLOBBERS \\\n  ")
+        cl = clobbers()
+        f.write(", ".join(f'"{c}"' for c in cl))
+        f.write("\n")
+    n_mfma = sum(1 for ln in g.lines if ln.startswith("v_mfma"))
+    print(f"wrote {OUT}: {len(g.lines)} instructions / labels, {n_mfma} MFMAs")
+
+
+if __name__ == "__main__":
+    main()

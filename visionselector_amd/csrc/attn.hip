@@ -28,8 +28,6 @@ namespace vsel {
 using namespace attn;      // tile layout + fragment addressing shared with the backward (attn_common.h)
 
 // LDS rows are 256 bytes for every supported head_dim (64 / 80 / 128)
-constexpr int kTileK = 64;
-constexpr float kLazyTau = 8.f;     // online softmax: the reference exponent of a row moves only past this slack (log2 units)
 constexpr int kBuf = kTileBytes;             // 16 KiB per tile
 constexpr int kLds = 4 * kBuf;               // K[2], V[2]: 64 KiB
 
@@ -54,18 +52,6 @@ __device__ unsigned long long g_fwd_tile_trace[8][8];
 #define VSEL_FWD_STAMP(slot) do {} while (0)
 #endif
 
-// Optional paged-KV / separate key lengths.  Contiguous var-len prefill (the reference's call sites) leaves it empty.
-struct PagedKV {
-  const int32_t* seqlens_k;     // [n_seq] key length per sequence (NULL: same cu_seqlens as the queries)
-  const int32_t* block_table;   // [n_seq, max_pages] physical page of logical page p (NULL: keys contiguous at cu_k)
-  const int32_t* cu_k;          // [n_seq + 1] key row offsets when keys are contiguous but differ from the queries (or NULL)
-  int max_pages;
-  int page_size;
-  // Layout of q and of k / v in elements (0 = packed [T, H, d]: row stride H * d, head stride d).  Head-major tensors
-  // ([B, H, L, d] as HuggingFace attention modules hold them): row stride d, head stride L * d; the sequence base stays
-  // cu[seq] * H * d in both layouts (cu = b * L).
-  int64_t q_row_stride, q_head_stride, kv_row_stride, kv_head_stride, v_row_stride, v_head_stride;   // v_*: 0 = same as k
-};
 
 // NW = waves per workgroup (4 -> 128 queries, two workgroups per CU; 8 -> 256 queries, one workgroup per CU sharing ONE K/V
 // stream among its 8 waves: half the global loads and LDS stores per FLOP, used when the grid is large enough).
@@ -691,6 +677,10 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
                       (g_attn_split == 1 || (lse == nullptr && (pg.seqlens_k != nullptr || max_seqlen_q >= 256)));
   // ... and 64-query workgroups whose wave pairs split every tile's keys (KH = 2) while those still fit one per CU
   const bool split2_q64 = split2 && g_attn_split_q64 && cdiv(max_seqlen_q, 64) * hq * n_seq <= 256;
+  // 64 rows per wave, one wave per SIMD, hand-scheduled tile loop (attn_fwd64.hip): the large-grid form for head_dim 128
+  const int g_rows64 = knob(VSEL_KNOB_ATTN_ROWS64);
+  if (d == 128 && g_attn_use_tr && !pack && !pg.block_table && g_attn_nw == 0 && (g_rows64 == 1 || (g_rows64 < 0 && big && !split2)))
+    return attn::attn_fwd64_launch(st, q, k, v, cu_q, n_seq, max_seqlen_q, hq, hkv, scale, causal, out, pg, lse);
   const int block_q = big ? 256 : (split2_q64 ? 64 : 128);
   const int q_tiles = (int)cdiv(max_seqlen_q, block_q);
   const int64_t n_items = pack ? hkv * n_seq : (int64_t)q_tiles * hq * n_seq;

@@ -72,6 +72,26 @@ __device__ __forceinline__ void load_slice_lds(const uint16_t* src_row_ptr, int 
 // 4 i + (l >> 4) holds part (l & 15) ^ swz(row), and swz(row) = ((l >> 4) << 2) | (w & 3) for every such slice.
 __device__ __forceinline__ int slice_src_part(int lane, int wave) { return (lane & 15) ^ (((lane >> 4) << 2) | (wave & 3)); }
 
+constexpr int kTileK = 64;           // keys per K / V tile
+constexpr float kLazyTau = 8.f;      // online softmax: the reference exponent of a row moves only past this slack (log2 units)
+
+// Optional paged-KV / separate key lengths.  Contiguous var-len prefill (the reference's call sites) leaves it empty.
+struct PagedKV {
+  const int32_t* seqlens_k;     // [n_seq] key length per sequence (NULL: same cu_seqlens as the queries)
+  const int32_t* block_table;   // [n_seq, max_pages] physical page of logical page p (NULL: keys contiguous at cu_k)
+  const int32_t* cu_k;          // [n_seq + 1] key row offsets when keys are contiguous but differ from the queries (or NULL)
+  int max_pages;
+  int page_size;
+  // Layout of q and of k / v in elements (0 = packed [T, H, d]: row stride H * d, head stride d).  Head-major tensors
+  // ([B, H, L, d] as HuggingFace attention modules hold them): row stride d, head stride L * d; the sequence base stays
+  // cu[seq] * H * d in both layouts (cu = b * L).
+  int64_t q_row_stride, q_head_stride, kv_row_stride, kv_head_stride, v_row_stride, v_head_stride;   // v_*: 0 = same as k
+};
+
+// 64-rows-per-wave forward for head_dim 128 (attn_fwd64.hip): contiguous keys only (no page table); same items as the 8-wave form
+int attn_fwd64_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
+                      int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg, float* lse);
+
 // ---- XCD-local work queues (round 4) ------------------------------------------------------------------------------------------
 // Every attention kernel streams one operand pair (K / V in the forward and the dQ pass, Q / dO in the dK / dV pass) that ALL the
 // work items of a (sequence, kv head) pair share.  With one global queue the workgroups resident on an XCD belong to 8+ different

@@ -29,7 +29,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "visionselector_amd", "csrc", "attn_fwd64_body.inc")
+OUT = os.environ.get("F64_OUT", os.path.join(ROOT, "visionselector_amd", "csrc", "attn_fwd64_body.inc"))
 
 # ---- register map ---------------------------------------------------------------------------------------------------------------
 A_O, A_Q, A_K, A_V = 0, 128, 192, 224
@@ -55,8 +55,11 @@ S_EXEC = 64
 S_VA, S_VB_ = 66, 68                              # valid-row exec masks of blocks A / B
 S_MV = 70                                         # 70..73: "moves" masks of blocks A / B
 S_M0SAVE, S_LENM1 = 74, 75
-S_TMP2 = 76                                       # 76..79
-FIRST_S, LAST_S = 40, 79
+S_TMP2 = 76                                       # 76..77
+S_NSTEADY = 78
+S_TR = 80                                         # trace: 80..81 stamp, 82 previous stamp, 83.. accumulators (12)
+N_ACC = 12
+FIRST_S, LAST_S = 40, 95
 
 KBUF = 16384
 
@@ -89,7 +92,8 @@ class Gen:
     def __init__(self):
         self.lines = []
         self.out = []          # outstanding LDS reads, oldest first (tags)
-        self.uid = 0
+        self.done = set()      # tags already waited for (since the last phase start)
+        self.strict = True
 
     def e(self, text):
         self.lines.append(text)
@@ -104,18 +108,36 @@ class Gen:
     def lds(self, text, tag):
         assert len(self.out) < 15, "lgkmcnt is a 4-bit counter"
         self.out.append(tag)
+        self.done.discard(tag)
         self.e(text)
 
     def need(self, tag):
         if tag in self.out:
             idx = self.out.index(tag)
             self.e(f"s_waitcnt lgkmcnt({len(self.out) - idx - 1})")
+            self.done.update(self.out[:idx + 1])
             self.out = self.out[idx + 1:]
+        else:
+            assert tag in self.done or not self.strict, f"fragment {tag} is consumed before its read was issued"
 
     def drain(self):
         if self.out:
             self.e("s_waitcnt lgkmcnt(0)")
             self.out = []
+
+
+def stamp(g, k):
+    """trace builds: cycles since the previous stamp are added to accumulator k (no LDS read may be outstanding: s_memtime
+    returns through lgkmcnt)"""
+    if not OPT["trace"]:
+        return
+    assert not g.out
+    g.e(f"s_memtime {sr(S_TR)}")
+    g.e("s_waitcnt lgkmcnt(0)")
+    if k >= 0:
+        g.e(f"s_sub_u32 {s(S_TMP2)}, {s(S_TR)}, {s(S_TR + 2)}")
+        g.e(f"s_add_u32 {s(S_TR + 3 + k)}, {s(S_TR + 3 + k)}, {s(S_TMP2)}")
+    g.e(f"s_mov_b32 {s(S_TR + 2)}, {s(S_TR)}")
 
 
 def s_regs(par):
@@ -124,34 +146,59 @@ def s_regs(par):
 
 
 # ---- instruction streams ----------------------------------------------------------------------------------------------------------
+def frag_kb_st(f):
+    """fragment f of a K tile in issue order -> (key block, k-step).  srot: k-step major, so the MFMAs rotate over the four score
+    accumulators (block A / B x key block 0 / 1) and a dependent accumulate sits four MFMAs behind its producer, not two"""
+    return (f % 2, f // 2) if OPT["srot"] else (f // 8, f % 8)
+
+
 def k_read(g, f, ks):
-    """K fragment f (key block f // 8, k-step f % 8) of K slot ks into fragment slot f % 8"""
-    kb, st = f // 8, f % 8
+    """K fragment f (frag_kb_st) of K slot ks into fragment slot f % 8"""
+    kb, st = frag_kb_st(f)
     g.lds(f"ds_read_b128 {ar(A_K + 4 * (f % 8), 4)}, {v(V_RA + st)} offset:{ks * KBUF + kb * 8192}", ("k", f))
 
 
-def s_mfma(g, i, sn):
+def s_mfma(g, i, sn, emit=True, acc_dst=False):
     """MFMA i of S = K Q^T: fragment i // 2, block i % 2"""
     f, b = i // 2, i % 2
-    kb, st = f // 8, f % 8
-    g.need(("k", f))
+    kb, st = frag_kb_st(f)
+    # one counted wait per group of four fragments (their reads were issued >= 4 gaps ago): every s_waitcnt is an issue slot
+    g.need(("k", f | 3) if OPT["wgrp"] else ("k", f))
     dst = vr(sn + 32 * b + 16 * kb, 16)
-    g.e(f"v_mfma_f32_32x32x16_bf16 {dst}, {ar(A_K + 4 * (f % 8), 4)}, {ar(A_Q + 32 * b + 4 * st, 4)}, {'0' if st == 0 else dst}")
+    if acc_dst:                                  # timing experiment: the same MFMAs with accumulator-register destinations
+        dst = ar(32 * b + 16 * kb, 16)
+    if emit:
+        g.e(f"v_mfma_f32_32x32x16_bf16 {dst}, {ar(A_K + 4 * (f % 8), 4)}, {ar(A_Q + 32 * b + 4 * st, 4)}, {'0' if st == 0 else dst}")
+
+
+def v_frag(grp, dt):
+    """accumulator registers of V^T fragment (key group, d-tile).  pvsplit: all sixteen stay resident through the step (key groups
+    2 and 3 in the K fragment registers, which are dead during P V)"""
+    if OPT["pvsplit"]:
+        return (A_V, A_V + 16, A_K, A_K + 16)[grp] + 4 * dt
+    return A_V + 16 * (grp & 1) + 4 * dt
 
 
 def v_reads(g, grp, dt, vs):
     """the two transposed reads of V^T fragment (key group grp, d-tile dt) of V slot vs"""
     off = (2 + vs) * KBUF + (32 * (grp >> 1) + 16 * (grp & 1)) * 256
-    base = A_V + 16 * (grp & 1) + 4 * dt
+    base = v_frag(grp, dt)
     return [(f"ds_read_b64_tr_b16 {ar(base + 2 * hi, 2)}, {v(V_TR + 2 * dt + hi)} offset:{off}", ("v", grp, dt, hi)) for hi in range(2)]
 
 
-def pv_mfma(g, i):
-    grp, dt, b = i // 8, (i % 8) // 2, i % 2
-    g.need(("v", grp, dt, 0))
-    g.need(("v", grp, dt, 1))
+def pv_mfma(g, i, emit=True):
+    if OPT["pvsplit"]:                           # block A over all key groups, then block B from the resident fragments
+        b, grp, dt = i // 16, (i % 16) // 4, i % 4
+    else:
+        grp, dt, b = i // 8, (i % 8) // 2, i % 2
+    if OPT["wgrp"]:
+        g.need(("v", grp, 3, 1))                 # the whole key group's eight reads
+    else:
+        g.need(("v", grp, dt, 0))
+        g.need(("v", grp, dt, 1))
     acc = ar(A_O + 64 * b + 16 * dt, 16)
-    g.e(f"v_mfma_f32_32x32x16_bf16 {acc}, {ar(A_V + 16 * (grp & 1) + 4 * dt, 4)}, {vr(V_P + 16 * b + 4 * grp, 4)}, {acc}")
+    if emit:
+        g.e(f"v_mfma_f32_32x32x16_bf16 {acc}, {ar(v_frag(grp, dt), 4)}, {vr(V_P + 16 * b + 4 * grp, 4)}, {acc}")
 
 
 def finish_chunk(sc, b, kb, first):
@@ -177,6 +224,10 @@ def finish_chunk(sc, b, kb, first):
             ops.append(f"v_cvt_pk_bf16_f32 {v(V_P + 16 * b + 4 * (2 * kb + half) + w)}, {v(base + r - 1)}, {v(base + r)}")
     assert len(ops) == 56
     return ops
+
+
+def finish_a(sc):
+    return finish_chunk(sc, 0, 0, True) + finish_chunk(sc, 0, 1, False) + [f"v_add_f32 {v(V_L)}, {v(V_L)}, {v(V_PS)}"]
 
 
 def max_chunk(sn, b, kb, first):
@@ -340,7 +391,174 @@ def emit_phase(g, n_mfma, mfma_fn, gaps):
                 g.e(ins)
 
 
-MOVE_CHUNK = True      # exponentials of (block B, key block 1) run beside P V instead of beside K Q^T (balances the two phases)
+# ---- schedule options (F64_OPTS="key=value,..." overrides; tools/ab_fwd64.py builds one library per option set) -------------------
+OPT = {
+    "move_chunk": 1,      # exponentials of (block B, key block 1) beside P V instead of beside K Q^T (balances the two phases)
+    "dmak": "x:1,3,5,7",  # steady steps: where the four K(t + 2) slices are issued: "top" | "x:<gaps>" | "y:<gaps>"
+    "dmav": "x:9,11,13,15",   # ... and the four V(t + 1) slices
+    "pre": 12,            # VALU of the exponentials issued before the first MFMA of phase X (covers the first K reads' latency)
+    "vg0": "22,29",       # phase-X gaps over which the first V^T group's reads are spread
+    "pvsplit": 0,         # P V: all of block A, then all of block B from V^T fragments that stay resident; block B's exponentials
+                          # then run beside block A's MFMAs and only block A's beside K Q^T
+    "mxx": 0,             # with pvsplit and srot = 0: the maxima of key block 0 already beside the last K Q^T MFMAs
+    "early": 0,           # exponentials of the NEXT tile (block A first) issued at the end of a step, in front of the barrier wait
+    "srot": 1,            # S MFMAs rotate over the four score accumulators (k-step major fragment order)
+    "wgrp": 1,            # one s_waitcnt per group of four K fragments / per V key group instead of one per fragment
+    "trace": 0,           # s_memtime stamps summed per wave and added to a global table at the end of every item (timing builds only)
+    "ko": "",             # knock-outs for timing experiments (WRONG results): any of fin,max,dma,bar,lds,mfma joined by "+"
+}
+for kv in os.environ.get("F64_OPTS", "").replace(";", ",").split(","):
+    if "=" in kv:
+        key, val = kv.split("=", 1)
+        assert key in OPT, key
+        OPT[key] = type(OPT[key])(val) if not isinstance(OPT[key], str) else val.replace("/", ",")
+
+
+def dma_pieces(tensor, slot):
+    """in-gap form of one full tile's four slices: [(m0 write, DMA)] + the pointer advance"""
+    ptr, step, lo = (S_KPTR, S_KSTEP, V_LOK) if tensor == "k" else (S_VPTR, S_VSTEP, V_LOV)
+    lds0 = (0 if tensor == "k" else 2 * KBUF) + slot * KBUF
+    pieces = [(f"s_add_u32 m0, {s(S_LDSW)}, {lds0 + u * 4096}", f"global_load_lds_dwordx4 {v(lo + u)}, {sr(ptr)}") for u in range(4)]
+    adv = [f"s_add_u32 {s(ptr)}, {s(ptr)}, {s(step)}", f"s_addc_u32 {s(ptr + 1)}, {s(ptr + 1)}, 0"]
+    return pieces, adv
+
+
+def insert_dma(gaps, where, pieces, adv):
+    """m0 write first in its gap, the load behind the gap's first other instruction (>= 1 wait state after the m0 write)"""
+    for w, (m0w, ld) in zip(where, pieces):
+        rest = gaps[w]
+        gaps[w] = [m0w] + (rest[:1] if rest else ["s_nop 0"]) + [ld] + rest[1:]
+    gaps[where[-1] + 1] = adv + gaps[where[-1] + 1]
+
+
+def parse_where(spec):
+    if spec == "top":
+        return None, None
+    ph, lst = spec.split(":")
+    return ph, [int(x) for x in lst.split(",")]
+
+
+def full_step(g, par, tag, steady):
+    """S(t + 1) beside the exponentials of tile t; mask; P V beside the maxima of tile t + 1; reference exponents.  s[S_TMP] = t + 1.
+    steady: K(t + 2) / V(t + 1) are full tiles that exist -- their direct-to-LDS loads ride in the gaps."""
+    sc, sn = s_regs(par)
+    ks, vs = 1 - par, par
+    for f in range(8):
+        k_read(g, f, ks)
+    gx = [[] for _ in range(33)]
+    gy = [[] for _ in range(33)]
+    fin = finish_a(sc)[OPT["early"]:] + finish_chunk(sc, 1, 0, True)      # (the first "early" ones ran at the end of the previous step)
+    fin_b1 = finish_chunk(sc, 1, 1, False) + [f"v_add_f32 {v(V_L + 1)}, {v(V_L + 1)}, {v(V_PS + 1)}"]
+    if OPT["pvsplit"]:
+        fin = finish_a(sc)[OPT["early"]:]
+        fin_b0 = finish_chunk(sc, 1, 0, True)
+    elif not OPT["move_chunk"]:
+        fin += fin_b1
+    pre = fin[:OPT["pre"]]
+    fin = fin[OPT["pre"]:]
+    for ins in pre:                                          # the first K fragments are still on their way
+        g.e(ins)
+    place(gx, fin, spread(len(fin), 0, 31))
+    for f in range(8, 16):                                   # second K batch: slot f % 8 is free one MFMA after its last user
+        kb, st = frag_kb_st(f)
+        gx[2 * (f - 8) + 2].append((f"ds_read_b128 {ar(A_K + 4 * (f % 8), 4)}, {v(V_RA + st)} offset:{ks * KBUF + kb * 8192}", ("k", f)))
+    vg0 = [r for dt in range(4) for r in v_reads(g, 0, dt, vs)]
+    vg1 = [r for dt in range(4) for r in v_reads(g, 1, dt, vs)]
+    mx = []
+    ca, cb = max_chunk(sn, 0, 0, True), max_chunk(sn, 1, 0, True)
+    for x, y in zip(ca, cb):
+        mx += [x, y]
+    mx_kb0 = list(mx)
+    ca, cb = max_chunk(sn, 0, 1, False), max_chunk(sn, 1, 1, False)
+    for x, y in zip(ca, cb):
+        mx += [x, y]
+    if OPT["pvsplit"]:
+        # X: block A's exponentials, K reads, V key groups 0 and 1 (last read in Y: lgkmcnt counts 15), [maxima of key block 0]
+        place(gx, vg0, spread(8, 16, 23))
+        place(gx, vg1[:7], spread(7, 24, 30))
+        gy[0].append(vg1[7])
+        for grp, lo in ((2, 1), (3, 5)):
+            reads = [r for dt in range(4) for r in v_reads(g, grp, dt, vs)]
+            place(gy, reads, [lo + k // 2 for k in range(8)])
+        if OPT["mxx"]:                                       # (k-step-minor fragment order only: key block 0 is complete after MFMA 15)
+            assert not OPT["srot"]
+            place(gx, mx_kb0, spread(len(mx_kb0), 22, 31))
+            mx = mx[len(mx_kb0):]
+        place(gy, fin_b0, spread(len(fin_b0), 0, 13))        # P of (B, key groups 0 / 1) feeds MFMA 16 at the earliest
+        place(gy, fin_b1, spread(len(fin_b1), 8, 22))        # ... of key groups 2 / 3 MFMA 24
+        place(gy, mx, spread(len(mx), 4, 27))
+    else:
+        lo, hi = [int(x) for x in OPT["vg0"].split(",")]
+        place(gx, vg0, spread(8, lo, hi))
+        place(gy, vg1, [0, 0, 1, 1, 2, 2, 3, 3])
+        for grp in (2, 3):
+            for dt in range(4):
+                where = 8 * (grp - 2) + 2 * dt + 2 + (2 if grp == 2 else 0)
+                for r in v_reads(g, grp, dt, vs):
+                    gy[where].append(r)
+    if OPT["pvsplit"]:
+        pass
+    elif OPT["move_chunk"]:
+        place(gy, fin_b1, spread(len(fin_b1), 0, 13))        # P of (B, key block 1) feeds MFMA 17 at the earliest
+        place(gy, mx, spread(len(mx), 12, 27))
+    else:
+        place(gy, mx, spread(len(mx), 2, 25))
+    dh = decide_head()
+    place(gy, dh, spread(len(dh), 28, 31))
+    ko = set(OPT["ko"].split("+")) if steady else set()
+    if "fin" in ko:
+        gx = [[i for i in gap if not (isinstance(i, str) and i.split()[0] in ("v_fma_f32", "v_exp_f32", "v_add_f32", "v_mov_b32", "v_cvt_pk_bf16_f32"))] for gap in gx]
+        gy = [[i for i in gap if not (isinstance(i, str) and i.split()[0] in ("v_fma_f32", "v_exp_f32", "v_cvt_pk_bf16_f32"))] for gap in gy]
+    if "exp" in ko:
+        gx = [[(i.replace("v_exp_f32", "v_mov_b32") if isinstance(i, str) else i) for i in gap] for gap in gx]
+        gy = [[(i.replace("v_exp_f32", "v_mov_b32") if isinstance(i, str) else i) for i in gap] for gap in gy]
+    if "max" in ko:
+        gy = [[i for i in gap if not (isinstance(i, str) and i.split()[0] in ("v_max3_f32", "v_max_f32"))] for gap in gy]
+    if "lds" in ko:
+        gx = [[i for i in gap if not isinstance(i, tuple)] for gap in gx]
+        gy = [[i for i in gap if not isinstance(i, tuple)] for gap in gy]
+        g.out = []
+        g.strict = False
+    if steady and "dma" not in ko:
+        for tensor, slot, spec in (("k", par, OPT["dmak"]), ("v", 1 - par, OPT["dmav"])):
+            ph, where = parse_where(spec)
+            pieces, adv = dma_pieces(tensor, slot)
+            if ph is None:
+                for m0w, ld in pieces:
+                    g.e(m0w)
+                    g.e("s_nop 0")
+                    g.e(ld)
+                for ins in adv:
+                    g.e(ins)
+            else:
+                insert_dma(gx if ph == "x" else gy, where, pieces, adv)
+    assert not gx[32] or all(isinstance(i, str) and i.startswith("s_add") for i in gx[32])
+    emit_phase(g, 32, lambda i: s_mfma(g, i, sn, "mfma" not in ko, "sacc" in ko), gx)
+    for ins in gx[32]:
+        g.e(ins)
+    if OPT["trace"] and steady:
+        saved = list(g.out)
+        g.e("s_waitcnt lgkmcnt(0)")
+        g.out = []
+        stamp(g, 1)
+        g.done.update(saved)
+    # mask of tile t + 1
+    g.e(f"s_cmp_ge_i32 {s(S_TMP)}, {s(S_MFIRST)}")
+    g.e(f"s_cbranch_scc0 {g.lref('Lnomask' + tag)}")
+    mask_block(g, sn, S_TMP)
+    g.label("Lnomask" + tag)
+    emit_phase(g, 32, lambda i: pv_mfma(g, i, "mfma" not in ko), gy)
+    for ins in gy[32]:
+        g.e(ins)
+    if ko:
+        g.drain()
+        g.strict = True
+    assert not g.out
+    if steady:
+        stamp(g, 2)
+    decide_tail(g, "Lkeep" + tag)
+    for ins in finish_a(sn)[:OPT["early"]]:                  # tile t + 1's exponentials start here: VALU is free while the wave
+        g.e(ins)                                             # waits for the others at the next barrier
 
 
 def gen_step(g, par):
@@ -349,7 +567,20 @@ def gen_step(g, par):
     P = f"p{par}"
     g.label(f"Lstep{P}")
     g.e("s_waitcnt vmcnt(0)")
-    g.e("s_barrier")
+    if "bar" not in OPT["ko"].split("+"):
+        g.e("s_barrier")
+    g.e(f"s_add_i32 {s(S_TMP)}, {s(S_T)}, 1")                 # stays t + 1 through a full step (mask test)
+    g.e(f"s_cmp_lt_i32 {s(S_T)}, {s(S_NSTEADY)}")
+    g.e(f"s_cbranch_scc0 {g.lref('Lgen' + P)}")
+    # ---------------- steady full step: the next tiles' loads ride in the gaps ----------------
+    stamp(g, 0)
+    if OPT["trace"]:
+        g.e(f"s_add_u32 {s(S_TR + 3 + 7)}, {s(S_TR + 3 + 7)}, 1")
+    full_step(g, par, "s" + P, True)
+    stamp(g, 3)
+    g.e(f"s_branch {g.lref('Lend' + P)}")
+    # ---------------- generic step: loads up front (conditional, partial tiles), then full / last / nothing ----------------
+    g.label("Lgen" + P)
     # K(t + 2) -> K slot par, V(t + 1) -> V slot 1 - par
     g.e(f"s_add_i32 {s(S_TMP)}, {s(S_T)}, 2")
     g.e(f"s_cmp_lt_i32 {s(S_TMP)}, {s(S_NT)}")
@@ -362,65 +593,18 @@ def gen_step(g, par):
     dma_tile(g, "v", 1 - par, S_TMP, "v" + P)
     g.label("LnoV" + P)
     g.e(f"s_cmp_ge_i32 {s(S_T)}, {s(S_NW)}")
-    g.e(f"s_cbranch_scc1 {g.lref('Lend' + P)}")
-    g.e(f"s_add_i32 {s(S_TMP)}, {s(S_T)}, 1")                 # stays t + 1 through the full step (mask test)
+    g.e(f"s_cbranch_scc1 {g.lref('Lidle' + P)}")
+    g.e(f"s_add_i32 {s(S_TMP)}, {s(S_T)}, 1")
     g.e(f"s_cmp_lt_i32 {s(S_TMP)}, {s(S_NW)}")
     g.e(f"s_cbranch_scc0 {g.lref('Llast' + P)}")
-
-    # ---------------- full step ----------------
-    for f in range(8):
-        k_read(g, f, ks)
-    # phase X gaps
-    gx = [[] for _ in range(32)]
-    for f in range(8, 16):                                   # second K batch: slot f % 8 is free one MFMA after its last user
-        kb, st = f // 8, f % 8
-        gx[2 * (f - 8) + 2].append((f"ds_read_b128 {ar(A_K + 4 * (f % 8), 4)}, {v(V_RA + st)} offset:{ks * KBUF + kb * 8192}", ("k", f)))
-    fin = finish_chunk(sc, 0, 0, True) + finish_chunk(sc, 0, 1, False) + [f"v_add_f32 {v(V_L)}, {v(V_L)}, {v(V_PS)}"] + \
-        finish_chunk(sc, 1, 0, True)
-    fin_b1 = finish_chunk(sc, 1, 1, False) + [f"v_add_f32 {v(V_L + 1)}, {v(V_L + 1)}, {v(V_PS + 1)}"]
-    if not MOVE_CHUNK:
-        fin += fin_b1
-    place(gx, fin, spread(len(fin), 0, 31))
-    vg0 = [r for dt in range(4) for r in v_reads(g, 0, dt, vs)]
-    place(gx, vg0, spread(8, 22, 29))
-    emit_phase(g, 32, lambda i: s_mfma(g, i, sn), gx)
-    # mask of tile t + 1
-    g.e(f"s_cmp_ge_i32 {s(S_TMP)}, {s(S_MFIRST)}")
-    g.e(f"s_cbranch_scc0 {g.lref('Lnomask' + P)}")
-    mask_block(g, sn, S_TMP)
-    g.label("Lnomask" + P)
-    # phase Y gaps
-    gy = [[] for _ in range(32)]
-    vg1 = [r for dt in range(4) for r in v_reads(g, 1, dt, vs)]
-    place(gy, vg1, [0, 0, 1, 1, 2, 2, 3, 3])
-    for grp in (2, 3):
-        for dt in range(4):
-            where = 8 * (grp - 2) + 2 * dt + 2 + (2 if grp == 2 else 0)
-            for r in v_reads(g, grp, dt, vs):
-                gy[where].append(r)
-    mx = []
-    ca, cb = max_chunk(sn, 0, 0, True), max_chunk(sn, 1, 0, True)
-    for x, y in zip(ca, cb):
-        mx += [x, y]
-    ca, cb = max_chunk(sn, 0, 1, False), max_chunk(sn, 1, 1, False)
-    for x, y in zip(ca, cb):
-        mx += [x, y]
-    if MOVE_CHUNK:
-        place(gy, fin_b1, spread(len(fin_b1), 0, 13))        # P of (B, key block 1) feeds MFMA 17 at the earliest
-        place(gy, mx, spread(len(mx), 12, 27))
-    else:
-        place(gy, mx, spread(len(mx), 2, 25))
-    dh = decide_head()
-    place(gy, dh, spread(len(dh), 28, 31))
-    emit_phase(g, 32, lambda i: pv_mfma(g, i), gy)
-    assert not g.out
-    decide_tail(g, "Lkeep" + P)
+    full_step(g, par, "g" + P, False)
+    stamp(g, 4)
     g.e(f"s_branch {g.lref('Lend' + P)}")
 
     # ---------------- the wave's last tile: nothing to overlap with ----------------
     g.label("Llast" + P)
-    for ins in finish_chunk(sc, 0, 0, True) + finish_chunk(sc, 0, 1, False) + [f"v_add_f32 {v(V_L)}, {v(V_L)}, {v(V_PS)}"] + \
-            finish_chunk(sc, 1, 0, True) + finish_chunk(sc, 1, 1, False) + [f"v_add_f32 {v(V_L + 1)}, {v(V_L + 1)}, {v(V_PS + 1)}"]:
+    for ins in finish_a(sc)[OPT["early"]:] + finish_chunk(sc, 1, 0, True) + finish_chunk(sc, 1, 1, False) + \
+            [f"v_add_f32 {v(V_L + 1)}, {v(V_L + 1)}, {v(V_PS + 1)}"]:
         g.e(ins)
     gl = [[] for _ in range(32)]
     for text, tag in [r for dt in range(4) for r in v_reads(g, 0, dt, vs)]:
@@ -429,11 +613,17 @@ def gen_step(g, par):
     for grp in (2, 3):
         for dt in range(4):
             where = 8 * (grp - 2) + 2 * dt + 2 + (2 if grp == 2 else 0)
+            if OPT["pvsplit"]:
+                where = 4 * (grp - 1) + dt                   # key group g feeds MFMA 4 g of the block-A pass
             for r in v_reads(g, grp, dt, vs):
                 gl[where].append(r)
     emit_phase(g, 32, lambda i: pv_mfma(g, i), gl)
     assert not g.out
+    stamp(g, 4)
 
+    g.e(f"s_branch {g.lref('Lend' + P)}")
+    g.label("Lidle" + P)
+    stamp(g, 4)
     g.label("Lend" + P)
     g.e(f"s_add_i32 {s(S_T)}, {s(S_T)}, 1")
     g.e(f"s_cmp_lt_i32 {s(S_T)}, {s(S_NT)}")
@@ -449,12 +639,23 @@ def gen_body():
     # ---- inputs into the fixed registers ----
     e(f"s_mov_b64 {sr(S_EXEC)}, exec")
     e(f"s_mov_b32 {s(S_M0SAVE)}, m0")
+    if OPT["trace"]:
+        for k in range(N_ACC):
+            e(f"s_mov_b32 {s(S_TR + 3 + k)}, 0")
+        stamp(g, -1)
     for dst, name in ((S_NT, "ntiles"), (S_NW, "nw"), (S_MFIRST, "mfirst"), (S_LEN, "len"), (S_C, "c"), (S_KRS2, "krs2"), (S_VRS2, "vrs2")):
         e(f"s_mov_b32 {s(dst)}, %[{name}]")
     e(f"s_lshl_b32 {s(S_W4)}, %[wave], 2")
     e(f"s_lshl_b32 {s(S_TMP)}, %[wave], 10")
     e(f"s_add_u32 {s(S_LDSW)}, %[ldsbase], {s(S_TMP)}")
     e(f"s_add_i32 {s(S_LENM1)}, {s(S_LEN)}, -1")
+    # steps 0 .. NSTEADY - 1 are full steps whose next tiles K(t + 2), V(t + 1) exist and are whole: min(nw - 1, ntiles - 2, len / 64 - 2)
+    e(f"s_add_i32 {s(S_NSTEADY)}, {s(S_NW)}, -1")
+    e(f"s_add_i32 {s(S_TMP)}, {s(S_NT)}, -2")
+    e(f"s_min_i32 {s(S_NSTEADY)}, {s(S_NSTEADY)}, {s(S_TMP)}")
+    e(f"s_ashr_i32 {s(S_TMP)}, {s(S_LEN)}, 6")
+    e(f"s_add_i32 {s(S_TMP)}, {s(S_TMP)}, -2")
+    e(f"s_min_i32 {s(S_NSTEADY)}, {s(S_NSTEADY)}, {s(S_TMP)}")
     e(f"s_mov_b64 {sr(S_KB0)}, %[kbase]")
     e(f"s_mov_b64 {sr(S_VB0)}, %[vbase]")
     # running pointers start at row 4 * wave of tile 0
@@ -466,7 +667,7 @@ def gen_body():
     e(f"s_addc_u32 {s(S_VPTR + 1)}, {s(S_VB0 + 1)}, 0")
     e(f"s_lshl_b32 {s(S_KSTEP)}, {s(S_KRS2)}, 6")
     e(f"s_lshl_b32 {s(S_VSTEP)}, {s(S_VRS2)}, 6")
-    for dst, name in ((V_QA, "qa"), (V_QB, "qb"), (V_OA, "oa"), (V_OB, "ob")):
+    for dst, name in ((V_QA, "qa"), (V_QB, "qb")):
         e(f"v_lshl_add_u64 {vr(dst, 2)}, %[{name}], 0, 0")
     e(f"v_lshrrev_b32 {v(V_LANE4)}, 4, %[lane]")
     e(f"v_lshrrev_b32 {v(V_HH8)}, 5, %[lane]")
@@ -474,7 +675,6 @@ def gen_body():
     e(f"v_mov_b32 {v(V_P8)}, %[p8]")
     e(f"v_mov_b32 {v(V_KMAX)}, %[kmaxa]")
     e(f"v_mov_b32 {v(V_KMAX + 1)}, %[kmaxb]")
-    e(f"v_mov_b32 {v(V_VALID)}, %[valid]")
     e(f"v_mov_b32 {v(V_NEGINF)}, 0xff800000")
     # slice offsets: lane_off + u * 16 rows
     e(f"s_lshl_b32 {s(S_TMP)}, {s(S_KRS2)}, 4")
@@ -500,11 +700,6 @@ def gen_body():
     for i in range(8):                                # (the relations hold for offsets inside a tile: the LDS base comes last)
         e(f"v_add_u32 {v(V_RA + i)}, %[ldsbase], {v(V_RA + i)}")
         e(f"v_add_u32 {v(V_TR + i)}, %[ldsbase], {v(V_TR + i)}")
-    # valid-row masks
-    e(f"v_and_b32 {v(V_T)}, 1, {v(V_VALID)}")
-    e(f"v_cmp_ne_u32 {sr(S_VA)}, 0, {v(V_T)}")
-    e(f"v_and_b32 {v(V_T)}, 2, {v(V_VALID)}")
-    e(f"v_cmp_ne_u32 {sr(S_VB_)}, 0, {v(V_T)}")
     # ---- Q fragments straight into accumulator registers; O = 0; softmax state ----
     for b, ptr in ((0, V_QA), (1, V_QB)):
         for st in range(8):
@@ -522,8 +717,10 @@ def gen_body():
     for b in range(2):
         e(f"v_mov_b32 {v(V_M + b)}, 0xf149f2ca")       # -1e30f
         e(f"v_mov_b32 {v(V_L + b)}, 0")
+    stamp(g, 8)
     e("s_waitcnt vmcnt(0)")
     e("s_barrier")
+    stamp(g, 9)
     e(f"s_cmp_gt_i32 {s(S_NW)}, 0")
     e(f"s_cbranch_scc0 {g.lref('Lstepp0')}")
     # ---- S(0) without overlap, mask, maxima, first reference exponents ----
@@ -531,9 +728,10 @@ def gen_body():
         k_read(g, f, 0)
     g0 = [[] for _ in range(32)]
     for f in range(8, 16):
-        kb, st = f // 8, f % 8
+        kb, st = frag_kb_st(f)
         g0[2 * (f - 8) + 2].append((f"ds_read_b128 {ar(A_K + 4 * (f % 8), 4)}, {v(V_RA + st)} offset:{kb * 8192}", ("k", f)))
     emit_phase(g, 32, lambda i: s_mfma(g, i, V_SA), g0)
+    stamp(g, 10)
     e(f"s_cmp_ge_i32 {s(S_T)}, {s(S_MFIRST)}")
     e(f"s_cbranch_scc0 {g.lref('Lnomask0')}")
     mask_block(g, V_SA, S_T)
@@ -550,13 +748,22 @@ def gen_body():
     for ins in decide_head():
         e(ins)
     decide_tail(g, "Lkeep0", first_tile=True)
+    for ins in finish_a(V_SA)[:OPT["early"]]:
+        e(ins)
     # ---- tile loop ----
+    stamp(g, 5)
     gen_step(g, 0)
     gen_step(g, 1)
-    # ---- epilogue: O^T / l as bf16, 8 bytes per store ----
+    # ---- epilogue: O^T / l as bf16.  A lane holds 4 consecutive features of ONE row per register quad, so direct stores are 8 bytes
+    # at a 7 KB stride (32 of them per lane: 11-16k cycles of store issue per item, measured).  The tile goes through LDS instead (the
+    # K / V rings are free once every wave has passed the barrier below): ds_write_b64 with the 16-byte chunk c of row r at position
+    # c ^ (r & 15) (conflict-free for the 16 lanes of a group), read back as whole rows (ds_read_b128, 4 rows per instruction) and
+    # stored as 16 x 1 KiB of whole 256-byte rows.
     g.label("Lepi")
     e("s_nop 15")
-    T0, T1, X, D0, R, N, E1, Q_, INV = [V_T + i for i in range(8)] + [V_U]
+    e("s_barrier")
+    T0, T1, X, D0, R, N, E1, Q_ = [V_T + i for i in range(8)]
+    INV = [V_U, V_U + 1]
     for b in range(2):
         e(f"v_mov_b32 {v(T0)}, {v(V_L + b)}")
         e(f"v_mov_b32 {v(T1)}, {v(V_L + b)}")
@@ -575,22 +782,71 @@ def gen_body():
         e(f"v_fmac_f32 {v(Q_)}, {v(E1)}, {v(R)}")
         e(f"v_fma_f32 {v(D0)}, -{v(D0)}, {v(Q_)}, {v(N)}")
         e(f"v_div_fmas_f32 {v(D0)}, {v(D0)}, {v(R)}, {v(Q_)}")
-        e(f"v_div_fixup_f32 {v(INV)}, {v(D0)}, {v(X)}, 1.0")
+        e(f"v_div_fixup_f32 {v(INV[b])}, {v(D0)}, {v(X)}, 1.0")
         e(f"v_cmp_lt_f32 vcc, 0, {v(X)}")
-        e(f"v_cndmask_b32 {v(INV)}, 0, {v(INV)}, vcc")
-        e(f"s_mov_b64 exec, {sr(S_VA if b == 0 else S_VB_)}")
-        optr = V_OA if b == 0 else V_OB
-        tmp = [V_U + 1 + i for i in range(4)]
+        e(f"v_cndmask_b32 {v(INV[b])}, 0, {v(INV[b])}, vcc")
+    # this wave's 16 KiB of LDS: base + wave * 16384 (base is a multiple of 1024: the XOR below commutes with the add)
+    WA, RD, AD = V_T, V_T + 1, V_T + 2
+    e(f"s_lshl_b32 {s(S_TMP)}, %[wave], 14")
+    e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, %[ldsbase]")
+    e(f"v_and_b32 {v(WA)}, 31, %[lane]")
+    e(f"v_lshlrev_b32 {v(WA)}, 8, {v(WA)}")                         # row * 256
+    e(f"v_add_u32 {v(WA)}, {v(WA)}, {v(V_HH8)}")                     # + 8 hh
+    e(f"v_and_b32 {v(AD)}, 15, %[lane]")
+    e(f"v_lshlrev_b32 {v(AD)}, 4, {v(AD)}")                          # (row & 15) << 4
+    e(f"v_xor_b32 {v(WA)}, {v(WA)}, {v(AD)}")
+    e(f"v_add_u32 {v(WA)}, {s(S_TMP)}, {v(WA)}")
+    e(f"v_lshlrev_b32 {v(RD)}, 4, %[lane]")
+    e(f"v_add_u32 {v(RD)}, {s(S_TMP)}, {v(RD)}")
+    tmp = [V_U + 3 + i for i in range(4)]                         # (64-bit VGPR operands must start at an even register)
+    assert tmp[0] % 2 == 0 and tmp[3] <= LAST_V
+    for b in range(2):
         for dt in range(4):
             for g4 in range(4):
                 base = A_O + 64 * b + 16 * dt + 4 * g4
                 for i in range(4):
                     e(f"v_accvgpr_read_b32 {v(tmp[i])}, {a(base + i)}")
                 for i in range(4):
-                    e(f"v_mul_f32 {v(tmp[i])}, {v(tmp[i])}, {v(INV)}")
+                    e(f"v_mul_f32 {v(tmp[i])}, {v(tmp[i])}, {v(INV[b])}")
                 e(f"v_cvt_pk_bf16_f32 {v(tmp[0])}, {v(tmp[0])}, {v(tmp[1])}")
                 e(f"v_cvt_pk_bf16_f32 {v(tmp[1])}, {v(tmp[2])}, {v(tmp[3])}")
-                e(f"global_store_dwordx2 {vr(optr, 2)}, {vr(tmp[0], 2)}, off offset:{64 * dt + 16 * g4}")
+                e(f"v_xor_b32 {v(AD)}, {(4 * dt + g4) << 4}, {v(WA)}")
+                e(f"ds_write_b64 {v(AD)}, {vr(tmp[0], 2)} offset:{8192 * b}")
+    e("s_waitcnt lgkmcnt(0)")
+    # global offsets of the four row phases: (lane >> 4) * row stride + 16 * ((lane & 15) ^ (4 k + (lane >> 4)))
+    VO = [V_KR, V_KR + 1, V_MX, V_MX + 1]
+    e(f"v_and_b32 {v(AD)}, 15, %[lane]")
+    e(f"v_mul_lo_u32 {v(WA)}, {v(V_LANE4)}, %[ostride]")
+    for k in range(4):
+        e(f"v_add_u32 {v(VO[k])}, {4 * k}, {v(V_LANE4)}")
+        e(f"v_xor_b32 {v(VO[k])}, {v(VO[k])}, {v(AD)}")
+        e(f"v_lshl_add_u32 {v(VO[k])}, {v(VO[k])}, 4, {v(WA)}")
+    e(f"s_mov_b64 {sr(S_TMP)}, %[obase]")
+    e(f"s_lshl_b32 {s(S_TMP2)}, %[ostride], 2")
+    e(f"s_mov_b32 {s(S_TMP2 + 1)}, %[nvalid]")
+    for i in range(12):
+        e(f"ds_read_b128 {vr(V_SA + 4 * i, 4)}, {v(RD)} offset:{1024 * i}")
+    e("s_waitcnt lgkmcnt(8)")                                  # (lgkmcnt counts at most 15 outstanding operations)
+    for i in range(12, 16):
+        e(f"ds_read_b128 {vr(V_SA + 4 * i, 4)}, {v(RD)} offset:{1024 * i}")
+    for i in range(16):
+        if i >= 4:
+            e(f"s_waitcnt lgkmcnt({15 - i})")
+        e(f"v_cmp_gt_i32 vcc, {s(S_TMP2 + 1)}, {v(V_LANE4)}")        # row 4 i + (lane >> 4) of this wave exists
+        e("s_mov_b64 exec, vcc")
+        e(f"global_store_dwordx4 {v(VO[i % 4])}, {vr(V_SA + 4 * i, 4)}, {sr(S_TMP)}")
+        e(f"s_mov_b64 exec, {sr(S_EXEC)}")
+        e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, {s(S_TMP2)}")
+        e(f"s_addc_u32 {s(S_TMP + 1)}, {s(S_TMP + 1)}, 0")
+        e(f"s_add_i32 {s(S_TMP2 + 1)}, {s(S_TMP2 + 1)}, -4")
+    if OPT["trace"]:
+        e("s_waitcnt vmcnt(0)")
+        stamp(g, 6)
+        e("s_mov_b64 exec, 1")
+        e(f"v_mov_b32 {v(V_T + 1)}, 0")
+        for k in range(N_ACC):
+            e(f"v_mov_b32 {v(V_T)}, {s(S_TR + 3 + k)}")
+            e(f"global_atomic_add {v(V_T + 1)}, {v(V_T)}, %[dbg] offset:{4 * k}")
         e(f"s_mov_b64 exec, {sr(S_EXEC)}")
     for b in range(2):
         e(f"v_mov_b32 %[m{b}], {v(V_M + b)}")
@@ -608,7 +864,7 @@ def main():
     g = gen_body()
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_attn_fwd64.py -- do not edit; the per-item body of attn_fwd64_kernel as one inline-asm statement.\n")
-        f.write(f"// {len(g.lines)} lines; MOVE_CHUNK = {MOVE_CHUNK}\n")
+        f.write(f"// {len(g.lines)} lines; options {OPT}\n")
         f.write("#define VSEL_FWD64_ASM_TEXT \\\n")
         for ln in g.lines:
             f.write(f'  "{ln}\\n\\t" \\\n')

@@ -44,7 +44,7 @@ typedef enum vsel_debug_knob {
                                      stream they share stays in that XCD's L2: -1 by sequence length and pair count per kernel (default), 0 / 1 force (env
                                      VSEL_ATTN_XCD_QUEUE); placement only, outputs bit-identical */
   VSEL_KNOB_ATTN_ROWS64 = 14,     /* forward for head_dim 128 by the 64-rows-per-wave kernel (one 512-register wave per SIMD, hand-scheduled
-                                     tile loop; csrc/attn_fwd64.hip): -1 where the 8-wave form would be chosen (default), 0 never,
+                                     tile loop; csrc/attn_fwd64.hip): -1 from 2048 tokens in the longest sequence (default), 0 never,
                                      1 whenever it applies (contiguous keys); env VSEL_ATTN_ROWS64; bit-identical outputs */
   VSEL_KNOB_COUNT = 15
 } vsel_debug_knob;

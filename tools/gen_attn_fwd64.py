@@ -64,6 +64,15 @@ FIRST_S, LAST_S = 40, 95
 KBUF = 16384
 
 
+def nk():
+    return OPT["kring"]
+
+
+def v_base():
+    """LDS offset of V slot 0 (behind the K ring)"""
+    return nk() * KBUF
+
+
 def v(i):
     return f"v{i}"
 
@@ -131,7 +140,8 @@ def stamp(g, k):
     returns through lgkmcnt)"""
     if not OPT["trace"]:
         return
-    assert not g.out
+    g.done.update(g.out)                                   # (trace builds wait for whatever is in flight here)
+    g.out = []
     g.e(f"s_memtime {sr(S_TR)}")
     g.e("s_waitcnt lgkmcnt(0)")
     if k >= 0:
@@ -181,7 +191,7 @@ def v_frag(grp, dt):
 
 def v_reads(g, grp, dt, vs):
     """the two transposed reads of V^T fragment (key group grp, d-tile dt) of V slot vs"""
-    off = (2 + vs) * KBUF + (32 * (grp >> 1) + 16 * (grp & 1)) * 256
+    off = vs * KBUF + (32 * (grp >> 1) + 16 * (grp & 1)) * 256          # (the address registers point at V slot 0: ds offsets are 16 bits)
     base = v_frag(grp, dt)
     return [(f"ds_read_b64_tr_b16 {ar(base + 2 * hi, 2)}, {v(V_TR + 2 * dt + hi)} offset:{off}", ("v", grp, dt, hi)) for hi in range(2)]
 
@@ -343,7 +353,7 @@ def dma_tile(g, tensor, slot, tile_reg, uniq):
     """one 16 KiB tile of K or V into ring slot `slot`: four 1 KiB slices per wave.  tile_reg = SGPR holding the tile index (for the
     partial-tile test).  Advances the running pointer."""
     ptr, step, lo, rs2, b0 = (S_KPTR, S_KSTEP, V_LOK, S_KRS2, S_KB0) if tensor == "k" else (S_VPTR, S_VSTEP, V_LOV, S_VRS2, S_VB0)
-    lds0 = (0 if tensor == "k" else 2 * KBUF) + slot * KBUF
+    lds0 = (0 if tensor == "k" else v_base()) + slot * KBUF
     g.e(f"s_lshl_b32 {s(S_TMP2)}, {s(tile_reg)}, 6")
     g.e(f"s_add_i32 {s(S_TMP2 + 1)}, {s(S_TMP2)}, 64")
     g.e(f"s_cmp_gt_i32 {s(S_TMP2 + 1)}, {s(S_LEN)}")
@@ -398,6 +408,9 @@ OPT = {
     "dmav": "x:9,11,13,15",   # ... and the four V(t + 1) slices
     "pre": 12,            # VALU of the exponentials issued before the first MFMA of phase X (covers the first K reads' latency)
     "vg0": "22,29",       # phase-X gaps over which the first V^T group's reads are spread
+    "kring": 2,           # K ring slots: 3 = K three tiles ahead, so that K(t + 2) has been visible since the PREVIOUS step's barrier and
+                          # the first K fragments of a step are read at the end of the step before (LDS latency out of phase X: measured
+                          # -80 cycles in X, +110 elsewhere and one more non-steady step per item: 1146 vs 1160 TFLOP/s; not the default)
     "pvsplit": 0,         # P V: all of block A, then all of block B from V^T fragments that stay resident; block B's exponentials
                           # then run beside block A's MFMAs and only block A's beside K Q^T
     "mxx": 0,             # with pvsplit and srot = 0: the maxima of key block 0 already beside the last K Q^T MFMAs
@@ -417,7 +430,7 @@ for kv in os.environ.get("F64_OPTS", "").replace(";", ",").split(","):
 def dma_pieces(tensor, slot):
     """in-gap form of one full tile's four slices: [(m0 write, DMA)] + the pointer advance"""
     ptr, step, lo = (S_KPTR, S_KSTEP, V_LOK) if tensor == "k" else (S_VPTR, S_VSTEP, V_LOV)
-    lds0 = (0 if tensor == "k" else 2 * KBUF) + slot * KBUF
+    lds0 = (0 if tensor == "k" else v_base()) + slot * KBUF
     pieces = [(f"s_add_u32 m0, {s(S_LDSW)}, {lds0 + u * 4096}", f"global_load_lds_dwordx4 {v(lo + u)}, {sr(ptr)}") for u in range(4)]
     adv = [f"s_add_u32 {s(ptr)}, {s(ptr)}, {s(step)}", f"s_addc_u32 {s(ptr + 1)}, {s(ptr + 1)}, 0"]
     return pieces, adv
@@ -438,13 +451,17 @@ def parse_where(spec):
     return ph, [int(x) for x in lst.split(",")]
 
 
-def full_step(g, par, tag, steady):
+def full_step(g, par, tag, steady, ks, kdma, ks_next):
     """S(t + 1) beside the exponentials of tile t; mask; P V beside the maxima of tile t + 1; reference exponents.  s[S_TMP] = t + 1.
     steady: K(t + 2) / V(t + 1) are full tiles that exist -- their direct-to-LDS loads ride in the gaps."""
     sc, sn = s_regs(par)
-    ks, vs = 1 - par, par
-    for f in range(8):
-        k_read(g, f, ks)
+    vs = par
+    if nk() == 3:
+        seed = [("k", f) for f in range(8)]                  # issued at the end of the previous step / prologue
+        assert g.out == seed or (OPT["trace"] and not g.out and all(t in g.done for t in seed))
+    else:
+        for f in range(8):
+            k_read(g, f, ks)
     gx = [[] for _ in range(33)]
     gy = [[] for _ in range(33)]
     fin = finish_a(sc)[OPT["early"]:] + finish_chunk(sc, 1, 0, True)      # (the first "early" ones ran at the end of the previous step)
@@ -520,7 +537,7 @@ def full_step(g, par, tag, steady):
         g.out = []
         g.strict = False
     if steady and "dma" not in ko:
-        for tensor, slot, spec in (("k", par, OPT["dmak"]), ("v", 1 - par, OPT["dmav"])):
+        for tensor, slot, spec in (("k", kdma, OPT["dmak"]), ("v", 1 - par, OPT["dmav"])):
             ph, where = parse_where(spec)
             pieces, adv = dma_pieces(tensor, slot)
             if ph is None:
@@ -559,12 +576,22 @@ def full_step(g, par, tag, steady):
     decide_tail(g, "Lkeep" + tag)
     for ins in finish_a(sn)[:OPT["early"]]:                  # tile t + 1's exponentials start here: VALU is free while the wave
         g.e(ins)                                             # waits for the others at the next barrier
+    if nk() == 3:                                            # K(t + 2) has been visible since this step's barrier: the next step's first
+        for f in range(8):                                   # fragments are on their way while the wave waits at the next barrier
+            k_read(g, f, ks_next)
 
 
-def gen_step(g, par):
+def gen_step(g, idx, period):
+    """step t with t % period == idx"""
+    par = idx & 1
     sc, sn = s_regs(par)
-    ks, vs = 1 - par, par
-    P = f"p{par}"
+    vs = par
+    if nk() == 3:
+        ks, kdma, ks_next, ahead = (idx + 1) % 3, idx % 3, (idx + 2) % 3, 3       # K(t + 1) read, K(t + 3) loaded, K(t + 2) read early
+    else:
+        ks, kdma, ks_next, ahead = 1 - par, par, None, 2
+    seed = [("k", f) for f in range(8)] if nk() == 3 else []
+    P = f"p{idx}"
     g.label(f"Lstep{P}")
     g.e("s_waitcnt vmcnt(0)")
     if "bar" not in OPT["ko"].split("+"):
@@ -573,19 +600,21 @@ def gen_step(g, par):
     g.e(f"s_cmp_lt_i32 {s(S_T)}, {s(S_NSTEADY)}")
     g.e(f"s_cbranch_scc0 {g.lref('Lgen' + P)}")
     # ---------------- steady full step: the next tiles' loads ride in the gaps ----------------
+    g.out = list(seed)
     stamp(g, 0)
     if OPT["trace"]:
         g.e(f"s_add_u32 {s(S_TR + 3 + 7)}, {s(S_TR + 3 + 7)}, 1")
-    full_step(g, par, "s" + P, True)
+    full_step(g, par, "s" + P, True, ks, kdma, ks_next)
     stamp(g, 3)
     g.e(f"s_branch {g.lref('Lend' + P)}")
     # ---------------- generic step: loads up front (conditional, partial tiles), then full / last / nothing ----------------
+    g.out = []
     g.label("Lgen" + P)
-    # K(t + 2) -> K slot par, V(t + 1) -> V slot 1 - par
-    g.e(f"s_add_i32 {s(S_TMP)}, {s(S_T)}, 2")
+    # K(t + ahead) -> K slot kdma, V(t + 1) -> V slot 1 - par
+    g.e(f"s_add_i32 {s(S_TMP)}, {s(S_T)}, {ahead}")
     g.e(f"s_cmp_lt_i32 {s(S_TMP)}, {s(S_NT)}")
     g.e(f"s_cbranch_scc0 {g.lref('LnoK' + P)}")
-    dma_tile(g, "k", par, S_TMP, "k" + P)
+    dma_tile(g, "k", kdma, S_TMP, "k" + P)
     g.label("LnoK" + P)
     g.e(f"s_add_i32 {s(S_TMP)}, {s(S_T)}, 1")
     g.e(f"s_cmp_lt_i32 {s(S_TMP)}, {s(S_NT)}")
@@ -597,17 +626,21 @@ def gen_step(g, par):
     g.e(f"s_add_i32 {s(S_TMP)}, {s(S_T)}, 1")
     g.e(f"s_cmp_lt_i32 {s(S_TMP)}, {s(S_NW)}")
     g.e(f"s_cbranch_scc0 {g.lref('Llast' + P)}")
-    full_step(g, par, "g" + P, False)
+    g.out = list(seed)
+    full_step(g, par, "g" + P, False, ks, kdma, ks_next)
     stamp(g, 4)
     g.e(f"s_branch {g.lref('Lend' + P)}")
 
     # ---------------- the wave's last tile: nothing to overlap with ----------------
+    g.out = list(seed)                                       # (K fragments read ahead for a step that does not come: never used)
     g.label("Llast" + P)
     for ins in finish_a(sc)[OPT["early"]:] + finish_chunk(sc, 1, 0, True) + finish_chunk(sc, 1, 1, False) + \
             [f"v_add_f32 {v(V_L + 1)}, {v(V_L + 1)}, {v(V_PS + 1)}"]:
         g.e(ins)
     gl = [[] for _ in range(32)]
     for text, tag in [r for dt in range(4) for r in v_reads(g, 0, dt, vs)]:
+        if len(g.out) >= 14:
+            g.need(g.out[0])
         g.lds(text, tag)
     place(gl, [r for dt in range(4) for r in v_reads(g, 1, dt, vs)], [0, 0, 1, 1, 2, 2, 3, 3])
     for grp in (2, 3):
@@ -628,7 +661,7 @@ def gen_step(g, par):
     g.e(f"s_add_i32 {s(S_T)}, {s(S_T)}, 1")
     g.e(f"s_cmp_lt_i32 {s(S_T)}, {s(S_NT)}")
     g.e(f"s_cbranch_scc0 {g.lref('Lepi')}")
-    if par == 1:
+    if idx == period - 1:
         g.e(f"s_branch {g.lref('Lstepp0')}")
 
 
@@ -649,12 +682,12 @@ def gen_body():
     e(f"s_lshl_b32 {s(S_TMP)}, %[wave], 10")
     e(f"s_add_u32 {s(S_LDSW)}, %[ldsbase], {s(S_TMP)}")
     e(f"s_add_i32 {s(S_LENM1)}, {s(S_LEN)}, -1")
-    # steps 0 .. NSTEADY - 1 are full steps whose next tiles K(t + 2), V(t + 1) exist and are whole: min(nw - 1, ntiles - 2, len / 64 - 2)
+    # steps 0 .. NSTEADY - 1 are full steps whose next tiles K(t + ring), V(t + 1) exist and are whole: min(nw - 1, ntiles - ring, len / 64 - ring)
     e(f"s_add_i32 {s(S_NSTEADY)}, {s(S_NW)}, -1")
-    e(f"s_add_i32 {s(S_TMP)}, {s(S_NT)}, -2")
+    e(f"s_add_i32 {s(S_TMP)}, {s(S_NT)}, {-nk()}")
     e(f"s_min_i32 {s(S_NSTEADY)}, {s(S_NSTEADY)}, {s(S_TMP)}")
     e(f"s_ashr_i32 {s(S_TMP)}, {s(S_LEN)}, 6")
-    e(f"s_add_i32 {s(S_TMP)}, {s(S_TMP)}, -2")
+    e(f"s_add_i32 {s(S_TMP)}, {s(S_TMP)}, {-nk()}")
     e(f"s_min_i32 {s(S_NSTEADY)}, {s(S_NSTEADY)}, {s(S_TMP)}")
     e(f"s_mov_b64 {sr(S_KB0)}, %[kbase]")
     e(f"s_mov_b64 {sr(S_VB0)}, %[vbase]")
@@ -700,6 +733,8 @@ def gen_body():
     for i in range(8):                                # (the relations hold for offsets inside a tile: the LDS base comes last)
         e(f"v_add_u32 {v(V_RA + i)}, %[ldsbase], {v(V_RA + i)}")
         e(f"v_add_u32 {v(V_TR + i)}, %[ldsbase], {v(V_TR + i)}")
+    for i in range(8):
+        e(f"v_add_u32 {v(V_TR + i)}, {v_base()}, {v(V_TR + i)}")
     # ---- Q fragments straight into accumulator registers; O = 0; softmax state ----
     for b, ptr in ((0, V_QA), (1, V_QB)):
         for st in range(8):
@@ -712,6 +747,12 @@ def gen_body():
     e(f"s_mov_b32 {s(S_TMP)}, 1")
     dma_tile(g, "k", 1, S_TMP, "pk1")
     g.label("Lp1")
+    if nk() == 3:
+        e(f"s_cmp_gt_i32 {s(S_NT)}, 2")
+        e(f"s_cbranch_scc0 {g.lref('Lp2')}")
+        e(f"s_mov_b32 {s(S_TMP)}, 2")
+        dma_tile(g, "k", 2, S_TMP, "pk2")
+        g.label("Lp2")
     for i in range(128):
         e(f"v_accvgpr_write_b32 {a(A_O + i)}, 0")
     for b in range(2):
@@ -750,10 +791,15 @@ def gen_body():
     decide_tail(g, "Lkeep0", first_tile=True)
     for ins in finish_a(V_SA)[:OPT["early"]]:
         e(ins)
+    if nk() == 3:
+        for f in range(8):                                   # step 0's first K(1) fragments
+            k_read(g, f, 1)
+        g.out = []
     # ---- tile loop ----
     stamp(g, 5)
-    gen_step(g, 0)
-    gen_step(g, 1)
+    period = 6 if nk() == 3 else 2
+    for idx in range(period):
+        gen_step(g, idx, period)
     # ---- epilogue: O^T / l as bf16.  A lane holds 4 consecutive features of ONE row per register quad, so direct stores are 8 bytes
     # at a 7 KB stride (32 of them per lane: 11-16k cycles of store issue per item, measured).  The tile goes through LDS instead (the
     # K / V rings are free once every wave has passed the barrier below): ds_write_b64 with the 16-byte chunk c of row r at position
@@ -865,6 +911,7 @@ def main():
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_attn_fwd64.py -- do not edit; the per-item body of attn_fwd64_kernel as one inline-asm statement.\n")
         f.write(f"// {len(g.lines)} lines; options {OPT}\n")
+        f.write(f"#define VSEL_FWD64_LDS_BYTES {(nk() + 2) * KBUF}\n")
         f.write("#define VSEL_FWD64_ASM_TEXT \\\n")
         for ln in g.lines:
             f.write(f'  "{ln}\\n\\t" \\\n')

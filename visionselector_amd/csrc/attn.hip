@@ -677,9 +677,12 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
                       (g_attn_split == 1 || (lse == nullptr && (pg.seqlens_k != nullptr || max_seqlen_q >= 256)));
   // ... and 64-query workgroups whose wave pairs split every tile's keys (KH = 2) while those still fit one per CU
   const bool split2_q64 = split2 && g_attn_split_q64 && cdiv(max_seqlen_q, 64) * hq * n_seq <= 256;
-  // 64 rows per wave, one wave per SIMD, hand-scheduled tile loop (attn_fwd64.hip): the large-grid form for head_dim 128
+  // 64 rows per wave, one wave per SIMD, hand-scheduled tile loop (attn_fwd64.hip): head_dim 128 from 2048 tokens in the longest
+  // sequence, whatever the batch (same-process A/B, tools/exp_fwd64_shapes.py, profiles/r04_fwd64_shapes.txt: 1 x 2368 59.8 vs 68.0 us,
+  // 1 x 4096 112 vs 125, 8 x 2048 +15 %, 16 x 4096 +11 %, 2 x 8192 +16 %; 16 x 1100 -2 %, 32 x 524 -20 %: those keep the 4-wave form)
   const int g_rows64 = knob(VSEL_KNOB_ATTN_ROWS64);
-  if (d == 128 && g_attn_use_tr && !pack && !pg.block_table && g_attn_nw == 0 && (g_rows64 == 1 || (g_rows64 < 0 && big && !split2)))
+  if (d == 128 && g_attn_use_tr && !pack && !pg.block_table && g_attn_nw == 0 &&
+      (g_rows64 == 1 || (g_rows64 < 0 && max_seqlen_q >= 2048 && !split2)))
     return attn::attn_fwd64_launch(st, q, k, v, cu_q, n_seq, max_seqlen_q, hq, hkv, scale, causal, out, pg, lse);
   const int block_q = big ? 256 : (split2_q64 ? 64 : 128);
   const int q_tiles = (int)cdiv(max_seqlen_q, block_q);

@@ -40,8 +40,8 @@ V_KMAX = 216                                      # [2]
 V_T = 218                                         # T0..T7 temporaries 218..225
 V_LOK, V_LOV = 226, 230                           # [4] each: per-lane byte offsets of the four slices a wave loads per tile
 V_P8, V_LANE4 = 234, 235                          # part8 * 2 bytes ; lane >> 4
-V_QA, V_QB, V_OA, V_OB = 236, 238, 240, 242       # 64-bit pointers
-V_VALID, V_NEGINF, V_KR = 244, 245, 246           # KR[2] = 246, 247
+V_LANE, V_NEGINF, V_KR = 244, 245, 246            # KR[2] = 246, 247
+V_QLO = 240                                       # [4] per-lane byte offsets of a Q slice by slice phase (the old output pointers' registers)
 V_HH8 = 248
 V_U = 249                                         # U0..U6 more temporaries 249..255
 FIRST_V, LAST_V = 32, 255
@@ -52,14 +52,15 @@ S_KSTEP, S_VSTEP, S_KRS2, S_VRS2 = 52, 53, 54, 55
 S_KB0, S_VB0 = 56, 58
 S_TMP = 60                                        # 60..63
 S_EXEC = 64
-S_VA, S_VB_ = 66, 68                              # valid-row exec masks of blocks A / B
+S_RING, S_QST, S_QRS2 = 66, 67, 68                # LDS base; this wave's Q staging area; Q row stride in bytes
+S_QPTR = 80                                       # 80..81 running Q row pointer
 S_MV = 70                                         # 70..73: "moves" masks of blocks A / B
 S_M0SAVE, S_LENM1 = 74, 75
 S_TMP2 = 76                                       # 76..77
 S_NSTEADY = 78
-S_TR = 80                                         # trace: 80..81 stamp, 82 previous stamp, 83.. accumulators (12)
+S_TR = 84                                         # trace: 84..85 stamp, 86 previous stamp, 87.. accumulators (12)
 N_ACC = 12
-FIRST_S, LAST_S = 40, 95
+FIRST_S, LAST_S = 40, 99                           # (s100 / s101 are reserved: flat_scratch)
 
 KBUF = 16384
 
@@ -349,17 +350,29 @@ def mask_block(g, sx, tile_expr_reg):
                 g.e(f"v_cndmask_b32 {v(reg)}, {v(reg)}, {v(V_NEGINF)}, vcc")
 
 
-def dma_tile(g, tensor, slot, tile_reg, uniq):
+def dma_ctx(tensor):
+    """registers of a tile load: running pointer, 64-row step, per-lane slice offsets, row stride, row-0 pointer, key count, key count - 1,
+    LDS base (+ wave * 1024)"""
+    if tensor == "k":
+        c = dict(ptr=S_KPTR, step=S_KSTEP, lo=V_LOK, rs2=S_KRS2, b0=S_KB0)
+    else:
+        c = dict(ptr=S_VPTR, step=S_VSTEP, lo=V_LOV, rs2=S_VRS2, b0=S_VB0)
+    c.update(len=S_LEN, lenm1=S_LENM1, ldsw=S_LDSW, tensor=tensor)
+    return c
+
+
+def dma_tile(g, tensor, slot, tile_reg, uniq, ctx=None):
     """one 16 KiB tile of K or V into ring slot `slot`: four 1 KiB slices per wave.  tile_reg = SGPR holding the tile index (for the
     partial-tile test).  Advances the running pointer."""
-    ptr, step, lo, rs2, b0 = (S_KPTR, S_KSTEP, V_LOK, S_KRS2, S_KB0) if tensor == "k" else (S_VPTR, S_VSTEP, V_LOV, S_VRS2, S_VB0)
+    c = ctx or dma_ctx(tensor)
+    ptr, step, lo, rs2, b0 = c["ptr"], c["step"], c["lo"], c["rs2"], c["b0"]
     lds0 = (0 if tensor == "k" else v_base()) + slot * KBUF
     g.e(f"s_lshl_b32 {s(S_TMP2)}, {s(tile_reg)}, 6")
     g.e(f"s_add_i32 {s(S_TMP2 + 1)}, {s(S_TMP2)}, 64")
-    g.e(f"s_cmp_gt_i32 {s(S_TMP2 + 1)}, {s(S_LEN)}")
+    g.e(f"s_cmp_gt_i32 {s(S_TMP2 + 1)}, {s(c['len'])}")
     g.e(f"s_cbranch_scc1 {g.lref('Ltail' + uniq)}")
     for u in range(4):
-        g.e(f"s_add_u32 m0, {s(S_LDSW)}, {lds0 + u * 4096}")
+        g.e(f"s_add_u32 m0, {s(c['ldsw'])}, {lds0 + u * 4096}")
         g.e("s_nop 0")
         g.e(f"global_load_lds_dwordx4 {v(lo + u)}, {sr(ptr)}")
     g.e(f"s_branch {g.lref('Ldone' + uniq)}")
@@ -367,10 +380,10 @@ def dma_tile(g, tensor, slot, tile_reg, uniq):
     g.e(f"s_add_i32 {s(S_TMP2)}, {s(S_TMP2)}, {s(S_W4)}")                 # first row of this wave's first slice
     for u in range(4):
         g.e(f"v_add_u32 {v(V_U)}, {s(S_TMP2)}, {v(V_LANE4)}")
-        g.e(f"v_min_i32 {v(V_U)}, {v(V_U)}, {s(S_LENM1)}")
+        g.e(f"v_min_i32 {v(V_U)}, {v(V_U)}, {s(c['lenm1'])}")
         g.e(f"v_mul_lo_u32 {v(V_U)}, {v(V_U)}, {s(rs2)}")
         g.e(f"v_add_u32 {v(V_U)}, {v(V_U)}, {v(V_P8)}")
-        g.e(f"s_add_u32 m0, {s(S_LDSW)}, {lds0 + u * 4096}")
+        g.e(f"s_add_u32 m0, {s(c['ldsw'])}, {lds0 + u * 4096}")
         g.e(f"s_add_i32 {s(S_TMP2)}, {s(S_TMP2)}, 16")
         g.e(f"global_load_lds_dwordx4 {v(V_U)}, {sr(b0)}")
     g.label("Ldone" + uniq)
@@ -408,6 +421,8 @@ OPT = {
     "dmav": "x:9,11,13,15",   # ... and the four V(t + 1) slices
     "pre": 12,            # VALU of the exponentials issued before the first MFMA of phase X (covers the first K reads' latency)
     "vg0": "22,29",       # phase-X gaps over which the first V^T group's reads are spread
+    "qlds": 1,            # Q through LDS: 16 direct-to-LDS loads of whole rows per wave (8 lines each) and 16 ds_read_b128 instead of 16
+                          # per-lane loads at a 7 KB stride (32 lines each); the staging area is the 64 KiB behind the ring
     "kring": 2,           # K ring slots: 3 = K three tiles ahead, so that K(t + 2) has been visible since the PREVIOUS step's barrier and
                           # the first K fragments of a step are read at the end of the step before (LDS latency out of phase X: measured
                           # -80 cycles in X, +110 elsewhere and one more non-steady step per item: 1146 vs 1160 TFLOP/s; not the default)
@@ -679,8 +694,13 @@ def gen_body():
     for dst, name in ((S_NT, "ntiles"), (S_NW, "nw"), (S_MFIRST, "mfirst"), (S_LEN, "len"), (S_C, "c"), (S_KRS2, "krs2"), (S_VRS2, "vrs2")):
         e(f"s_mov_b32 {s(dst)}, %[{name}]")
     e(f"s_lshl_b32 {s(S_W4)}, %[wave], 2")
+    e(f"s_mov_b32 {s(S_RING)}, %[ldsbase]")
     e(f"s_lshl_b32 {s(S_TMP)}, %[wave], 10")
-    e(f"s_add_u32 {s(S_LDSW)}, %[ldsbase], {s(S_TMP)}")
+    e(f"s_add_u32 {s(S_LDSW)}, {s(S_RING)}, {s(S_TMP)}")
+    e(f"s_lshl_b32 {s(S_TMP)}, %[wave], 14")                 # Q staging: 64 KiB behind the ring, 16 KiB per wave
+    e(f"s_add_u32 {s(S_QST)}, {s(S_RING)}, {s(S_TMP)}")
+    e(f"s_add_u32 {s(S_QST)}, {s(S_QST)}, 0x10000")
+    e(f"s_mov_b32 {s(S_QRS2)}, %[qrs2]")
     e(f"s_add_i32 {s(S_LENM1)}, {s(S_LEN)}, -1")
     # steps 0 .. NSTEADY - 1 are full steps whose next tiles K(t + ring), V(t + 1) exist and are whole: min(nw - 1, ntiles - ring, len / 64 - ring)
     e(f"s_add_i32 {s(S_NSTEADY)}, {s(S_NW)}, -1")
@@ -700,12 +720,54 @@ def gen_body():
     e(f"s_addc_u32 {s(S_VPTR + 1)}, {s(S_VB0 + 1)}, 0")
     e(f"s_lshl_b32 {s(S_KSTEP)}, {s(S_KRS2)}, 6")
     e(f"s_lshl_b32 {s(S_VSTEP)}, {s(S_VRS2)}, 6")
-    for dst, name in ((V_QA, "qa"), (V_QB, "qb")):
-        e(f"v_lshl_add_u64 {vr(dst, 2)}, %[{name}], 0, 0")
-    e(f"v_lshrrev_b32 {v(V_LANE4)}, 4, %[lane]")
-    e(f"v_lshrrev_b32 {v(V_HH8)}, 5, %[lane]")
+    # lane-derived constants (attn_common.h: slice_src_part, make_row_addr, make_tr_addr; emulated against them in the generator's
+    # self-check): lane, lane >> 4, 8 * (lane >> 5), the byte offset of this lane's source part in a slice, the first K row-fragment
+    # and V^T fragment offsets
+    T = [V_T + i for i in range(6)]
+    e(f"v_mbcnt_lo_u32_b32 {v(V_LANE)}, -1, 0")
+    e(f"v_mbcnt_hi_u32_b32 {v(V_LANE)}, -1, {v(V_LANE)}")
+    e(f"v_lshrrev_b32 {v(V_LANE4)}, 4, {v(V_LANE)}")
+    e(f"v_lshrrev_b32 {v(V_HH8)}, 5, {v(V_LANE)}")
     e(f"v_lshlrev_b32 {v(V_HH8)}, 3, {v(V_HH8)}")
-    e(f"v_mov_b32 {v(V_P8)}, %[p8]")
+    e(f"s_and_b32 {s(S_TMP)}, %[wave], 3")
+    e(f"v_and_b32 {v(T[0])}, 15, {v(V_LANE)}")
+    e(f"v_lshlrev_b32 {v(T[1])}, 2, {v(V_LANE4)}")
+    e(f"v_or_b32 {v(T[1])}, {s(S_TMP)}, {v(T[1])}")
+    e(f"v_xor_b32 {v(T[0])}, {v(T[0])}, {v(T[1])}")
+    e(f"v_lshlrev_b32 {v(V_P8)}, 4, {v(T[0])}")
+
+    def swz_of(row, dst, tmp):                              # ((row & 3) << 2) | ((row >> 2) & 3)
+        e(f"v_and_b32 {v(dst)}, 3, {v(row)}")
+        e(f"v_lshlrev_b32 {v(dst)}, 2, {v(dst)}")
+        e(f"v_bfe_u32 {v(tmp)}, {v(row)}, 2, 2")
+        e(f"v_or_b32 {v(dst)}, {v(dst)}, {v(tmp)}")
+    # row_addr[0]: row = perm_row(lane & 31), part = (lane >> 5) ^ swz(row)
+    e(f"v_and_b32 {v(T[0])}, 31, {v(V_LANE)}")
+    e(f"v_and_b32 {v(T[1])}, 0x13, {v(T[0])}")
+    e(f"v_and_b32 {v(T[2])}, 4, {v(T[0])}")
+    e(f"v_lshl_or_b32 {v(T[1])}, {v(T[2])}, 1, {v(T[1])}")
+    e(f"v_and_b32 {v(T[2])}, 8, {v(T[0])}")
+    e(f"v_lshrrev_b32 {v(T[2])}, 1, {v(T[2])}")
+    e(f"v_or_b32 {v(T[1])}, {v(T[1])}, {v(T[2])}")
+    swz_of(T[1], T[2], T[3])
+    e(f"v_lshrrev_b32 {v(T[3])}, 5, {v(V_LANE)}")
+    e(f"v_xor_b32 {v(T[3])}, {v(T[3])}, {v(T[2])}")
+    e(f"v_lshlrev_b32 {v(V_RA)}, 8, {v(T[1])}")
+    e(f"v_lshl_or_b32 {v(V_RA)}, {v(T[3])}, 4, {v(V_RA)}")
+    # tr_addr[0][0]: p16 = lane & 15, row = 8 hh + (p16 >> 2), part = (2 ((lane >> 4) & 1) + ((p16 & 3) >> 1)) ^ swz(row), + 8 (p16 & 1)
+    e(f"v_and_b32 {v(T[0])}, 15, {v(V_LANE)}")
+    e(f"v_lshrrev_b32 {v(T[1])}, 2, {v(T[0])}")
+    e(f"v_add_u32 {v(T[1])}, {v(T[1])}, {v(V_HH8)}")
+    swz_of(T[1], T[2], T[3])
+    e(f"v_and_b32 {v(T[3])}, 1, {v(V_LANE4)}")
+    e(f"v_lshlrev_b32 {v(T[3])}, 1, {v(T[3])}")
+    e(f"v_bfe_u32 {v(T[4])}, {v(T[0])}, 1, 1")
+    e(f"v_or_b32 {v(T[3])}, {v(T[3])}, {v(T[4])}")
+    e(f"v_xor_b32 {v(T[3])}, {v(T[3])}, {v(T[2])}")
+    e(f"v_lshlrev_b32 {v(V_TR)}, 8, {v(T[1])}")
+    e(f"v_lshl_or_b32 {v(V_TR)}, {v(T[3])}, 4, {v(V_TR)}")
+    e(f"v_and_b32 {v(T[4])}, 1, {v(T[0])}")
+    e(f"v_lshl_or_b32 {v(V_TR)}, {v(T[4])}, 3, {v(V_TR)}")
     e(f"v_mov_b32 {v(V_KMAX)}, %[kmaxa]")
     e(f"v_mov_b32 {v(V_KMAX + 1)}, %[kmaxb]")
     e(f"v_mov_b32 {v(V_NEGINF)}, 0xff800000")
@@ -721,25 +783,54 @@ def gen_body():
         e(f"v_add_u32 {v(V_LOV + u)}, {v(V_LOV + u - 1)}, {s(S_TMP + 1)}")
     # LDS fragment addresses: row_addr[st] = row_addr[0] ^ (st << 5); tr_addr[dt][0] = tr_addr[0][0] ^ (dt << 6),
     # tr_addr[dt][1] = (tr_addr[dt][0] ^ 16) + 1024   (attn_common.h make_row_addr / make_tr_addr; checked by the C++ side)
-    e(f"v_mov_b32 {v(V_RA)}, %[ra0]")
     for st in range(1, 8):
         e(f"v_xor_b32 {v(V_RA + st)}, {st << 5}, {v(V_RA)}")
-    e(f"v_mov_b32 {v(V_TR)}, %[tr0]")
     for dt in range(1, 4):
         e(f"v_xor_b32 {v(V_TR + 2 * dt)}, {dt << 6}, {v(V_TR)}")
     for dt in range(4):
         e(f"v_xor_b32 {v(V_TR + 2 * dt + 1)}, 16, {v(V_TR + 2 * dt)}")
         e(f"v_add_u32 {v(V_TR + 2 * dt + 1)}, 0x400, {v(V_TR + 2 * dt + 1)}")
     for i in range(8):                                # (the relations hold for offsets inside a tile: the LDS base comes last)
-        e(f"v_add_u32 {v(V_RA + i)}, %[ldsbase], {v(V_RA + i)}")
-        e(f"v_add_u32 {v(V_TR + i)}, %[ldsbase], {v(V_TR + i)}")
+        e(f"v_add_u32 {v(V_RA + i)}, {s(S_RING)}, {v(V_RA + i)}")
+        e(f"v_add_u32 {v(V_TR + i)}, {s(S_RING)}, {v(V_TR + i)}")
     for i in range(8):
         e(f"v_add_u32 {v(V_TR + i)}, {v_base()}, {v(V_TR + i)}")
     # ---- Q fragments straight into accumulator registers; O = 0; softmax state ----
-    for b, ptr in ((0, V_QA), (1, V_QB)):
-        for st in range(8):
-            e(f"global_load_dwordx4 {ar(A_Q + 32 * b + 4 * st, 4)}, {vr(ptr, 2)}, off offset:{32 * st}")
     e(f"s_mov_b32 {s(S_T)}, 0")
+    # Q: 16 slices of 4 whole rows per wave, direct to LDS (row r, 16-byte chunk c at c ^ swz(r), as the K tiles); a wave whose rows
+    # do not all exist clamps the source row per lane (the replayed rows are never stored)
+    e(f"v_mul_lo_u32 {v(V_T)}, {v(V_LANE4)}, {s(S_QRS2)}")
+    e(f"v_and_b32 {v(V_T + 1)}, 15, {v(V_LANE)}")
+    e(f"v_lshlrev_b32 {v(V_T + 2)}, 2, {v(V_LANE4)}")
+    for kq in range(4):
+        e(f"v_or_b32 {v(V_QLO + kq)}, {kq}, {v(V_T + 2)}")
+        e(f"v_xor_b32 {v(V_QLO + kq)}, {v(V_QLO + kq)}, {v(V_T + 1)}")
+        e(f"v_lshl_add_u32 {v(V_QLO + kq)}, {v(V_QLO + kq)}, 4, {v(V_T)}")
+    e(f"s_mov_b64 {sr(S_QPTR)}, %[qbase]")
+    e(f"s_lshl_b32 {s(S_TMP + 1)}, {s(S_QRS2)}, 2")
+    e(f"s_cmp_gt_i32 %[nvalid], 63")
+    e(f"s_cbranch_scc0 {g.lref('Lqpart')}")
+    for i in range(16):
+        e(f"s_add_u32 m0, {s(S_QST)}, {1024 * i}")
+        e("s_nop 0")
+        e(f"global_load_lds_dwordx4 {v(V_QLO + (i & 3))}, {sr(S_QPTR)}")
+        e(f"s_add_u32 {s(S_QPTR)}, {s(S_QPTR)}, {s(S_TMP + 1)}")
+        e(f"s_addc_u32 {s(S_QPTR + 1)}, {s(S_QPTR + 1)}, 0")
+    e(f"s_branch {g.lref('Lqdone')}")
+    g.label("Lqpart")
+    e(f"s_cmp_gt_i32 %[nvalid], 0")
+    e(f"s_cbranch_scc0 {g.lref('Lqdone')}")
+    e(f"s_add_i32 {s(S_TMP2)}, %[nvalid], -1")
+    for i in range(16):
+        e(f"v_add_u32 {v(V_U)}, {4 * i}, {v(V_LANE4)}")
+        e(f"v_min_i32 {v(V_U)}, {v(V_U)}, {s(S_TMP2)}")
+        e(f"v_mul_lo_u32 {v(V_U)}, {v(V_U)}, {s(S_QRS2)}")
+        e(f"v_sub_u32 {v(V_U + 1)}, {v(V_QLO + (i & 3))}, {v(V_T)}")          # the chunk term of this slice phase
+        e(f"v_add_u32 {v(V_U)}, {v(V_U)}, {v(V_U + 1)}")
+        e(f"s_add_u32 m0, {s(S_QST)}, {1024 * i}")
+        e("s_nop 0")
+        e(f"global_load_lds_dwordx4 {v(V_U)}, {sr(S_QPTR)}")
+    g.label("Lqdone")
     dma_tile(g, "k", 0, S_T, "pk0")
     dma_tile(g, "v", 0, S_T, "pv0")
     e(f"s_cmp_gt_i32 {s(S_NT)}, 1")
@@ -747,12 +838,6 @@ def gen_body():
     e(f"s_mov_b32 {s(S_TMP)}, 1")
     dma_tile(g, "k", 1, S_TMP, "pk1")
     g.label("Lp1")
-    if nk() == 3:
-        e(f"s_cmp_gt_i32 {s(S_NT)}, 2")
-        e(f"s_cbranch_scc0 {g.lref('Lp2')}")
-        e(f"s_mov_b32 {s(S_TMP)}, 2")
-        dma_tile(g, "k", 2, S_TMP, "pk2")
-        g.label("Lp2")
     for i in range(128):
         e(f"v_accvgpr_write_b32 {a(A_O + i)}, 0")
     for b in range(2):
@@ -764,6 +849,26 @@ def gen_body():
     stamp(g, 9)
     e(f"s_cmp_gt_i32 {s(S_NW)}, 0")
     e(f"s_cbranch_scc0 {g.lref('Lstepp0')}")
+    # ---- Q^T fragments out of the staging area: lane (j, hh) takes chunk 2 st + hh of rows j and 32 + j ----
+    QR = [V_T + i for i in range(8)]
+    e(f"v_and_b32 {v(V_U)}, 31, {v(V_LANE)}")                          # j
+    e(f"v_and_b32 {v(V_U + 1)}, 3, {v(V_U)}")
+    e(f"v_lshlrev_b32 {v(V_U + 1)}, 2, {v(V_U + 1)}")
+    e(f"v_bfe_u32 {v(V_U + 2)}, {v(V_U)}, 2, 2")
+    e(f"v_or_b32 {v(V_U + 1)}, {v(V_U + 1)}, {v(V_U + 2)}")            # swz(j)
+    e(f"v_lshrrev_b32 {v(V_U + 2)}, 5, {v(V_LANE)}")
+    e(f"v_xor_b32 {v(V_U + 1)}, {v(V_U + 1)}, {v(V_U + 2)}")           # hh ^ swz(j)
+    e(f"v_lshlrev_b32 {v(V_U)}, 8, {v(V_U)}")
+    e(f"v_lshl_or_b32 {v(V_U)}, {v(V_U + 1)}, 4, {v(V_U)}")
+    e(f"v_add_u32 {v(QR[0])}, {s(S_QST)}, {v(V_U)}")                    # (the staging base is a multiple of 256: the XOR below commutes)
+    for st in range(1, 8):
+        e(f"v_xor_b32 {v(QR[st])}, {st << 5}, {v(QR[0])}")
+    n = 0
+    for b in range(2):
+        for st in range(8):
+            g.lds(f"ds_read_b128 {ar(A_Q + 32 * b + 4 * st, 4)}, {v(QR[st])} offset:{8192 * b}", ("q", n))
+            n += 1
+        g.need(("q", 8 * b + 1))
     # ---- S(0) without overlap, mask, maxima, first reference exponents ----
     for f in range(8):
         k_read(g, f, 0)
@@ -834,15 +939,15 @@ def gen_body():
     # this wave's 16 KiB of LDS: base + wave * 16384 (base is a multiple of 1024: the XOR below commutes with the add)
     WA, RD, AD = V_T, V_T + 1, V_T + 2
     e(f"s_lshl_b32 {s(S_TMP)}, %[wave], 14")
-    e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, %[ldsbase]")
-    e(f"v_and_b32 {v(WA)}, 31, %[lane]")
+    e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, {s(S_RING)}")
+    e(f"v_and_b32 {v(WA)}, 31, {v(V_LANE)}")
     e(f"v_lshlrev_b32 {v(WA)}, 8, {v(WA)}")                         # row * 256
     e(f"v_add_u32 {v(WA)}, {v(WA)}, {v(V_HH8)}")                     # + 8 hh
-    e(f"v_and_b32 {v(AD)}, 15, %[lane]")
+    e(f"v_and_b32 {v(AD)}, 15, {v(V_LANE)}")
     e(f"v_lshlrev_b32 {v(AD)}, 4, {v(AD)}")                          # (row & 15) << 4
     e(f"v_xor_b32 {v(WA)}, {v(WA)}, {v(AD)}")
     e(f"v_add_u32 {v(WA)}, {s(S_TMP)}, {v(WA)}")
-    e(f"v_lshlrev_b32 {v(RD)}, 4, %[lane]")
+    e(f"v_lshlrev_b32 {v(RD)}, 4, {v(V_LANE)}")
     e(f"v_add_u32 {v(RD)}, {s(S_TMP)}, {v(RD)}")
     tmp = [V_U + 3 + i for i in range(4)]                         # (64-bit VGPR operands must start at an even register)
     assert tmp[0] % 2 == 0 and tmp[3] <= LAST_V
@@ -861,7 +966,7 @@ def gen_body():
     e("s_waitcnt lgkmcnt(0)")
     # global offsets of the four row phases: (lane >> 4) * row stride + 16 * ((lane & 15) ^ (4 k + (lane >> 4)))
     VO = [V_KR, V_KR + 1, V_MX, V_MX + 1]
-    e(f"v_and_b32 {v(AD)}, 15, %[lane]")
+    e(f"v_and_b32 {v(AD)}, 15, {v(V_LANE)}")
     e(f"v_mul_lo_u32 {v(WA)}, {v(V_LANE4)}, %[ostride]")
     for k in range(4):
         e(f"v_add_u32 {v(VO[k])}, {4 * k}, {v(V_LANE4)}")
@@ -911,7 +1016,7 @@ def main():
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_attn_fwd64.py -- do not edit; the per-item body of attn_fwd64_kernel as one inline-asm statement.\n")
         f.write(f"// {len(g.lines)} lines; options {OPT}\n")
-        f.write(f"#define VSEL_FWD64_LDS_BYTES {(nk() + 2) * KBUF}\n")
+        f.write(f"#define VSEL_FWD64_LDS_BYTES {2 * 65536}\n")
         f.write("#define VSEL_FWD64_ASM_TEXT \\\n")
         for ln in g.lines:
             f.write(f'  "{ln}\\n\\t" \\\n')

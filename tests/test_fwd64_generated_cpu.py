@@ -1,0 +1,43 @@
+"""The per-item body of attn_fwd64_kernel is GENERATED (tools/gen_attn_fwd64.py -> csrc/attn_fwd64_body.inc).  The committed file
+must be what the committed generator writes with its default options, and the generator's own consistency checks (counted LDS
+waits, register pipelines) must hold for the option sets the tools build."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN = os.path.join(ROOT, "tools", "gen_attn_fwd64.py")
+INC = os.path.join(ROOT, "visionselector_amd", "csrc", "attn_fwd64_body.inc")
+
+
+def _gen(tmp_path, opts=""):
+    out = tmp_path / "body.inc"
+    env = dict(os.environ, F64_OUT=str(out), F64_OPTS=opts)
+    subprocess.check_call([sys.executable, GEN], env=env, stdout=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def test_committed_body_is_the_generators_output(tmp_path):
+    assert _gen(tmp_path) == open(INC).read(), "run `python tools/gen_attn_fwd64.py` and commit csrc/attn_fwd64_body.inc"
+
+
+@pytest.mark.parametrize("opts", ["move_chunk=0", "pvsplit=1", "wgrp=0,srot=0", "dmak=top,dmav=top,pre=0", "trace=1",
+                                  "early=57", "ko=fin+max+lds+dma"])
+def test_generator_option_sets_are_consistent(tmp_path, opts):
+    text = _gen(tmp_path, opts)
+    assert text.count("v_mfma_f32_32x32x16_bf16") >= 352       # prologue S(0) + two steady, two generic, two last-tile step bodies
+
+
+def test_body_register_budget():
+    """every register the body names is inside the clobber list it declares (the compiler keeps v0..v31 and the low SGPRs)"""
+    import re
+    text = open(INC).read()
+    body, clob = text.split("#define VSEL_FWD64_ASM_CLOBBERS")
+    declared = set(re.findall(r'"([vas]\d+)"', clob))
+    used = set()
+    for kind, lo, hi in re.findall(r"\b([vas])\[(\d+):(\d+)\]", body):
+        used.update(f"{kind}{i}" for i in range(int(lo), int(hi) + 1))
+    used.update(re.findall(r"(?<![\w%\[])([vas]\d+)\b", body))
+    assert used <= declared, sorted(used - declared)[:10]

@@ -682,6 +682,7 @@ def gen_step(g, idx, period):
 
 def gen_body():
     rescale_selfcheck()
+    assert nk() == 2, "kring = 3 (measured slower) predates the Q staging area at +64 KiB: its five tiles would overlap it"
     g = Gen()
     e = g.e
     # ---- inputs into the fixed registers ----

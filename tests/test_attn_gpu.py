@@ -451,3 +451,24 @@ def test_rows64_is_the_default_for_large_grids(ops):
     with N.debug_knob(attn_rows64=0):
         b = ops.varlen_attn(q, k, v, cu, L)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("b,hq,hkv,lq,lk,causal", [(2, 8, 2, 300, 300, True), (1, 4, 4, 2368, 2368, True), (2, 4, 2, 70, 700, True),
+                                                    (2, 4, 2, 257, 257, False)])
+def test_rows64_forward_on_head_major_strided_tensors(ops, b, hq, hkv, lq, lk, causal):
+    """HuggingFace-layout tensors [B, H, L, d] (row stride d, head stride L d; V as a transposed view with its own strides) through the
+    64-rows-per-wave form: its Q rows come by whole-row direct-to-LDS loads at the caller's row stride -- bit-identical to the other
+    forms on the same strided tensors."""
+    from visionselector_amd import _native as N
+    rng = np.random.default_rng(3 * b + lq)
+    f = lambda *sh: torch.from_numpy(rng.standard_normal(sh, dtype=np.float32)).bfloat16().cuda()  # noqa: E731
+    q, k = f(b, hq, lq, 128), f(b, hkv, lk, 128)
+    v = f(b, lk, hkv, 128).transpose(1, 2)                 # a view: row stride Hkv d, head stride d
+    outs = []
+    for r64 in (0, 1):
+        with N.debug_knob(attn_rows64=r64, attn_split=0, attn_pack=0):
+            N.profile_start()
+            outs.append(ops.attn_head_major(q, k, v, causal=causal))
+            prof = N.profile_stop()
+            assert ("attn_fwd64_kernel" in prof) == bool(r64), prof
+    assert torch.equal(outs[0], outs[1])

@@ -927,6 +927,14 @@ extern "C" int vsel_debug_read_bwd_trace(unsigned long long* out) {
 static constexpr int64_t kSplitBelowItems = 288;
 // knob VSEL_KNOB_ATTN_BWD_SPLIT (include/vsel_debug.h): -1 = choose by item count, 0 / 1 = force (tests)
 
+namespace vsel { namespace bwd {
+int dq64_launch(hipStream_t st, const void* q, const void* k, const void* v, const void* dout, const void* out, const float* lse,
+                float* dvec, float* lse2, const int32_t* cu, int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv, float scale,
+                int causal, void* dq, int xcd_local);          // attn_bwd_dq64.hip
+} }
+
+constexpr int64_t kDq64FromTokens = 0;       // (0 = only when forced by the knob, until measured)
+
 static bool bwd_use_split(int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv) {
   if (hq == hkv) return false;
   const int forced = knob(VSEL_KNOB_ATTN_BWD_SPLIT);
@@ -980,7 +988,13 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
   const int xcd_local_dq = attn_use_xcd_queues(max_seqlen, n_seq * hkv, 2048, 32);
   const int xcd_local_dkdv = attn_use_xcd_queues(max_seqlen, n_seq * hkv, 4096, 16);
   // dQ first: it also leaves D = rowsum(dO * O) and the exp2-domain log-sum-exp in the workspace for the dK / dV kernel
-  {
+  const int g_dq64 = knob(VSEL_KNOB_ATTN_BWD_DQ64);
+  if (g_dq64 == 1 || (g_dq64 < 0 && kDq64FromTokens > 0 && max_seqlen >= kDq64FromTokens)) {
+    // long sequences: 64 query rows per wave, one wave per SIMD, hand-scheduled unit pipeline (attn_bwd_dq64.hip); same dQ / D / lse2
+    if (int rc = bwd::dq64_launch(st, q, k, v, dout, out, lse, dvec, lse2, cu_seqlens, n_seq, max_seqlen, hq, hkv, scale, causal, dq,
+                                  xcd_local_dq))
+      return rc;
+  } else {
     const int q_tiles = (int)cdiv(max_seqlen, 128);
     const int64_t n_items = (int64_t)q_tiles * hq * n_seq;
     if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");

@@ -239,3 +239,33 @@ def test_kernels_match_reference_eager_attention_golden(ops, golden_dir, name):
     assert _rel(dq, g["dq"].astype(np.float64)) <= 2 ** -6
     assert _rel(dk, g["dk"].astype(np.float64)) <= 2 ** -6
     assert _rel(dv, g["dv"].astype(np.float64)) <= 2 ** -6
+
+
+# ---- dQ pass with 64 query rows per wave (csrc/attn_bwd_dq64.hip, knob attn_bwd_dq64) ---------------------------------------------
+@pytest.mark.parametrize("lens,hq,hkv", [([1], 2, 1), ([64], 4, 4), ([65], 4, 2), ([256], 4, 4), ([257], 4, 1), ([300, 129, 64], 4, 2),
+                                         ([37, 700, 256, 129], 28, 4), ([1230], 32, 8), ([2368], 4, 4)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_dq64_pass_is_bit_identical_to_the_reference_dq_kernel(lens, hq, hkv, causal):
+    """The hand-scheduled 64-rows-per-wave dQ pass performs, per query row, the operations of attn_bwd_dq_kernel in the same order:
+    dQ is bit-identical, and so are dK / dV, which consume the D = rowsum(dO o O) and lse * log2(e) it leaves in the workspace.
+    (The oracle parity of these gradients is test_backward_matches_oracle's; this is the form-vs-form gate.)  Ragged lengths
+    exercise partial query tiles aligned to the END of each sequence, partial key tiles, waves without rows and diagonal masks."""
+    import torch
+    from visionselector_amd import _native as N, ops
+    g = torch.Generator(device="cuda").manual_seed(17 + len(lens))
+    T = sum(lens)
+    q = torch.randn(T, hq, 128, device="cuda", generator=g).bfloat16()
+    k = torch.randn(T, hkv, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(T, hkv, 128, device="cuda", generator=g).bfloat16()
+    do = torch.randn(T, hq, 128, device="cuda", generator=g).bfloat16()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
+    out, lse = ops.varlen_attn_fwd_lse(q, k, v, cu, max(lens), causal=causal)
+    res = []
+    for dq64 in (0, 1):
+        with N.debug_knob(attn_bwd_dq64=dq64):
+            N.profile_start()
+            res.append(ops.varlen_attn_bwd(do, q, k, v, out, lse, cu, max(lens), causal=causal))
+            prof = N.profile_stop()
+            assert ("attn_bwd_dq64_kernel" in prof) == bool(dq64), prof
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

@@ -491,33 +491,41 @@ def gen_body():
             if len(g.out) >= 12:
                 g.need(g.out[3])
     g.drain()
-    # ---- round 2: O -> staging area (Q has been read) ----
+    # ---- round 2: O -> staging area (Q has been read); and, once EVERY wave has read its dO rows out of the ring, the first K / V tiles:
+    # issued behind O, so that the counted wait below leaves them in flight under the D arithmetic ----
     row_dma(g, "obase", S_QST, "o")
-    e("s_waitcnt vmcnt(0)")
-    # D = sum_d dO O of this lane's rows: the lane's 64 features in the order of attn_bwd_dq_kernel (k-step, dword, low half then high),
-    # then the two lane halves (hh = 0: own + other; hh = 1: other + own)
-    for b in range(2):
-        DOV, OV = V_S, V_DP                                  # 32 registers each: eight 16-byte chunks
+    # D's second operand: dO once more, into VGPRs this time (block A now, block B below) -- read BEFORE the ring is overwritten
+    DOV, OV = V_S, V_DP                                      # 32 registers each: eight 16-byte chunks
+    DOV2 = V_KV                                              # block B's dO chunks wait in the K / V / K^T fragment registers (32)
+    for b, dst in ((0, DOV), (1, DOV2)):
         for st in range(8):
             e(f"v_add_u32 {v(V_T + 1)}, {s(S_RST)}, {v(QR[st])}")
-            g.lds(f"ds_read_b128 {vr(DOV + 4 * st, 4)}, {v(V_T + 1)} offset:{8192 * b}", ("dv", st))
-            e(f"v_add_u32 {v(V_T + 2)}, {s(S_QST)}, {v(QR[st])}")
-            g.lds(f"ds_read_b128 {vr(OV + 4 * st, 4)}, {v(V_T + 2)} offset:{8192 * b}", ("ov", st))
+            g.lds(f"ds_read_b128 {vr(dst + 4 * st, 4)}, {v(V_T + 1)} offset:{8192 * b}", ("dv", b, st))
             if len(g.out) >= 12:
                 g.need(g.out[3])
+    g.drain()
+    e("s_barrier")                                           # ... by every wave: now the ring belongs to K / V
+    dma_tile(g, "k", 0, S_T, "pk0")
+    dma_tile(g, "v", 0, S_T, "pv0")
+    e("s_waitcnt vmcnt(8)")                                  # the sixteen O slices have landed; K(0) / V(0) stay in flight
+    # D = sum_d dO O of this lane's rows: the lane's 64 features in the order of attn_bwd_dq_kernel (k-step, dword, low half then high),
+    # then the two lane halves (hh = 0: own + other; hh = 1: other + own)
+    for b, dreg0 in ((0, DOV), (1, DOV2)):
+        for st in range(8):
+            e(f"v_add_u32 {v(V_T + 2)}, {s(S_QST)}, {v(QR[st])}")
+            g.lds(f"ds_read_b128 {vr(OV + 4 * st, 4)}, {v(V_T + 2)} offset:{8192 * b}", ("ov", b, st))
         g.drain()
         acc = V_DSUM + b
         e(f"v_mov_b32 {v(acc)}, 0")
         for st in range(8):
             for i in range(4):
-                dreg, oreg = DOV + 4 * st + i, OV + 4 * st + i
+                dreg, oreg = dreg0 + 4 * st + i, OV + 4 * st + i
                 e(f"v_lshlrev_b32 {v(V_T + 1)}, 16, {v(dreg)}")
                 e(f"v_lshlrev_b32 {v(V_T + 2)}, 16, {v(oreg)}")
                 e(f"v_and_b32 {v(V_T + 3)}, 0xffff0000, {v(dreg)}")
                 e(f"v_and_b32 {v(V_T + 4)}, 0xffff0000, {v(oreg)}")
                 e(f"v_fma_f32 {v(acc)}, {v(V_T + 1)}, {v(V_T + 2)}, {v(acc)}")
                 e(f"v_fma_f32 {v(acc)}, {v(V_T + 3)}, {v(V_T + 4)}, {v(acc)}")
-        # other half's partial
         e(f"v_mov_b32 {v(V_T + 1)}, {v(acc)}")
         e(f"v_mov_b32 {v(V_T + 2)}, {v(acc)}")
         e("s_nop 1")
@@ -533,10 +541,6 @@ def gen_body():
         e(f"global_store_dword {v(V_X + b)}, {v(V_DSUM + b)}, %[dvecbase]")
         e(f"global_store_dword {v(V_X + b)}, {v(V_LSE2 + b)}, %[lse2base]")
         e(f"s_mov_b64 exec, {sr(S_EXEC)}")
-    # ---- the ring is free for K / V once every wave has read its dO rows ----
-    e("s_barrier")
-    dma_tile(g, "k", 0, S_T, "pk0")
-    dma_tile(g, "v", 0, S_T, "pv0")
     # ---- tile loop ----
     gen_step(g, 0)
     gen_step(g, 1)

@@ -47,7 +47,8 @@ typedef enum vsel_debug_knob {
                                      tile loop; csrc/attn_fwd64.hip): -1 from 2048 tokens in the longest sequence (default), 0 never,
                                      1 whenever it applies (contiguous keys); env VSEL_ATTN_ROWS64; bit-identical outputs */
   VSEL_KNOB_ATTN_BWD_DQ64 = 15,   /* dQ pass of the attention backward by the 64-rows-per-wave kernel (csrc/attn_bwd_dq64.hip, generated body):
-                                     -1 by sequence length (default), 0 never, 1 always; env VSEL_ATTN_BWD_DQ64; dQ / D / lse2 bit-identical */
+                                     -1 from 2048 tokens in the longest sequence (default), 0 never, 1 always; env VSEL_ATTN_BWD_DQ64; dQ / D / lse2
+                                     bit-identical */
   VSEL_KNOB_COUNT = 16
 } vsel_debug_knob;
 

@@ -59,10 +59,15 @@ S_QPTR = 80                                       # 80..81
 FIRST_S, LAST_S = 40, 87
 
 KBUF = 16384
-OPT = {"dma": "1,3,5,7,9,11,13,15"}              # gaps of a steady step's first SdP batch that carry the next tile's eight slices
+OPT = {
+    "dma": "1,3,5,7,9,11,13,15",                  # gaps of a steady step's first SdP batch that carry the next tile's eight slices
+    "split": "18",                                # VALU of a unit issued beside the dQ batch right behind its SdP; the rest beside the next SdP batch
+    "ko": "",                                     # knock-outs (timing only, WRONG results): valu, lds, dma, mfma joined by "+"
+}
 for kv in os.environ.get("DQ64_OPTS", "").split(","):
     if "=" in kv:
         key, val = kv.split("=", 1)
+        assert key in OPT, key
         OPT[key] = val.replace("/", ",")
 
 
@@ -181,12 +186,27 @@ def dma_pieces(tensor, slot):
     return pieces, adv
 
 
+KO = set(OPT["ko"].split("+")) - {""}
+
+
 def emit_batch(g, n, mfma_fn, gaps):
     for i in range(n):
-        mfma_fn(i)
+        if "mfma" in KO:
+            mark = len(g.lines)
+            mfma_fn(i)
+            g.lines[mark:] = [ln for ln in g.lines[mark:] if not ln.startswith("v_mfma")]
+        else:
+            mfma_fn(i)
         for ins in gaps[i]:
             if isinstance(ins, tuple):
-                g.lds(ins[0], ins[1])
+                if "lds" in KO:
+                    g.done.add(ins[1])
+                else:
+                    g.lds(ins[0], ins[1])
+            elif "valu" in KO and ins.split()[0] in ("v_fma_f32", "v_sub_f32", "v_exp_f32", "v_mul_f32", "v_cvt_pk_bf16_f32"):
+                pass
+            elif "dma" in KO and (ins.startswith("global_load_lds") or ins.startswith("s_add_u32 m0")):
+                pass
             else:
                 g.e(ins)
 
@@ -204,7 +224,7 @@ def second_reads(kb, ks):
     return out
 
 
-VALU_SPLIT = 18                                   # VALU of a unit issued in the 8-MFMA dQ batch right behind its SdP (gaps 3..7); the rest in the next SdP batch
+VALU_SPLIT = int(OPT["split"])
 
 
 def step_body(g, par, tag, has_prev, steady):

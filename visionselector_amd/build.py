@@ -25,7 +25,8 @@ def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(PKG_DIR), "include", "vsel.h")]
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + \
+        [os.path.join(os.path.dirname(PKG_DIR), "include", "vsel.h")]          # (*.inc: the generated kernel bodies)
     return any(os.path.getmtime(p) > t for p in deps)
 
 
@@ -88,7 +89,7 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(build_dir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
-                os.path.getmtime(p) for p in [src] + glob.glob(os.path.join(CSRC, "*.h"))
+                os.path.getmtime(p) for p in [src] + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc"))
                 + [os.path.join(os.path.dirname(PKG_DIR), "include", "vsel.h")]):
             continue
         checked = any(os.path.basename(src) == s_ for s_, _ in ASM_READ_KERNELS)

@@ -931,11 +931,15 @@ namespace vsel { namespace bwd {
 int dq64_launch(hipStream_t st, const void* q, const void* k, const void* v, const void* dout, const void* out, const float* lse,
                 float* dvec, float* lse2, const int32_t* cu, int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv, float scale,
                 int causal, void* dq, int xcd_local);          // attn_bwd_dq64.hip
+int dkdv64_launch(hipStream_t st, const void* q, const void* k, const void* v, const void* dout, const float* lse2, const float* dvec,
+                  const int32_t* cu, int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv, float scale, int causal, void* dk, void* dv,
+                  int xcd_local);                              // attn_bwd_dkdv64.hip
 } }
 
 // the 64-rows-per-wave dQ pass from this many tokens in the longest sequence (same-process A/B, tools/exp_dq64_shapes.py,
 // profiles/r04_dq64_shapes.txt: 1 x 2368 +5 %, 16 x 2368 +12 %, 1 x 4096 +17 %, 16 x 4096 +17 %, 2 x 8192 +17 %; 16 x 1100 -1 %, 32 x 524 -13 %)
 constexpr int64_t kDq64FromTokens = 2048;
+constexpr int64_t kDkdv64FromTokens = 0;     // (0 = only when forced by the knob, until measured)
 
 static bool bwd_use_split(int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv) {
   if (hq == hkv) return false;
@@ -1007,6 +1011,11 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
                        cu_seqlens,
                        (int)hq, (int)hkv, scale, causal, (uint16_t*)dq, q_tiles, (int)n_seq, slot, xcd_local_dq);
     VSEL_AFTER_LAUNCH(st, "attn_bwd_dq_kernel");
+  }
+  const int g_dkdv64 = knob(VSEL_KNOB_ATTN_BWD_DKDV64);
+  if (!bwd_use_split(n_seq, max_seqlen, hq, hkv) &&
+      (g_dkdv64 == 1 || (g_dkdv64 < 0 && kDkdv64FromTokens > 0 && max_seqlen >= kDkdv64FromTokens))) {
+    return bwd::dkdv64_launch(st, q, k, v, dout, lse2, dvec, cu_seqlens, n_seq, max_seqlen, hq, hkv, scale, causal, dk, dv, xcd_local_dkdv);
   }
   {
     const bool split = bwd_use_split(n_seq, max_seqlen, hq, hkv);

@@ -46,6 +46,7 @@ constexpr KnobSpec kKnobs[VSEL_KNOB_COUNT] = {
     {"VSEL_ATTN_XCD_QUEUE", -1, -1, 1},  // VSEL_KNOB_ATTN_XCD_QUEUE
     {"VSEL_ATTN_ROWS64", -1, -1, 1},     // VSEL_KNOB_ATTN_ROWS64
     {"VSEL_ATTN_BWD_DQ64", -1, -1, 1},   // VSEL_KNOB_ATTN_BWD_DQ64
+    {"VSEL_ATTN_BWD_DKDV64", -1, -1, 1}, // VSEL_KNOB_ATTN_BWD_DKDV64
 };
 int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 int knob_default(int id) {

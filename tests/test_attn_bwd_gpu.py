@@ -269,3 +269,64 @@ def test_dq64_pass_is_bit_identical_to_the_reference_dq_kernel(lens, hq, hkv, ca
             assert ("attn_bwd_dq64_kernel" in prof) == bool(dq64), prof
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+# ---- dK / dV pass, one wave per SIMD with the unit pipeline (csrc/attn_bwd_dkdv64.hip, knob attn_bwd_dkdv64) -----------------------
+@pytest.mark.parametrize("lens,hq,hkv", [([1], 2, 1), ([64], 4, 4), ([65], 4, 2), ([129], 2, 2), ([193], 4, 1), ([256], 4, 4),
+                                         ([300, 129, 64], 4, 2), ([37, 700, 256, 129], 28, 4), ([1230], 32, 8), ([2368], 4, 4)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_dkdv64_pass_is_bit_identical_to_the_four_wave_dkdv_kernel(lens, hq, hkv, causal):
+    """The hand-scheduled dK / dV pass keeps the four-wave kernel's work split (wave w owns keys 32 w .. 32 w + 31 of a 128-key item,
+    the group's q heads looped inside) and its summation order over query tiles: dK and dV are bit-identical to that form's.  (Oracle
+    parity of the gradients is test_backward_matches_oracle's; this is the form-vs-form gate.)  Lengths with remainders 1 / 65 / 129
+    exercise the clamped tile loads (one valid row), partial key blocks, key blocks above the diagonal and the two-sided mask."""
+    import torch
+    from visionselector_amd import _native as N, ops
+    g = torch.Generator(device="cuda").manual_seed(23 + len(lens))
+    T = sum(lens)
+    q = torch.randn(T, hq, 128, device="cuda", generator=g).bfloat16()
+    k = torch.randn(T, hkv, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(T, hkv, 128, device="cuda", generator=g).bfloat16()
+    do = torch.randn(T, hq, 128, device="cuda", generator=g).bfloat16()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
+    out, lse = ops.varlen_attn_fwd_lse(q, k, v, cu, max(lens), causal=causal)
+    res = []
+    for dkdv64 in (0, 1):
+        with N.debug_knob(attn_bwd_dkdv64=dkdv64, attn_bwd_waves=4, attn_bwd_split=0):
+            N.profile_start()
+            res.append(ops.varlen_attn_bwd(do, q, k, v, out, lse, cu, max(lens), causal=causal))
+            prof = N.profile_stop()
+            assert ("attn_bwd_dkdv64_kernel" in prof) == bool(dkdv64), prof
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+def test_long_sequences_take_the_64_row_passes_by_default_and_match_the_oracle_bound():
+    """From 2048 tokens in the longest sequence the library picks attn_bwd_dq64_kernel and (outside the few-item split form)
+    attn_bwd_dkdv64_kernel by itself; gradients against the fp64 eager formula on the bf16-rounded inputs, at the backward test's bound."""
+    import torch
+    from visionselector_amd import _native as N, ops
+    lens, hq, hkv = [2100, 700], 4, 4
+    g = torch.Generator(device="cuda").manual_seed(5)
+    T = sum(lens)
+    q = torch.randn(T, hq, 128, device="cuda", generator=g).bfloat16()
+    k = torch.randn(T, hkv, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(T, hkv, 128, device="cuda", generator=g).bfloat16()
+    do = torch.randn(T, hq, 128, device="cuda", generator=g).bfloat16()
+    cu = torch.tensor([0, lens[0], T], dtype=torch.int32, device="cuda")
+    out, lse = ops.varlen_attn_fwd_lse(q, k, v, cu, max(lens))
+    N.profile_start()
+    dq, dk, dv = ops.varlen_attn_bwd(do, q, k, v, out, lse, cu, max(lens))
+    prof = N.profile_stop()
+    assert "attn_bwd_dq64_kernel" in prof and "attn_bwd_dkdv64_kernel" in prof, prof
+    o = 0
+    for L in lens:
+        sl = slice(o, o + L)
+        qq, kk, vv = (t[sl].double().transpose(0, 1).requires_grad_(True) for t in (q, k, v))
+        s = qq @ kk.transpose(1, 2) / 128 ** 0.5
+        s = s.masked_fill(torch.ones(L, L, device="cuda", dtype=torch.bool).triu(1), float("-inf"))
+        (torch.softmax(s, -1) @ vv).backward(do[sl].double().transpose(0, 1))
+        for got, ref in ((dq, qq.grad), (dk, kk.grad), (dv, vv.grad)):
+            ref = ref.transpose(0, 1)
+            assert ((got[sl].double() - ref).abs().max() / ref.abs().max()).item() <= 2 ** -6
+        o += L

@@ -939,7 +939,7 @@ int dkdv64_launch(hipStream_t st, const void* q, const void* k, const void* v, c
 // the 64-rows-per-wave dQ pass from this many tokens in the longest sequence (same-process A/B, tools/exp_dq64_shapes.py,
 // profiles/r04_dq64_shapes.txt: 1 x 2368 +5 %, 16 x 2368 +12 %, 1 x 4096 +17 %, 16 x 4096 +17 %, 2 x 8192 +17 %; 16 x 1100 -1 %, 32 x 524 -13 %)
 constexpr int64_t kDq64FromTokens = 2048;
-constexpr int64_t kDkdv64FromTokens = 0;     // (0 = only when forced by the knob, until measured)
+constexpr int64_t kDkdv64FromTokens = 2048;  // (profiles/r04_dkdv64_shapes.txt: +15 ... +18 % from 2368 tokens, level at 1100, behind at 524)
 
 static bool bwd_use_split(int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv) {
   if (hq == hkv) return false;

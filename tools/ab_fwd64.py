@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Same-box A/B of schedule variants of the 64-rows-per-wave attention kernels (generator options of tools/gen_attn_fwd64.py, or of
-tools/gen_attn_bwd_dq64.py with --dq64).
+tools/gen_attn_bwd_dq64.py with --dq64, of tools/gen_attn_bwd_dkdv64.py with --dkdv64).
 
-    python tools/ab_fwd64.py build [--dq64] name1:key=val,key=val name2:...   # here (no GPU): one libvsel_<name>.so per option set
-    python tools/ab_fwd64.py run [--dq64] [rounds] [--shapes 16x4096,4x8192]  # on the GPU box: alternating runs; forward TFLOP/s per
-                                                                              # variant, or (--dq64) microseconds of the dQ kernel
+    python tools/ab_fwd64.py build [--dq64|--dkdv64] name1:key=val,key=val name2:...   # here (no GPU): one libvsel_<name>.so per option set
+    python tools/ab_fwd64.py run [--dq64|--dkdv64] [rounds] [--shapes 16x4096,4x8192]  # on the GPU box: alternating runs; forward TFLOP/s per
+                                                                              # variant, or (--dq64 / --dkdv64) microseconds of that pass's kernel
 
 A variant = the shipped library with csrc/attn_fwd64.hip recompiled against another generated body (visionselector_amd/build/variants/)."""
 import glob, json, os, subprocess, sys
@@ -13,11 +13,16 @@ VDIR = os.path.join(ROOT, "visionselector_amd", "build", "variants")
 PKG = os.path.join(ROOT, "visionselector_amd")
 
 
-DQ64 = "--dq64" in sys.argv
-if DQ64:
-    sys.argv.remove("--dq64")
-GEN, SRC, OBJ_SKIP, ENV_OPTS, ENV_OUT, DEF = (("gen_attn_bwd_dq64.py", "attn_bwd_dq64.hip", "attn_bwd_dq64.o", "DQ64_OPTS", "DQ64_OUT", "VSEL_DQ64_BODY")
-                                              if DQ64 else ("gen_attn_fwd64.py", "attn_fwd64.hip", "attn_fwd64.o", "F64_OPTS", "F64_OUT", "VSEL_FWD64_BODY"))
+BWD = next((m for m in ("dq64", "dkdv64") if "--" + m in sys.argv), None)      # which backward pass's variants (None: the forward's)
+if BWD:
+    sys.argv.remove("--" + BWD)
+DQ64 = BWD is not None
+GEN, SRC, OBJ_SKIP, ENV_OPTS, ENV_OUT, DEF = {
+    None: ("gen_attn_fwd64.py", "attn_fwd64.hip", "attn_fwd64.o", "F64_OPTS", "F64_OUT", "VSEL_FWD64_BODY"),
+    "dq64": ("gen_attn_bwd_dq64.py", "attn_bwd_dq64.hip", "attn_bwd_dq64.o", "DQ64_OPTS", "DQ64_OUT", "VSEL_DQ64_BODY"),
+    "dkdv64": ("gen_attn_bwd_dkdv64.py", "attn_bwd_dkdv64.hip", "attn_bwd_dkdv64.o", "DKDV64_OPTS", "DKDV64_OUT", "VSEL_DKDV64_BODY")}[BWD]
+BWD_ENV, BWD_NEW, BWD_OLD = {None: ("", "", ""), "dq64": ("VSEL_ATTN_BWD_DQ64", "attn_bwd_dq64_kernel", "attn_bwd_dq_kernel"),
+                             "dkdv64": ("VSEL_ATTN_BWD_DKDV64", "attn_bwd_dkdv64_kernel", "attn_bwd_dkdv_kernel")}[BWD]
 
 
 def build(specs):
@@ -81,7 +86,7 @@ print("RESULT " + json.dumps(out))
 def bench_dq64(lib, shapes, dq64=1):
     code = f"""
 import sys, json, os, torch
-os.environ["VSEL_ATTN_BWD_DQ64"] = "{dq64}"
+os.environ["{BWD_ENV}"] = "{dq64}"
 sys.path.insert(0, {ROOT!r})
 from visionselector_amd import _native
 _native.LIB_PATH = {lib!r}
@@ -102,7 +107,7 @@ for nseq, L in {shapes!r}:
     for _ in range(8):
         ops.varlen_attn_bwd(do, q, k, v, o, lse, cu, L)
     prof = _native.profile_stop()
-    name = "attn_bwd_dq64_kernel" if {dq64} else "attn_bwd_dq_kernel"
+    name = "{BWD_NEW}" if {dq64} else "{BWD_OLD}"
     out[f"{{nseq}}x{{L}}"] = round(prof[name][0] / prof[name][1] * 1e3, 1)
 print("RESULT " + json.dumps(out))
 """
@@ -119,7 +124,7 @@ def run(rounds, shapes):
         table = {}
         for r in range(rounds):
             for lib in [None] + libs:
-                name = os.path.basename(lib)[8:-3] if lib else "dq_kernel"
+                name = os.path.basename(lib)[8:-3] if lib else BWD_OLD
                 res = bench_dq64(lib, shapes) if lib else bench_dq64(os.path.join(PKG, "libvsel.so"), shapes, dq64=0)
                 for k, val in res.items():
                     table.setdefault(name, {}).setdefault(k, []).append(val)

@@ -6,6 +6,8 @@
 import os, sys, json, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visionselector_amd import _native as N, ops
+if os.environ.get("VSEL_CHECK_LIB"):          # a variant library of tools/ab_fwd64.py instead of the shipped one
+    N.LIB_PATH = os.environ["VSEL_CHECK_LIB"]
 
 
 def grads(q, k, v, do, out, lse, cu, L, causal, new):

@@ -13,8 +13,13 @@ per accumulator in the same order, so dK / dV are bit-identical to that kernel's
 Units.  A (tile, query block) unit = 16 MFMAs "SdP" (S / dP alternating; Q / dO row fragments from LDS), 80 VALU and 16 MFMAs "dVdK"
 (dV / dK alternating; dO^T / Q^T fragments by transposed reads).  MFMA stream of tile t:
     SdP(t,0) dVdK(t-1,1) SdP(t,1) dVdK(t,0)        [dVdK(t,1) runs in step t + 1: the Q / dO rings have THREE slots]
-a unit's VALU runs in the gaps of the 32 MFMAs that follow its SdP (the other query block's), its per-query lse2 / D arrive as
-broadcast ds_read_b128 in the last gaps of its SdP.
+a unit's VALU runs in the gaps of the 32 MFMAs that follow its SdP (the other query block's): first the 32 operations that read the
+per-query lse2 / D (so those registers are free for the next unit's broadcast ds_read_b128 in the first gaps of ITS SdP), then exp / dS /
+conversions.  The step's barrier stands in front of its last batch (every wave is then past the slot the next loads overwrite, the next
+tile has landed), whose gaps carry the next tile's first row fragments across the step boundary.
+Per wave and tile the 64 MFMAs (2048 cycles) want 64 KiB of operands from LDS -- 16 KiB each of Q, dO rows (ds_read_b128) and of
+Q^T, dO^T (ds_read_b64_tr_b16, half the rate per byte) -- i.e. ~1800 LDS cycles per CU and tile with the direct-to-LDS writes: the LDS
+pipe is as busy as the MFMA pipe, and with <= 15 reads in flight per wave the schedule variants (options below) move the time by 1 - 3 %.
 
 Register map (per lane)
   a[0:63] dK^T accumulators (d-tile dt: + 16 dt), a[64:127] dV^T, a[128:159] K fragments (k-step st: + 4 st), a[160:191] V fragments,
@@ -42,6 +47,7 @@ V_QLIM = 194                                      # len - 8 hh
 V_REL, V_QL = 195, 196                            # per (unit, m): key_rel and query limit against the element index e
 V_LA = 197                                        # LDS address of lse slot 0 + 32 hh bytes
 V_U = 198                                         # U0..U9
+V_X = 232                                         # [16] four more transposed-fragment slots (trx=1)
 V_RA2, V_TR2 = 212, 220                           # the same fragment addresses inside the dO ring (ds offsets are 16 bits: the ring base rides in the register)
 FIRST_V, LAST_V = 32, 255
 
@@ -69,7 +75,8 @@ LSE_BASE = 2 * NQ * KBUF                          # lse2[NQ][64] floats, then D[
 D_BASE = LSE_BASE + NQ * 256
 LDS_BYTES = D_BASE + NQ * 256
 
-OPT = {"dma": "1,3,5,7,9,11,13,15", "split": "24", "ko": ""}
+# defaults = the measured best (profiles/r04_dkdv64_ab.txt); bar=top, valu=skew, split=24, tail=11 is the first working form
+OPT = {"dma": "1,3,5,7,9,11,13,15", "split": "40", "ko": "", "bar": "mid", "valu": "ab", "trx": "0", "tail": "13", "fw": "0", "fr": "9"}
 for kv in os.environ.get("DKDV64_OPTS", "").split(","):
     if "=" in kv:
         key, val = kv.split("=", 1)
@@ -77,6 +84,12 @@ for kv in os.environ.get("DKDV64_OPTS", "").split(","):
         OPT[key] = val.replace("/", ",")
 VALU_SPLIT = int(OPT["split"])
 KO = set(OPT["ko"].split("+")) - {""}
+VALU_AB = OPT["valu"] == "ab"      # a unit's VALU as stage A (the 32 operations that read lse2 / D) then stage B (exp, dS, conversions)
+TRX = OPT["trx"] == "1"            # the m = 0 fragments of d-tiles 2, 3 in four arch-VGPR slots: every transposed read is issued >= 7 MFMAs ahead
+FINE_WAITS = OPT["fw"] == "1"     # SdP waits per row fragment instead of per group of them
+FR_GAP = int(OPT["fr"])            # first dVdK gap that carries the next SdP's first row reads (two per gap)
+TAIL_HI = int(OPT["tail"])         # last SdP gap that takes VALU of the previous unit
+BAR_MID = OPT["bar"] == "mid"      # the step's barrier in front of its last batch, whose gaps then carry the NEXT tile's first reads
 
 
 # ---- streams ----------------------------------------------------------------------------------------------------------------------
@@ -89,7 +102,9 @@ def row_read(tensor, qb, st, slot):
 
 def sdp_mfma(g, i, qb):
     st, is_dp = i // 2, i % 2
-    if not is_dp and st in (0, 4, 6):
+    if FINE_WAITS:
+        g.need(("do" if is_dp else "q", qb, st))
+    elif not is_dp and st in (0, 4, 6):
         g.need(("do", qb, {0: 3, 4: 5, 6: 7}[st]))
     frag = ar(A_ROW + 4 * ((st & 3) + (4 if is_dp else 0)), 4)
     dst = vr((V_DP if is_dp else V_S) + 16 * qb, 16)
@@ -108,15 +123,24 @@ def second_reads(qb, slot):
     return out
 
 
+def tr_frag(m, dt, k, lo=0, n=4):
+    """registers of the transposed fragment (16-query half m, d-tile dt, k = 0 dO^T / 1 Q^T).  Eight accumulator-file slots: a half's
+    four d-tiles, a slot pair free one MFMA pair behind its m = 0 use; with trx, m = 0 keeps d-tiles 2, 3 in arch VGPRs and m = 1 has
+    slots 4 .. 7 (d-tiles 0, 1) and 0 .. 3 (d-tiles 2, 3) to itself."""
+    if not TRX:
+        return ar(A_TR + 4 * (2 * dt + k) + lo, n)
+    if m == 0:
+        return ar(A_TR + 4 * (2 * dt + k) + lo, n) if dt < 2 else vr(V_X + 4 * (2 * (dt - 2) + k) + lo, n)
+    return ar(A_TR + 16 + 4 * (2 * dt + k) + lo, n) if dt < 2 else ar(A_TR + 4 * (2 * (dt - 2) + k) + lo, n)
+
+
 def tr_reads(qb, m, dt, slot):
     """the four transposed reads of (query block, 16-query half, d-tile): dO^T fragment into slot 2 (dt & 3 ...) and Q^T behind it"""
     out = []
-    fs = 2 * dt
     for tensor, k in (("do", 0), ("q", 1)):
-        base = A_TR + 4 * (fs + k)
         for hi in range(2):
             off = slot * KBUF + (32 * qb + 16 * m) * 256
-            out.append((f"ds_read_b64_tr_b16 {ar(base + 2 * hi, 2)}, {v((V_TR if tensor == 'q' else V_TR2) + 2 * dt + hi)} offset:{off}",
+            out.append((f"ds_read_b64_tr_b16 {tr_frag(m, dt, k, 2 * hi, 2)}, {v((V_TR if tensor == 'q' else V_TR2) + 2 * dt + hi)} offset:{off}",
                         ("t" + tensor, qb, m, dt, hi)))
     return out
 
@@ -127,7 +151,7 @@ def dvdk_mfma(g, i, qb):
     if not is_dk:
         g.need(("tq", qb, m, dt, 1))                         # the pair's four reads (dO^T then Q^T)
     acc = ar((A_DK if is_dk else A_DV) + 16 * dt, 16)
-    frag = ar(A_TR + 4 * (2 * dt + (1 if is_dk else 0)), 4)
+    frag = tr_frag(m, dt, 1 if is_dk else 0)
     b = vr((V_DS if is_dk else V_P) + 8 * qb + 4 * m, 4)
     g.e(f"v_mfma_f32_32x32x16_bf16 {acc}, {frag}, {b}, {acc}")
 
@@ -136,6 +160,24 @@ def unit_valu(qb):
     """p = exp2(s c - lse2[q]) in place, dS = bf16(p (dP - D[q])), P = bf16(p): 80 VALU, skewed (no result used within two instructions)"""
     sb, db = V_S + 16 * qb, V_DP + 16 * qb
     ops = []
+    if VALU_AB:
+        for i in range(16):
+            ops.append(f"v_fma_f32 {v(sb + i)}, {v(sb + i)}, {s(S_SL2)}, -{v(V_L + i)}")
+            ops.append(f"v_sub_f32 {v(db + i)}, {v(db + i)}, {v(V_D + i)}")
+        for i in range(16 + 5):
+            if i < 16:
+                ops.append(f"v_exp_f32 {v(sb + i)}, {v(sb + i)}")
+            r = i - 2
+            if 0 <= r < 16:
+                ops.append(f"v_mul_f32 {v(db + r)}, {v(sb + r)}, {v(db + r)}")
+            r = i - 3
+            if 0 <= r < 16 and r % 2 == 1:
+                ops.append(f"v_cvt_pk_bf16_f32 {v(V_P + 8 * qb + 4 * (r >> 3) + ((r & 7) >> 1))}, {v(sb + r - 1)}, {v(sb + r)}")
+            r = i - 4
+            if 0 <= r < 16 and r % 2 == 1:
+                ops.append(f"v_cvt_pk_bf16_f32 {v(V_DS + 8 * qb + 4 * (r >> 3) + ((r & 7) >> 1))}, {v(db + r - 1)}, {v(db + r)}")
+        assert len(ops) == 80 and VALU_SPLIT >= 32          # (lse2 / D registers are free once the head has run)
+        return ops
     for i in range(16 + 8):
         if i < 16:
             ops.append(f"v_fma_f32 {v(sb + i)}, {v(sb + i)}, {s(S_SL2)}, -{v(V_L + i)}")
@@ -193,6 +235,17 @@ def mask_unit(g, qb, uniq):
     g.label("Lnm" + uniq)
 
 
+def issue(g, text, tag):
+    """an LDS read with its wait bookkeeping (timing-only knock-outs: ko=row / tr / ld leave a class of reads out)"""
+    kind = "tr" if tag[0] in ("tq", "tdo") else "row" if tag[0] in ("q", "do") else "ld"
+    if kind in KO:
+        g.strict = False
+        return
+    if len(g.out) >= 14:                                      # lgkmcnt counts 15: retire the oldest (long landed) read first
+        g.need(g.out[0])
+    g.lds(text, tag)
+
+
 def emit_batch(g, n, mfma_fn, gaps):
     for i in range(n):
         if "mfma" in KO:
@@ -203,9 +256,9 @@ def emit_batch(g, n, mfma_fn, gaps):
             mfma_fn(i)
         for ins in gaps[i]:
             if isinstance(ins, tuple):
-                if len(g.out) >= 14:                          # lgkmcnt counts 15: retire the oldest (long landed) read first
-                    g.need(g.out[0])
-                g.lds(ins[0], ins[1])
+                issue(g, ins[0], ins[1])
+            elif "dma" in KO and ins.startswith("global_load_lds"):
+                pass
             elif "valu" in KO and ins.split()[0] in ("v_fma_f32", "v_sub_f32", "v_exp_f32", "v_mul_f32", "v_cvt_pk_bf16_f32"):
                 pass
             else:
@@ -318,6 +371,20 @@ def load_tile(g, slot, uniq):
     load_tail(g, slot, uniq)
 
 
+def tr_plan(pqb, ps):
+    """-> (reads riding in the SdP batch in front [(gap, read)], reads in the dVdK batch's own gaps [(gap, read)])"""
+    if not TRX:
+        pre = list(zip([9, 9, 10, 10, 11, 11, 12, 12], tr_first(pqb, ps)))
+        own = [(dt - 2, r) for dt in (2, 3) for r in tr_reads(pqb, 0, dt, ps)]            # the rest of m = 0
+        own += [(2 * dt + 2, r) for dt in range(4) for r in tr_reads(pqb, 1, dt, ps)]      # m = 1: behind the slot pair's m = 0 use
+        return pre, sorted(own, key=lambda x: x[0])
+    m0 = [r for dt in range(4) for r in tr_reads(pqb, 0, dt, ps)]
+    pre = list(zip([8 + i // 2 for i in range(16)], m0))                                   # gaps 8 .. 15, a fragment per gap
+    own = list(zip([i // 2 for i in range(8)], [r for dt in (0, 1) for r in tr_reads(pqb, 1, dt, ps)]))          # slots 4 .. 7
+    own += list(zip([4 + i // 2 for i in range(8)], [r for dt in (2, 3) for r in tr_reads(pqb, 1, dt, ps)]))     # slots 0 .. 3, free after MFMA 3
+    return pre, own
+
+
 def tr_first(pqb, ps):
     """m = 0 fragments of d-tiles 0, 1 (eight reads): issued in the gaps of the SdP batch in front of the dVdK batch that uses them"""
     return [r for dt in range(2) for r in tr_reads(pqb, 0, dt, ps)]
@@ -328,8 +395,9 @@ def step_body(g, idx, tag, has_prev, steady):
     slot, pslot, nslot = idx, (idx + 2) % 3, (idx + 1) % 3
     e = g.e
     tile_flags(g)
-    for ins, tg in first_reads(0, slot):
-        g.lds(ins, tg)
+    if not BAR_MID:
+        for ins, tg in first_reads(0, slot):
+            issue(g, ins, tg)
     if steady:
         load_addr(g)
     for qb in range(2):
@@ -341,9 +409,14 @@ def step_body(g, idx, tag, has_prev, steady):
             gaps[gp].append(rd)
         if have_prev:
             tail = unit_valu(1 - qb)[VALU_SPLIT:]
-            place(gaps, tail, spread(len(tail), 0, 11))
-            place(gaps, tr_first(pqb, ps), [9, 9, 10, 10, 11, 11, 12, 12])
-        place(gaps, ld_reads(qb, slot), spread(8, 12, 15))
+            place(gaps, tail, spread(len(tail), 0, TAIL_HI))
+            for gp, rd in tr_plan(pqb, ps)[0]:
+                gaps[gp].append(rd)
+        if VALU_AB:
+            for gp, rd in zip(spread(8, 0, 3), ld_reads(qb, slot)):       # (in front of the gap's other reads: consumed first)
+                gaps[gp].insert(0, rd)
+        else:
+            place(gaps, ld_reads(qb, slot), spread(8, 12, 15))
         if qb == 0 and steady:
             where = [int(x) for x in OPT["dma"].split(",")]
             for w, (m0w, ld) in zip(where, load_pieces(nslot)):
@@ -355,41 +428,58 @@ def step_body(g, idx, tag, has_prev, steady):
         mask_unit(g, qb, f"{tag}q{qb}")
         # ---- dVdK of the previous unit beside the head of this unit's VALU, the transposed reads and the next SdP's first reads ----
         g.need(("d", qb, 1, 1))                                # this unit's lse2 / D have landed
+        if BAR_MID and qb == 1:
+            # every wave is past its last read of the slot the next step's loads overwrite (the deferred unit's, batch 2), and the
+            # next tile (loaded during batch 1) has landed: its first fragments can ride in this batch instead of behind a barrier
+            e("s_waitcnt vmcnt(0)")
+            e("s_barrier")
         if have_prev:
             gq = [[] for _ in range(17)]
             head = unit_valu(qb)[:VALU_SPLIT]
             place(gq, head, spread(len(head), 3, 15))
-            for dt in (2, 3):                                  # the rest of m = 0
-                for r in tr_reads(pqb, 0, dt, ps):
-                    gq[dt - 2].append(r)
-            for dt in range(4):                                # m = 1: a slot pair is free one MFMA pair behind its m = 0 use
-                for r in tr_reads(pqb, 1, dt, ps):
-                    gq[2 * dt + 2].append(r)
+            for gp, rd in tr_plan(pqb, ps)[1]:
+                gq[gp].append(rd)
             if qb == 0:
-                place(gq, first_reads(1, slot), [9, 9, 10, 10, 11, 11, 12, 12])
+                place(gq, first_reads(1, slot), [FR_GAP + i // 2 for i in range(8)])
+            elif BAR_MID:
+                place(gq, first_reads(0, nslot), [FR_GAP + i // 2 for i in range(8)])
             emit_batch(g, 16, lambda i: dvdk_mfma(g, i, pqb), gq)
         else:
             for ins in unit_valu(qb)[:VALU_SPLIT]:
                 e(ins)
             for ins, tg in first_reads(1, slot):
-                g.lds(ins, tg)
+                issue(g, ins, tg)
     advance_cqt(g)
-    assert not g.out, g.out
+    if CARRY[0] is None:
+        CARRY[0] = list(g.out)
+    assert g.out == CARRY[0], (g.out, CARRY[0])
+
+
+CARRY = [None]
+
+
+def carry_reads():
+    """reads in flight across a step boundary, oldest first (bar=mid: those of the next tile's first row fragments that the last batch
+    did not retire; a slot without a next tile is read all the same).  Found by a dry run of a step body, the same for every body."""
+    if not BAR_MID:
+        return []
+    if CARRY[0] is None:
+        dry = Gen()
+        dry.out = [tg for _, tg in first_reads(0, 0)] if "row" not in KO else []
+        step_body(dry, 1, "dry", True, True)
+    return list(CARRY[0])
 
 
 def drain(g, pslot):
     """the last unit (query block 1 of the last tile): the rest of its VALU, then its dVdK"""
     for ins in unit_valu(1)[VALU_SPLIT:]:
         g.e(ins)
-    for ins, tg in tr_first(1, pslot):
-        g.lds(ins, tg)
+    pre, own = tr_plan(1, pslot)
+    for _, (ins, tg) in pre:
+        issue(g, ins, tg)
     gq = [[] for _ in range(17)]
-    for dt in (2, 3):
-        for r in tr_reads(1, 0, dt, pslot):
-            gq[dt - 2].append(r)
-    for dt in range(4):
-        for r in tr_reads(1, 1, dt, pslot):
-            gq[2 * dt + 2].append(r)
+    for gp, rd in own:
+        gq[gp].append(rd)
     emit_batch(g, 16, lambda i: dvdk_mfma(g, i, 1), gq)
     assert not g.out
 
@@ -398,17 +488,18 @@ def gen_step(g, idx):
     P = f"p{idx}"
     e = g.e
     g.label("Lstep" + P)
-    e("s_waitcnt vmcnt(0)")
-    e("s_barrier")
+    if not BAR_MID:
+        e("s_waitcnt vmcnt(0)")
+        e("s_barrier")
     e(f"s_cmp_lt_i32 {s(S_IT)}, {s(S_NF)}")
     e(f"s_cbranch_scc0 {g.lref('Lgen' + P)}")
     e(f"s_cmp_gt_i32 {s(S_IT)}, 0")
     e(f"s_cbranch_scc0 {g.lref('Lgen' + P)}")
-    g.out = []
+    g.out = carry_reads()
     step_body(g, idx, "s" + P, True, True)
     e(f"s_branch {g.lref('Lend' + P)}")
     g.label("Lgen" + P)
-    g.out = []
+    g.out = carry_reads()
     e(f"s_cmp_lt_i32 {s(S_LCNT)}, {s(S_NIT)}")
     e(f"s_cbranch_scc0 {g.lref('Lnoload' + P)}")
     load_tile(g, (idx + 1) % 3, "g" + P)
@@ -418,7 +509,7 @@ def gen_step(g, idx):
     step_body(g, idx, "g" + P, True, False)
     e(f"s_branch {g.lref('Lend' + P)}")
     g.label("Lfirst" + P)
-    g.out = []
+    g.out = carry_reads()
     if idx == 0:
         step_body(g, idx, "f" + P, False, False)
     g.label("Lend" + P)
@@ -537,13 +628,20 @@ def gen_body():
         e(f"v_accvgpr_write_b32 {a(A_DK + i)}, 0")
     # ---- first tile ----
     load_tile(g, 0, "pro")
+    if BAR_MID:
+        e("s_waitcnt vmcnt(0)")
+        e("s_barrier")
+        for ins, tg in first_reads(0, 0):
+            issue(g, ins, tg)
+        while g.out and g.out != carry_reads():                # (the step bodies count the in-flight reads from this state)
+            g.need(g.out[0])
     # ---- tile loop: three step bodies (ring slot = it % 3) ----
     for idx in range(3):
         gen_step(g, idx)
     # ---- the last unit is still open: its fragments sit in the slot of the last tile ----
     for idx in range(3):
         g.label(f"Ldrainp{idx}")
-        g.out = []
+        g.out = carry_reads()
         drain(g, idx)
         e(f"s_branch {g.lref('Lepi')}")
     g.label("Lepi")

@@ -67,6 +67,7 @@ S_NF = 80                                         # number of leading steps that
 S_WAVE = 81
 S_PTR2 = 82                                       # 82..83
 S_FLAG = 84                                       # this tile needs the mask for this wave
+S_SL2P = 86                                       # 86..87: sl2 twice (operand pair of the packed fma)
 FIRST_S, LAST_S = 40, 87
 
 KBUF = 16384
@@ -76,7 +77,7 @@ D_BASE = LSE_BASE + NQ * 256
 LDS_BYTES = D_BASE + NQ * 256
 
 # defaults = the measured best (profiles/r04_dkdv64_ab.txt); bar=top, valu=skew, split=24, tail=11 is the first working form
-OPT = {"dma": "1,3,5,7,9,11,13,15", "split": "40", "ko": "", "bar": "mid", "valu": "ab", "trx": "0", "tail": "13", "fw": "0", "fr": "9"}
+OPT = {"dma": "1,3,5,7,9,11,13,15", "split": "40", "ko": "", "bar": "mid", "valu": "ab", "trx": "0", "tail": "13", "fw": "0", "fr": "9", "pk": "0"}
 for kv in os.environ.get("DKDV64_OPTS", "").split(","):
     if "=" in kv:
         key, val = kv.split("=", 1)
@@ -86,10 +87,14 @@ VALU_SPLIT = int(OPT["split"])
 KO = set(OPT["ko"].split("+")) - {""}
 VALU_AB = OPT["valu"] == "ab"      # a unit's VALU as stage A (the 32 operations that read lse2 / D) then stage B (exp, dS, conversions)
 TRX = OPT["trx"] == "1"            # the m = 0 fragments of d-tiles 2, 3 in four arch-VGPR slots: every transposed read is issued >= 7 MFMAs ahead
+PK = OPT["pk"] == "1"              # packed fp32 VALU (v_pk_fma / add / mul_f32: two registers per instruction, the same IEEE operations): a wave alone
+                                   # on its SIMD issues one instruction per 4 cycles, so the instruction COUNT beside the MFMAs is what costs
 FINE_WAITS = OPT["fw"] == "1"     # SdP waits per row fragment instead of per group of them
 FR_GAP = int(OPT["fr"])            # first dVdK gap that carries the next SdP's first row reads (two per gap)
 TAIL_HI = int(OPT["tail"])         # last SdP gap that takes VALU of the previous unit
-BAR_MID = OPT["bar"] == "mid"      # the step's barrier in front of its last batch, whose gaps then carry the NEXT tile's first reads
+BAR_STAG = OPT["bar"] == "stag"    # bar=mid with waves 2, 3 at the barrier one batch earlier: they then run one batch behind waves 0, 1, so
+                                   # two waves are in an SdP batch (row reads) while two are in a dVdK batch (half-rate transposed reads)
+BAR_MID = OPT["bar"] in ("mid", "stag")      # the step's barrier in front of its last batch, whose gaps then carry the NEXT tile's first reads
 
 
 # ---- streams ----------------------------------------------------------------------------------------------------------------------
@@ -160,6 +165,25 @@ def unit_valu(qb):
     """p = exp2(s c - lse2[q]) in place, dS = bf16(p (dP - D[q])), P = bf16(p): 80 VALU, skewed (no result used within two instructions)"""
     sb, db = V_S + 16 * qb, V_DP + 16 * qb
     ops = []
+    if PK:
+        assert VALU_AB and sb % 2 == 0 and db % 2 == 0 and V_L % 2 == 0 and V_D % 2 == 0
+        for j in range(8):
+            i = 2 * j
+            ops.append(f"v_pk_fma_f32 {vr(sb + i, 2)}, {vr(sb + i, 2)}, {sr(S_SL2P)}, {vr(V_L + i, 2)} neg_lo:[0,0,1] neg_hi:[0,0,1]")
+            ops.append(f"v_pk_add_f32 {vr(db + i, 2)}, {vr(db + i, 2)}, {vr(V_D + i, 2)} neg_lo:[0,1] neg_hi:[0,1]")
+        for j in range(8 + 2):
+            if j < 8:
+                ops.append(f"v_exp_f32 {v(sb + 2 * j)}, {v(sb + 2 * j)}")
+                ops.append(f"v_exp_f32 {v(sb + 2 * j + 1)}, {v(sb + 2 * j + 1)}")
+            r = 2 * (j - 1)
+            if 0 <= r < 16:
+                ops.append(f"v_pk_mul_f32 {vr(db + r, 2)}, {vr(sb + r, 2)}, {vr(db + r, 2)}")
+                ops.append(f"v_cvt_pk_bf16_f32 {v(V_P + 8 * qb + 4 * (r >> 3) + ((r & 7) >> 1))}, {v(sb + r)}, {v(sb + r + 1)}")
+            r = 2 * (j - 2)
+            if 0 <= r < 16:
+                ops.append(f"v_cvt_pk_bf16_f32 {v(V_DS + 8 * qb + 4 * (r >> 3) + ((r & 7) >> 1))}, {v(db + r)}, {v(db + r + 1)}")
+        assert len(ops) == 56 and VALU_SPLIT >= 16
+        return ops
     if VALU_AB:
         for i in range(16):
             ops.append(f"v_fma_f32 {v(sb + i)}, {v(sb + i)}, {s(S_SL2)}, -{v(V_L + i)}")
@@ -259,7 +283,7 @@ def emit_batch(g, n, mfma_fn, gaps):
                 issue(g, ins[0], ins[1])
             elif "dma" in KO and ins.startswith("global_load_lds"):
                 pass
-            elif "valu" in KO and ins.split()[0] in ("v_fma_f32", "v_sub_f32", "v_exp_f32", "v_mul_f32", "v_cvt_pk_bf16_f32"):
+            elif "valu" in KO and ins.split()[0] in ("v_fma_f32", "v_sub_f32", "v_exp_f32", "v_mul_f32", "v_cvt_pk_bf16_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32"):
                 pass
             else:
                 g.e(ins)
@@ -417,6 +441,12 @@ def step_body(g, idx, tag, has_prev, steady):
                 gaps[gp].insert(0, rd)
         else:
             place(gaps, ld_reads(qb, slot), spread(8, 12, 15))
+        if BAR_STAG and qb == 1:
+            e(f"s_cmp_lt_u32 {s(S_WAVE)}, 2")
+            e(f"s_cbranch_scc1 {g.lref('Lb3' + tag)}")
+            e("s_waitcnt vmcnt(0)")
+            e("s_barrier")
+            g.label("Lb3" + tag)
         if qb == 0 and steady:
             where = [int(x) for x in OPT["dma"].split(",")]
             for w, (m0w, ld) in zip(where, load_pieces(nslot)):
@@ -431,8 +461,13 @@ def step_body(g, idx, tag, has_prev, steady):
         if BAR_MID and qb == 1:
             # every wave is past its last read of the slot the next step's loads overwrite (the deferred unit's, batch 2), and the
             # next tile (loaded during batch 1) has landed: its first fragments can ride in this batch instead of behind a barrier
+            if BAR_STAG:
+                e(f"s_cmp_lt_u32 {s(S_WAVE)}, 2")
+                e(f"s_cbranch_scc0 {g.lref('Lb4' + tag)}")
             e("s_waitcnt vmcnt(0)")
             e("s_barrier")
+            if BAR_STAG:
+                g.label("Lb4" + tag)
         if have_prev:
             gq = [[] for _ in range(17)]
             head = unit_valu(qb)[:VALU_SPLIT]
@@ -528,6 +563,8 @@ def gen_body():
     for dst, name in ((S_NIT, "niter"), (S_QBEG, "qbegin"), (S_LEN, "len"), (S_SL2, "sl2"), (S_SCALE, "scale"),
                       (S_QRS2, "qrs2"), (S_FST, "fstride"), (S_KW0, "kw0"), (S_CAUSAL, "causal"), (S_WAVE, "wave"), (S_LHEAD, "head0")):
         e(f"s_mov_b32 {s(dst)}, %[{name}]")
+    e(f"s_mov_b32 {s(S_SL2P)}, {s(S_SL2)}")
+    e(f"s_mov_b32 {s(S_SL2P + 1)}, {s(S_SL2)}")
     e(f"s_lshl_b32 {s(S_W4)}, {s(S_WAVE)}, 2")
     e(f"s_mov_b32 {s(S_RING)}, %[ldsbase]")
     e(f"s_lshl_b32 {s(S_TMP)}, {s(S_WAVE)}, 10")
@@ -675,6 +712,10 @@ def clobbers():
 
 def main():
     g = gen_body()
+    if "wait" in KO:                                           # timing only: the reads stay, their waits go
+        g.lines = [ln for ln in g.lines if not ln.startswith("s_waitcnt lgkmcnt")]
+    if "bar" in KO:                                            # timing only: no step barriers (and no load waits in front of them)
+        g.lines = [ln for ln in g.lines if ln not in ("s_barrier", "s_waitcnt vmcnt(0)")]
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_attn_bwd_dkdv64.py -- do not edit; the per-item body of attn_bwd_dkdv64_kernel as one inline-asm statement.\n")
         f.write(f"// {len(g.lines)} lines; options {OPT}\n")

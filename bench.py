@@ -563,8 +563,26 @@ def bench_attention(ops, k, text=64, hq=28, hkv=4, dh=128, layers=28, iters=200)
         out["packed_16x4096"] = {"ms": ms, "tflops": tf,
                                  "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                               "frac": tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None}}
+        # ... and its backward (training): dQ, dK, dV from dO on the same batch, 5 algorithmic contractions
+        # (2.5 x the forward's FLOPs; the two-pass kernels execute 7)
+        do = torch.randn(n_seq * L, hq, dh, device="cuda", generator=gen).bfloat16()
+        o, lse = ops.varlen_attn_fwd_lse(q, kk, v, cu, L)
+        for _ in range(5):
+            ops.varlen_attn_bwd(do, q, kk, v, o, lse, cu, L)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            ops.varlen_attn_bwd(do, q, kk, v, o, lse, cu, L)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        tf = 10.0 * L * L * hq * dh / 2 * n_seq / (ms * 1e-3) / 1e12
+        out["packed_16x4096_backward"] = {"ms": ms, "tflops_algorithmic": tf,
+                                          "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                       "frac": tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None}}
     except Exception as e:  # optional
-        out["packed_16x4096"] = {"error": str(e)[:200]}
+        out.setdefault("packed_16x4096", {"error": str(e)[:200]})
+        out.setdefault("packed_16x4096_backward", {"error": str(e)[:200]})
     return out
 
 

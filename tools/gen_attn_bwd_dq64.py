@@ -61,8 +61,10 @@ FIRST_S, LAST_S = 40, 87
 KBUF = 16384
 OPT = {
     "dma": "1,3,5,7,9,11,13,15",                  # gaps of a steady step's first SdP batch that carry the next tile's eight slices
-    "split": "18",                                # VALU of a unit issued beside the dQ batch right behind its SdP; the rest beside the next SdP batch
+    "split": "24",                                # VALU of a unit issued beside the dQ batch right behind its SdP; the rest beside the next SdP batch
     "ko": "",                                     # knock-outs (timing only, WRONG results): valu, lds, dma, mfma joined by "+"
+    "bar": "mid",                                 # mid: the step's barrier in front of its last dQ batch, whose gaps then carry the NEXT tile's
+                                                  # first row fragments across the step boundary (tools/gen_attn_bwd_dkdv64.py has the argument)
 }
 for kv in os.environ.get("DQ64_OPTS", "").split(","):
     if "=" in kv:
@@ -225,6 +227,19 @@ def second_reads(kb, ks):
 
 
 VALU_SPLIT = int(OPT["split"])
+BAR_MID = OPT["bar"] == "mid"
+CARRY = [None]
+
+
+def carry_reads():
+    """reads in flight across a step boundary, oldest first (bar=mid); found by a dry run of a step body, the same for every body"""
+    if not BAR_MID or "lds" in KO:
+        return []
+    if CARRY[0] is None:
+        dry = Gen()
+        dry.out = [tg for _, tg in first_reads(0, 0)]
+        step_body(dry, 1, "dry", True, True)
+    return list(CARRY[0])
 
 
 def step_body(g, par, tag, has_prev, steady):
@@ -232,9 +247,10 @@ def step_body(g, par, tag, has_prev, steady):
     On entry with has_prev: S / dP / K^T of unit (2t-1, B) in registers, its first VALU_SPLIT VALU done."""
     ks = vs = par
     e = g.e
-    # the first SdP batch's first eight fragments
-    for ins, tag_ in first_reads(0, ks):
-        g.lds(ins, tag_)
+    # the first SdP batch's first eight fragments (bar=mid: in flight since the previous step's last batch)
+    if not BAR_MID:
+        for ins, tag_ in first_reads(0, ks):
+            g.lds(ins, tag_)
     order = [(0, 0), (0, 1), (1, 0), (1, 1)]                 # (key block, row block) in MFMA-stream order
     for ui, (kb, blk) in enumerate(order):
         # ---- SdP(kb, blk) beside the VALU tail of the previous unit ----
@@ -269,6 +285,12 @@ def step_body(g, par, tag, has_prev, steady):
             if ui < 3:
                 nkb = order[ui + 1][0]
                 place(gq, first_reads(nkb, ks), [1, 1, 2, 2, 3, 3, 4, 4])
+            elif BAR_MID:
+                # every wave is past its reads of this tile (the next loads overwrite its slots) and the next tile, loaded during the
+                # first batch, has landed
+                e("s_waitcnt vmcnt(0)")
+                e("s_barrier")
+                place(gq, first_reads(0, 1 - ks), [1, 1, 2, 2, 3, 3, 4, 4])
             # K^T of the previous unit's key block: read beside its row-block-A SdP... held since then (row block B reuses them)
             emit_batch(g, 8, lambda i: dq_mfma(g, i, pkb, pblk, wait=(pblk == 0)), gq)
         else:
@@ -277,7 +299,12 @@ def step_body(g, par, tag, has_prev, steady):
                 e(ins)
             for ins, tag_ in first_reads(order[ui + 1][0], ks):
                 g.lds(ins, tag_)
-    assert not [t for t in g.out if t[0] in ("k", "v")], g.out
+    if not BAR_MID or "lds" in KO:
+        assert not [t for t in g.out if t[0] in ("k", "v")], g.out
+    else:
+        if CARRY[0] is None:
+            CARRY[0] = list(g.out)
+        assert g.out == CARRY[0], (g.out, CARRY[0])
 
 
 def drain(g):
@@ -293,17 +320,18 @@ def gen_step(g, par):
     P = f"p{par}"
     e = g.e
     g.label("Lstep" + P)
-    e("s_waitcnt vmcnt(0)")
-    e("s_barrier")
+    if not BAR_MID:
+        e("s_waitcnt vmcnt(0)")
+        e("s_barrier")
     e(f"s_cmp_lt_i32 {s(S_T)}, {s(S_NSTEADY)}")
     e(f"s_cbranch_scc0 {g.lref('Lgen' + P)}")
     e(f"s_cmp_gt_i32 {s(S_T)}, 0")
     e(f"s_cbranch_scc0 {g.lref('Lgen' + P)}")
-    g.out = []
+    g.out = carry_reads()
     step_body(g, par, "s" + P, True, True)
     e(f"s_branch {g.lref('Lend' + P)}")
     g.label("Lgen" + P)
-    g.out = []
+    g.out = carry_reads()
     # K(t + 1), V(t + 1) -> slots 1 - par
     e(f"s_add_i32 {s(S_TMP)}, {s(S_T)}, 1")
     e(f"s_cmp_lt_i32 {s(S_TMP)}, {s(S_NT)}")
@@ -318,12 +346,15 @@ def gen_step(g, par):
     step_body(g, par, "g" + P, True, False)
     e(f"s_branch {g.lref('Lend' + P)}")
     g.label("Lfirst" + P)
-    g.out = []
+    g.out = carry_reads()
     if par == 0:
         step_body(g, par, "f" + P, False, False)
     e(f"s_branch {g.lref('Lend' + P)}")
     g.label("Lnotfull" + P)
-    g.out = []
+    g.out = carry_reads()                                     # (a wave past its last tile: in flight only in its first such step)
+    if BAR_MID:
+        e("s_waitcnt vmcnt(0)")                               # its share of the next tile's loads, then the step's barrier
+        e("s_barrier")
     e(f"s_cmp_eq_u32 {s(S_T)}, {s(S_NW)}")                    # the step right behind the wave's last tile: its last unit is still open
     e(f"s_cbranch_scc0 {g.lref('Lend' + P)}")
     e(f"s_cmp_gt_i32 {s(S_NW)}, 0")
@@ -562,10 +593,20 @@ def gen_body():
         e(f"global_store_dword {v(V_X + b)}, {v(V_LSE2 + b)}, %[lse2base]")
         e(f"s_mov_b64 exec, {sr(S_EXEC)}")
     # ---- tile loop ----
+    if BAR_MID:
+        assert not g.out, g.out
+        e("s_waitcnt vmcnt(0)")                               # K(0) / V(0) by every wave
+        e("s_barrier")
+        for ins, tag_ in first_reads(0, 0):
+            if "lds" not in KO:
+                g.lds(ins, tag_)
+        while g.out and g.out != carry_reads():                # (the step bodies count the in-flight reads from this state)
+            g.need(g.out[0])
     gen_step(g, 0)
     gen_step(g, 1)
     # ---- epilogue ----
     g.label("Lepi")
+    g.out = carry_reads()
     e(f"s_cmp_eq_u32 {s(S_NW)}, {s(S_NT)}")
     e(f"s_cbranch_scc0 {g.lref('Lnodrain')}")
     e(f"s_cmp_gt_i32 {s(S_NW)}, 0")

@@ -22,5 +22,7 @@ timeout 300 python tools/bench_select_splice.py 2>&1 | g > $O/select_splice.json
 timeout 300 python tools/exp_merger_fusion.py 2>&1 | g > $O/merger_fusion.jsonl
 timeout 600 python tools/sweep.py 2>&1 | g > $O/config_sweep.json
 timeout 600 python tools/bench_c5.py 2>&1 | g > $O/config5.jsonl
-timeout 120 tools/lds_tr_bench > $O/lds_read_rates.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/lds_tr_bench tools/lds_tr_bench.hip > /dev/null 2>&1 && timeout 120 /tmp/lds_tr_bench > $O/lds_read_rates.txt 2>&1
+timeout 200 bash tools/clock_under_load.sh 2>&1 | g > $O/clock_under_load.txt
+timeout 300 python tools/exp_dkdv64_shapes.py 2>&1 | g > $O/dkdv64_shapes.txt
 cat $O/pytest_gpu.txt; head -c 600 $O/bench_default.json

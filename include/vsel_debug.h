@@ -50,8 +50,8 @@ typedef enum vsel_debug_knob {
                                      -1 from 2048 tokens in the longest sequence (default), 0 never, 1 always; env VSEL_ATTN_BWD_DQ64; dQ / D / lse2
                                      bit-identical */
   VSEL_KNOB_ATTN_BWD_DKDV64 = 16, /* dK / dV pass by the one-wave-per-SIMD kernel with the unit pipeline (csrc/attn_bwd_dkdv64.hip, generated
-                                     body; only when the group's q heads are looped inside an item, i.e. not the split form): -1 by sequence
-                                     length (default), 0 never, 1 always; env VSEL_ATTN_BWD_DKDV64; dK / dV as the 4-wave form's, bit for bit */
+                                     body; either item form): -1 from 1024 tokens in the longest sequence, 2048 in the per-q-head split form
+                                     (default), 0 never, 1 always; env VSEL_ATTN_BWD_DKDV64; dK / dV as the 4-wave form's, bit for bit */
   VSEL_KNOB_COUNT = 17
 } vsel_debug_knob;
 

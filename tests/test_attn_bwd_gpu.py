@@ -167,16 +167,20 @@ def test_xcd_local_work_queues_do_not_change_results(ops):
     lens = [700, 130, 1500, 64, 900, 333, 1100, 257, 640, 1024, 12, 777, 1300]      # 13 x 4 pairs; > 512 forward / dQ items,
     res = {}                                                                         # 13 x 12 x 4 = 624 dK / dV items
     for mode in (0, 1):
-        for waves in (8, 4):
-            with N.debug_knob(attn_xcd_queue=mode, attn_bwd_waves=waves, attn_bwd_split=0):
+        for waves in (8, 4, 64):           # 64: the one-wave-per-SIMD passes (csrc/attn_bwd_dq64.hip, attn_bwd_dkdv64.hip) forced on
+            new = int(waves == 64)
+            with N.debug_knob(attn_xcd_queue=mode, attn_bwd_waves=min(waves, 8), attn_bwd_split=0, attn_bwd_dq64=new, attn_bwd_dkdv64=new):
                 N.profile_start()
                 _, out, lse, g = _run(ops, lens, 28, 4, True, seed=21)
                 prof = N.profile_stop()
-                assert prof["attn_bwd_dq_kernel"][1] == 1 and prof["attn_bwd_dkdv_kernel"][1] == 1
+                names = ("attn_bwd_dq64_kernel", "attn_bwd_dkdv64_kernel") if new else ("attn_bwd_dq_kernel", "attn_bwd_dkdv_kernel")
+                assert prof[names[0]][1] == 1 and prof[names[1]][1] == 1, prof
                 res[(mode, waves)] = (out, lse) + tuple(g)
-    for waves in (8, 4):
+    for waves in (8, 4, 64):
         for a, b in zip(res[(0, waves)], res[(1, waves)]):
             assert torch.equal(a, b)
+    for a, b in zip(res[(0, 4)], res[(0, 64)]):            # and the 64-row passes reproduce the four-wave form bit for bit
+        assert torch.equal(a, b)
 
 
 def test_flash_attn_compat_functions(ops):
@@ -275,11 +279,15 @@ def test_dq64_pass_is_bit_identical_to_the_reference_dq_kernel(lens, hq, hkv, ca
 @pytest.mark.parametrize("lens,hq,hkv", [([1], 2, 1), ([64], 4, 4), ([65], 4, 2), ([129], 2, 2), ([193], 4, 1), ([256], 4, 4),
                                          ([300, 129, 64], 4, 2), ([37, 700, 256, 129], 28, 4), ([1230], 32, 8), ([2368], 4, 4)])
 @pytest.mark.parametrize("causal", [True, False])
-def test_dkdv64_pass_is_bit_identical_to_the_four_wave_dkdv_kernel(lens, hq, hkv, causal):
+@pytest.mark.parametrize("split", [0, 1])
+def test_dkdv64_pass_is_bit_identical_to_the_four_wave_dkdv_kernel(lens, hq, hkv, causal, split):
     """The hand-scheduled dK / dV pass keeps the four-wave kernel's work split (wave w owns keys 32 w .. 32 w + 31 of a 128-key item,
     the group's q heads looped inside) and its summation order over query tiles: dK and dV are bit-identical to that form's.  (Oracle
     parity of the gradients is test_backward_matches_oracle's; this is the form-vs-form gate.)  Lengths with remainders 1 / 65 / 129
-    exercise the clamped tile loads (one valid row), partial key blocks, key blocks above the diagonal and the two-sided mask."""
+    exercise the clamped tile loads (one valid row), partial key blocks, key blocks above the diagonal and the two-sided mask.
+    split = 1: the per-q-head item form (raw fp32 partial rows + attn_bwd_group_sum_kernel) in both kernels."""
+    if split and hq == hkv:
+        pytest.skip("no group to split")
     import torch
     from visionselector_amd import _native as N, ops
     g = torch.Generator(device="cuda").manual_seed(23 + len(lens))
@@ -292,11 +300,11 @@ def test_dkdv64_pass_is_bit_identical_to_the_four_wave_dkdv_kernel(lens, hq, hkv
     out, lse = ops.varlen_attn_fwd_lse(q, k, v, cu, max(lens), causal=causal)
     res = []
     for dkdv64 in (0, 1):
-        with N.debug_knob(attn_bwd_dkdv64=dkdv64, attn_bwd_waves=4, attn_bwd_split=0):
+        with N.debug_knob(attn_bwd_dkdv64=dkdv64, attn_bwd_waves=4, attn_bwd_split=split):
             N.profile_start()
             res.append(ops.varlen_attn_bwd(do, q, k, v, out, lse, cu, max(lens), causal=causal))
             prof = N.profile_stop()
-            assert ("attn_bwd_dkdv64_kernel" in prof) == bool(dkdv64), prof
+            assert ("attn_bwd_dkdv64_kernel" in prof) == bool(dkdv64) and ("attn_bwd_group_sum_kernel" in prof) == bool(split), prof
     for a, b in zip(*res):
         assert torch.equal(a, b)
 

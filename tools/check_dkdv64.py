@@ -10,8 +10,8 @@ if os.environ.get("VSEL_CHECK_LIB"):          # a variant library of tools/ab_fw
     N.LIB_PATH = os.environ["VSEL_CHECK_LIB"]
 
 
-def grads(q, k, v, do, out, lse, cu, L, causal, new):
-    with N.debug_knob(attn_bwd_dkdv64=new, attn_bwd_waves=4, attn_bwd_split=0):
+def grads(q, k, v, do, out, lse, cu, L, causal, new, split=0):
+    with N.debug_knob(attn_bwd_dkdv64=new, attn_bwd_waves=4, attn_bwd_split=split):
         N.profile_start()
         res = ops.varlen_attn_bwd(do, q, k, v, out, lse, cu, L, causal=causal)
         prof = N.profile_stop()
@@ -19,7 +19,7 @@ def grads(q, k, v, do, out, lse, cu, L, causal, new):
     return res
 
 
-def case(lens, hq, hkv, causal, seed=0):
+def case(lens, hq, hkv, causal, seed=0, split=0):
     g = torch.Generator(device="cuda").manual_seed(seed)
     T = sum(lens)
     q = torch.randn(T, hq, 128, device="cuda", generator=g).bfloat16()
@@ -29,9 +29,9 @@ def case(lens, hq, hkv, causal, seed=0):
     cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
     L = max(lens)
     out, lse = ops.varlen_attn_fwd_lse(q, k, v, cu, L, causal=causal)
-    a, b = grads(q, k, v, do, out, lse, cu, L, causal, 0), grads(q, k, v, do, out, lse, cu, L, causal, 1)
+    a, b = grads(q, k, v, do, out, lse, cu, L, causal, 0, split), grads(q, k, v, do, out, lse, cu, L, causal, 1, split)
     torch.cuda.synchronize()
-    rec = {"lens": lens if len(lens) <= 4 else f"{len(lens)} x ...", "hq": hq, "hkv": hkv, "causal": causal}
+    rec = {"lens": lens if len(lens) <= 4 else f"{len(lens)} x ...", "hq": hq, "hkv": hkv, "causal": causal, "split": split}
     ok = True
     for name, x, y in zip(("dq", "dk", "dv"), a, b):
         same = torch.equal(x.view(torch.int16), y.view(torch.int16))
@@ -53,6 +53,8 @@ def main():
         cases = cases[:5]
     for lens, hq, hkv, causal in cases:
         ok &= case(lens, hq, hkv, causal)
+        if hq != hkv:                  # the per-q-head item form (fp32 partials + attn_bwd_group_sum_kernel), both kernels forced into it
+            ok &= case(lens, hq, hkv, causal, split=1)
     print(json.dumps({"all_bit_identical": bool(ok)}), flush=True)
     if "--no-bench" in sys.argv:
         return 0 if ok else 1

@@ -688,6 +688,15 @@ def gen_body():
     assert tmp[0] % 2 == 0
     e(f"v_cmp_ne_u32 vcc, 0, %[kvalid]")
     e("s_mov_b64 exec, vcc")
+    # split form (item = one q head): the raw fp32 accumulators into this head's partial rows, straight from the accumulator file
+    e("s_cmp_lg_u32 %[split], 0")
+    e(f"s_cbranch_scc0 {g.lref('Lbf16')}")
+    for acc, ptr in ((A_DK, "dkptr"), (A_DV, "dvptr")):
+        for dt in range(4):
+            for g4 in range(4):
+                e(f"global_store_dwordx4 %[{ptr}], {ar(acc + 16 * dt + 4 * g4, 4)}, off offset:{128 * dt + 32 * g4}")
+    e(f"s_branch {g.lref('Lstored')}")
+    g.label("Lbf16")
     for acc, ptr, scaled in ((A_DK, "dkptr", True), (A_DV, "dvptr", False)):
         for dt in range(4):
             for g4 in range(4):
@@ -700,6 +709,7 @@ def gen_body():
                 e(f"v_cvt_pk_bf16_f32 {v(tmp[0])}, {v(tmp[0])}, {v(tmp[1])}")
                 e(f"v_cvt_pk_bf16_f32 {v(tmp[1])}, {v(tmp[2])}, {v(tmp[3])}")
                 e(f"global_store_dwordx2 %[{ptr}], {vr(tmp[0], 2)}, off offset:{64 * dt + 16 * g4}")
+    g.label("Lstored")
     e(f"s_mov_b64 exec, {sr(S_EXEC)}")
     e(f"s_mov_b32 m0, {s(S_M0SAVE)}")
     return g

@@ -933,13 +933,14 @@ int dq64_launch(hipStream_t st, const void* q, const void* k, const void* v, con
                 int causal, void* dq, int xcd_local);          // attn_bwd_dq64.hip
 int dkdv64_launch(hipStream_t st, const void* q, const void* k, const void* v, const void* dout, const float* lse2, const float* dvec,
                   const int32_t* cu, int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv, float scale, int causal, void* dk, void* dv,
-                  int xcd_local);                              // attn_bwd_dkdv64.hip
+                  float* dk_part, float* dv_part, int xcd_local);   // attn_bwd_dkdv64.hip (dk_part != NULL: the per-q-head split form)
 } }
 
 // the 64-rows-per-wave dQ pass from this many tokens in the longest sequence (same-process A/B, tools/exp_dq64_shapes.py,
 // profiles/r04_dq64_shapes.txt: 1 x 2368 +5 %, 16 x 2368 +12 %, 1 x 4096 +17 %, 16 x 4096 +17 %, 2 x 8192 +17 %; 16 x 1100 -1 %, 32 x 524 -13 %)
 constexpr int64_t kDq64FromTokens = 2048;
-constexpr int64_t kDkdv64FromTokens = 2048;  // (profiles/r04_dkdv64_shapes.txt: +15 ... +18 % from 2368 tokens, level at 1100, behind at 524)
+constexpr int64_t kDkdv64FromTokens = 1024;       // q heads inside the item (profiles/r04_dkdv64_shapes.txt: +4 ... +8 % at 1100, +15 ... +22 % from 2368, level at 524)
+constexpr int64_t kDkdv64SplitFromTokens = 2048;  // per-q-head split form (few items): +5 % at 1 x 2368, +12 % at 1 x 4096, +15 % at 1 x 8192
 
 static bool bwd_use_split(int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv) {
   if (hq == hkv) return false;
@@ -1013,32 +1014,36 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
     VSEL_AFTER_LAUNCH(st, "attn_bwd_dq_kernel");
   }
   const int g_dkdv64 = knob(VSEL_KNOB_ATTN_BWD_DKDV64);
-  if (!bwd_use_split(n_seq, max_seqlen, hq, hkv) &&
-      (g_dkdv64 == 1 || (g_dkdv64 < 0 && kDkdv64FromTokens > 0 && max_seqlen >= kDkdv64FromTokens))) {
-    return bwd::dkdv64_launch(st, q, k, v, dout, lse2, dvec, cu_seqlens, n_seq, max_seqlen, hq, hkv, scale, causal, dk, dv, xcd_local_dkdv);
-  }
   {
     const bool split = bwd_use_split(n_seq, max_seqlen, hq, hkv);
+    const bool dkdv64 = g_dkdv64 == 1 || (g_dkdv64 < 0 && max_seqlen >= (split ? kDkdv64SplitFromTokens : kDkdv64FromTokens));
     const int k_blocks = (int)cdiv(max_seqlen, 128);
     const int64_t n_items = (int64_t)k_blocks * (split ? hq : hkv) * n_seq;
     if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
-    int slot;
-    if (int rc = take_slot(n_items, 256, slot)) return rc;
     float* dk_part = split ? (float*)((char*)workspace + 2 * d_bytes) : nullptr;
     float* dv_part = split ? dk_part + (size_t)rows * bwd::kD : nullptr;
-    const dim3 grid((unsigned)std::min<int64_t>(n_items, 256));
-    const bool w8 = knob(VSEL_KNOB_ATTN_BWD_WAVES) == 8;
-#define VSEL_DKDV_ARGS (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu_seqlens, (int)hq, \
-                       (int)hkv, scale, causal, (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, k_blocks, (int)n_seq, slot, xcd_local_dkdv
-    if (w8) {
-      if (split) hipLaunchKernelGGL((bwd::attn_bwd_dkdv2_kernel<true>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS);
-      else hipLaunchKernelGGL((bwd::attn_bwd_dkdv2_kernel<false>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS);
+    if (dkdv64) {
+      // long sequences: one wave per SIMD with the unit pipeline (attn_bwd_dkdv64.hip), either item form; dK / dV as the 4-wave kernel's
+      if (int rc = bwd::dkdv64_launch(st, q, k, v, dout, lse2, dvec, cu_seqlens, n_seq, max_seqlen, hq, hkv, scale, causal, dk, dv, dk_part,
+                                      dv_part, xcd_local_dkdv))
+        return rc;
     } else {
-      if (split) hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<true>), grid, dim3(256), 0, st, VSEL_DKDV_ARGS);
-      else hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<false>), grid, dim3(256), 0, st, VSEL_DKDV_ARGS);
-    }
+      int slot;
+      if (int rc = take_slot(n_items, 256, slot)) return rc;
+      const dim3 grid((unsigned)std::min<int64_t>(n_items, 256));
+      const bool w8 = knob(VSEL_KNOB_ATTN_BWD_WAVES) == 8;
+#define VSEL_DKDV_ARGS (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu_seqlens, (int)hq, \
+                         (int)hkv, scale, causal, (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, k_blocks, (int)n_seq, slot, xcd_local_dkdv
+      if (w8) {
+        if (split) hipLaunchKernelGGL((bwd::attn_bwd_dkdv2_kernel<true>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS);
+        else hipLaunchKernelGGL((bwd::attn_bwd_dkdv2_kernel<false>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS);
+      } else {
+        if (split) hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<true>), grid, dim3(256), 0, st, VSEL_DKDV_ARGS);
+        else hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<false>), grid, dim3(256), 0, st, VSEL_DKDV_ARGS);
+      }
 #undef VSEL_DKDV_ARGS
-    VSEL_AFTER_LAUNCH(st, "attn_bwd_dkdv_kernel");
+      VSEL_AFTER_LAUNCH(st, "attn_bwd_dkdv_kernel");
+    }
     if (split) {
       // rows past a sequence's end never exist in the packed layout, so every (t, h) partial row was written
       hipLaunchKernelGGL(bwd::attn_bwd_group_sum_kernel, dim3((unsigned)cdiv(total * hkv * 32, 256)), dim3(256), 0, st, dk_part,

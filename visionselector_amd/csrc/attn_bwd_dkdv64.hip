@@ -1,11 +1,12 @@
 // dK / dV pass of the var-len causal / full GQA attention backward, head_dim 128, bf16 -- one 512-register wave per SIMD with the MFMA
 // stream software-pipelined inside the wave (gfx950).
 //
-// Work split and arithmetic of attn_bwd_dkdv_kernel<false> (attn_bwd.hip; reference: the autograd of the eager formula,
+// Work split and arithmetic of attn_bwd_dkdv_kernel<SPLIT> (attn_bwd.hip; reference: the autograd of the eager formula,
 // qwen-evaluation/qwen25vl/modeling_qwen2_5_vl.py:777-797, reached in training through qwen-vl-finetune/qwenvl/train/trainer.py:101-113):
 // item = (128-key block, kv head, sequence); wave w owns keys 32 w .. 32 w + 31 (K / V fragments in registers) and loops over the q heads
 // of the group and the 64-query Q / dO tiles, which stream through three-slot direct-to-LDS rings; dK / dV are bit-identical to that
-// kernel's (same MFMAs per accumulator in the same order).  What is new is the schedule: units of (tile, 32-query block), a unit's
+// kernel's (same MFMAs per accumulator in the same order).  Split form (few items): item = (key block, Q head, sequence), raw fp32
+// partial rows for attn_bwd_group_sum_kernel, as attn_bwd_dkdv_kernel<true>.  What is new is the schedule: units of (tile, 32-query block), a unit's
 // exponentials and dS in the gaps of the OTHER query block's 32 MFMAs, transposed fragments and per-query lse2 / D read ahead -- as one
 // GENERATED inline-asm statement per item (tools/gen_attn_bwd_dkdv64.py; hipcc cannot hold the register plan: attn_fwd64.hip).
 #include "attn_common.h"
@@ -34,33 +35,38 @@ __device__ int g_dkdv64_work_counter[64 * 8];
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v, const uint16_t* __restrict__ dout,
     const float* __restrict__ lse2, const float* __restrict__ dvec, const int32_t* __restrict__ cu, int hq, int hkv, float scale, float sl2,
-    int causal, uint16_t* __restrict__ dk, uint16_t* __restrict__ dv, int k_blocks, int n_seq, int slot, int xcd_local) {
+    int causal, uint16_t* __restrict__ dk, uint16_t* __restrict__ dv, float* __restrict__ dk_part, float* __restrict__ dv_part, int split,
+    int k_blocks, int n_seq, int slot, int xcd_local) {
   __shared__ __attribute__((aligned(1024))) char smem[VSEL_DKDV64_LDS_BYTES + 16];
   int& s_item = *reinterpret_cast<int*>(smem + VSEL_DKDV64_LDS_BYTES);
-  const int n_items = k_blocks * hkv * n_seq;
+  // split (few items: attn_bwd.hip bwd_use_split): item = (key block, Q head, sequence) writing its fp32 partial [T, hq, 128];
+  // attn_bwd_group_sum_kernel adds the heads of a group -- the item numbering of attn_bwd_dkdv_kernel<SPLIT>
+  const int heads_dim = split ? hq : hkv;
+  const int n_items = k_blocks * heads_dim * n_seq;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
   const int lds_base = (int)lds_u32(smem);
   const int rep = hq / hkv;
-  XcdQueue wq{&g_dkdv64_work_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks, xcc_id(), 0};
+  XcdQueue wq{&g_dkdv64_work_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * (split ? rep : 1), xcc_id(), 0};
   for (int round = 0;; ++round) {
-    int kblock, kvh, seq;
+    int kblock, hsel, seq;
     if (slot < 0 || !xcd_local) {
       if (slot < 0 && round > 0) return;
       const int item = slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
       if (item < 0 || item >= n_items) return;
-      kblock = item / (hkv * n_seq);
-      const int rest = item % (hkv * n_seq);
-      kvh = rest % hkv, seq = rest / hkv;
+      kblock = item / (heads_dim * n_seq);
+      const int rest = item % (heads_dim * n_seq);
+      hsel = rest % heads_dim, seq = rest / heads_dim;
     } else {
       const int item = xcd_queue_next(wq, &s_item, tid);
       if (item < 0) return;
-      const int pair = item / wq.per_pair;
+      const int pair = item / wq.per_pair, r = item % wq.per_pair;
       seq = pair / hkv;
-      kblock = item % wq.per_pair;
-      kvh = pair % hkv;
+      kblock = r % k_blocks;
+      hsel = split ? (pair % hkv) * rep + r / k_blocks : pair % hkv;
     }
+    const int kvh = split ? hsel / rep : hsel;
     const int qs = cu[seq];
     const int len = cu[seq + 1] - qs;
     const int k0 = kblock * 128;
@@ -70,8 +76,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
     const int kvalid = (kw0 + j) < len ? 1 : 0;
     const int q_begin = causal ? k0 : 0;                         // a multiple of 128, hence of the 64-query tile
     const int tiles_per_head = (len - q_begin + kTileK - 1) / kTileK;
-    const int n_iter = __builtin_amdgcn_readfirstlane(tiles_per_head * rep);
-    const int head0 = __builtin_amdgcn_readfirstlane(kvh * rep);
+    const int n_iter = __builtin_amdgcn_readfirstlane(split ? tiles_per_head : tiles_per_head * rep);
+    const int head0 = __builtin_amdgcn_readfirstlane(split ? hsel : kvh * rep);
 
     const void* const qbase = uniform_ptr(q + (int64_t)qs * hq * kD);
     const void* const dobase = uniform_ptr(dout + (int64_t)qs * hq * kD);
@@ -80,15 +86,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
     const int64_t ro = ((int64_t)(qs + my_k) * hkv + kvh) * kD;
     const uint16_t* const kptr = k + ro + 8 * hh;
     const uint16_t* const vptr = v + ro + 8 * hh;
-    uint16_t* const dkptr = dk + ro + 4 * hh;
-    uint16_t* const dvptr = dv + ro + 4 * hh;
+    const int64_t po = ((int64_t)(qs + my_k) * hq + hsel) * kD + 4 * hh;
+    void* const dkptr = split ? (void*)(dk_part + po) : (void*)(dk + ro + 4 * hh);
+    void* const dvptr = split ? (void*)(dv_part + po) : (void*)(dv + ro + 4 * hh);
+    const int split_u = __builtin_amdgcn_readfirstlane(split);
     const int qrs2 = hq * kD * 2, fstride = hq * 4;
     const int len_u = __builtin_amdgcn_readfirstlane(len), qbeg_u = __builtin_amdgcn_readfirstlane(q_begin);
     asm volatile(VSEL_DKDV64_ASM_TEXT
                  :
                  : [qbase] "s"(qbase), [dobase] "s"(dobase), [lsebase] "s"(lsebase), [dbase] "s"(dbase), [qrs2] "s"(qrs2),
                    [fstride] "s"(fstride), [niter] "s"(n_iter), [qbegin] "s"(qbeg_u), [len] "s"(len_u), [sl2] "s"(sl2), [scale] "s"(scale),
-                   [kw0] "s"(kw0), [causal] "s"(causal), [wave] "s"(wave), [head0] "s"(head0), [ldsbase] "s"(lds_base),
+                   [kw0] "s"(kw0), [causal] "s"(causal), [wave] "s"(wave), [head0] "s"(head0), [ldsbase] "s"(lds_base), [split] "s"(split_u),
                    [kptr] "v"(kptr), [vptr] "v"(vptr), [dkptr] "v"(dkptr), [dvptr] "v"(dvptr), [kvalid] "v"(kvalid)
                  : VSEL_DKDV64_ASM_CLOBBERS);
     __syncthreads();                   // the next item's first loads overwrite ring slots other waves may still read
@@ -99,9 +107,10 @@ namespace bwd {
 // attn_bwd.hip's launcher hands the dK / dV pass over here (knob attn_bwd_dkdv64) when the group's q heads are looped inside an item
 int dkdv64_launch(hipStream_t st, const void* q, const void* k, const void* v, const void* dout, const float* lse2, const float* dvec,
                   const int32_t* cu, int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv, float scale, int causal, void* dk, void* dv,
-                  int xcd_local) {
+                  float* dk_part, float* dv_part, int xcd_local) {
+  const int split = dk_part != nullptr;                          // the caller runs attn_bwd_group_sum_kernel behind a split launch
   const int k_blocks = (int)cdiv(max_seqlen, 128);
-  const int64_t n_items = (int64_t)k_blocks * hkv * n_seq;
+  const int64_t n_items = (int64_t)k_blocks * (split ? hq : hkv) * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
   static unsigned next_slot = 0;
   int slot = -1;
@@ -113,7 +122,8 @@ int dkdv64_launch(hipStream_t st, const void* q, const void* k, const void* v, c
   }
   hipLaunchKernelGGL(attn_bwd_dkdv64_kernel, dim3((unsigned)std::min<int64_t>(n_items, 256)), dim3(256), 0, st, (const uint16_t*)q,
                      (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu, (int)hq, (int)hkv, scale,
-                     scale * 1.4426950408889634f, causal, (uint16_t*)dk, (uint16_t*)dv, k_blocks, (int)n_seq, slot, xcd_local);
+                     scale * 1.4426950408889634f, causal, (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, split, k_blocks, (int)n_seq, slot,
+                     xcd_local);
   VSEL_AFTER_LAUNCH(st, "attn_bwd_dkdv64_kernel");
   return VSEL_OK;
 }

@@ -47,7 +47,7 @@ typedef enum vsel_debug_knob {
                                      tile loop; csrc/attn_fwd64.hip): -1 from 2048 tokens in the longest sequence (default), 0 never,
                                      1 whenever it applies (contiguous keys); env VSEL_ATTN_ROWS64; bit-identical outputs */
   VSEL_KNOB_ATTN_BWD_DQ64 = 15,   /* dQ pass of the attention backward by the 64-rows-per-wave kernel (csrc/attn_bwd_dq64.hip, generated body):
-                                     -1 from 2048 tokens in the longest sequence (default), 0 never, 1 always; env VSEL_ATTN_BWD_DQ64; dQ / D / lse2
+                                     -1 from 1024 tokens in the longest sequence (default), 0 never, 1 always; env VSEL_ATTN_BWD_DQ64; dQ / D / lse2
                                      bit-identical */
   VSEL_KNOB_ATTN_BWD_DKDV64 = 16, /* dK / dV pass by the one-wave-per-SIMD kernel with the unit pipeline (csrc/attn_bwd_dkdv64.hip, generated
                                      body; either item form): -1 from 1024 tokens in the longest sequence, 2048 in the per-q-head split form

@@ -310,8 +310,8 @@ def test_dkdv64_pass_is_bit_identical_to_the_four_wave_dkdv_kernel(lens, hq, hkv
 
 
 def test_long_sequences_take_the_64_row_passes_by_default_and_match_the_oracle_bound():
-    """From 2048 tokens in the longest sequence the library picks attn_bwd_dq64_kernel and (outside the few-item split form)
-    attn_bwd_dkdv64_kernel by itself; gradients against the fp64 eager formula on the bf16-rounded inputs, at the backward test's bound."""
+    """From 1024 tokens in the longest sequence the library picks attn_bwd_dq64_kernel and attn_bwd_dkdv64_kernel (the per-q-head
+    split form of the latter from 2048) by itself; gradients against the fp64 eager formula on the bf16-rounded inputs, at the backward test's bound."""
     import torch
     from visionselector_amd import _native as N, ops
     lens, hq, hkv = [2100, 700], 4, 4

@@ -938,7 +938,7 @@ int dkdv64_launch(hipStream_t st, const void* q, const void* k, const void* v, c
 
 // the 64-rows-per-wave dQ pass from this many tokens in the longest sequence (same-process A/B, tools/exp_dq64_shapes.py,
 // profiles/r04_dq64_shapes.txt: 1 x 2368 +5 %, 16 x 2368 +12 %, 1 x 4096 +17 %, 16 x 4096 +17 %, 2 x 8192 +17 %; 16 x 1100 -1 %, 32 x 524 -13 %)
-constexpr int64_t kDq64FromTokens = 2048;
+constexpr int64_t kDq64FromTokens = 1024;         // (profiles/r04_dq64_shapes.txt: +2 ... +3 % at 1100, +9 ... +20 % from 2368, -10 % at 32 x 524)
 constexpr int64_t kDkdv64FromTokens = 1024;       // q heads inside the item (profiles/r04_dkdv64_shapes.txt: +4 ... +8 % at 1100, +15 ... +22 % from 2368, level at 524)
 constexpr int64_t kDkdv64SplitFromTokens = 2048;  // per-q-head split form (few items): +5 % at 1 x 2368, +12 % at 1 x 4096, +15 % at 1 x 8192
 

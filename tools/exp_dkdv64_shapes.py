@@ -22,10 +22,10 @@ for nseq, L in shapes:
     for rnd in range(2):
         for name, kw in kn.items():
             with N.debug_knob(**kw):
-                for _ in range(10):
+                for _ in range(6):
                     ops.varlen_attn_bwd(do, q, k, v, out, lse, cu, L)
                 N.profile_start()
-                for _ in range(10):
+                for _ in range(6):
                     ops.varlen_attn_bwd(do, q, k, v, out, lse, cu, L)
                 prof = N.profile_stop()
             us = sum(prof[n][0] / prof[n][1] * 1e3 for n in prof if any(n.startswith(d) for d in DKDV))

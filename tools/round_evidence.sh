@@ -25,4 +25,5 @@ timeout 600 python tools/bench_c5.py 2>&1 | g > $O/config5.jsonl
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/lds_tr_bench tools/lds_tr_bench.hip > /dev/null 2>&1 && timeout 120 /tmp/lds_tr_bench > $O/lds_read_rates.txt 2>&1
 timeout 200 bash tools/clock_under_load.sh 2>&1 | g > $O/clock_under_load.txt
 timeout 300 python tools/exp_dkdv64_shapes.py 2>&1 | g > $O/dkdv64_shapes.txt
+timeout 1500 bash tools/smoke_tools.sh > /dev/null 2>&1; cp gpurun_out/r04_tools_smoke.txt $O/tools_smoke.txt 2>/dev/null
 cat $O/pytest_gpu.txt; head -c 600 $O/bench_default.json

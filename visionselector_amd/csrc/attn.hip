@@ -19,6 +19,7 @@
 //   reads (ds_read_b128) and for the V transpose reads (ds_read_b64_tr_b16); the direct loads write LDS lane-linearly,
 //   so the swizzle is applied to their SOURCE address.  Online softmax in exp2 domain, fp32.
 #include "attn_common.h"
+#include <atomic>
 
 #include <algorithm>
 #include <type_traits>
@@ -689,10 +690,10 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   const int64_t n_items = pack ? hkv * n_seq : (int64_t)q_tiles * hq * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
   const int64_t slots = (big || split2) ? 256 : 512;               // resident workgroups (64 KiB LDS each; 128 KiB with two streams)
-  static unsigned next_slot = 0;
+  static std::atomic<unsigned> next_slot{0};      // (host threads may launch concurrently: a slot per launch, 64 in rotation)
   int slot = -1;                                                   // -1: direct mapping, one item per workgroup
   if (n_items > slots) {
-    slot = (int)(next_slot++ & 63u);
+    slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 63u);
     int* counters = nullptr;
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_attn_work_counter)));
     VSEL_HIP_CHECK(hipMemsetAsync(counters + 8 * slot, 0, 8 * sizeof(int), st));

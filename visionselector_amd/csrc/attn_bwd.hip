@@ -20,6 +20,7 @@
 // the transposed (b64_tr) reads without bank conflicts: 256-byte rows, 16-byte part p of row r stored at part p ^ swz(r),
 // swz(r) = ((r & 3) << 2) | ((r >> 2) & 3).
 #include "attn_common.h"
+#include <atomic>
 
 #include <algorithm>
 #include <type_traits>
@@ -980,11 +981,11 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
   float* lse2 = (float*)((char*)workspace + d_bytes);
   int* counters = nullptr;
   VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(bwd::g_bwd_counter)));
-  static unsigned next_slot = 0;
+  static std::atomic<unsigned> next_slot{0};      // (host threads may launch concurrently: a slot per launch, 64 in rotation)
   auto take_slot = [&](int64_t n_items, int64_t resident, int& slot) -> int {
     slot = -1;
     if (n_items > resident) {
-      slot = (int)(next_slot++ & 63u);
+      slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 63u);
       if (hipMemsetAsync(counters + 8 * slot, 0, 8 * sizeof(int), st) != hipSuccess) return fail(VSEL_ERR_HIP, "hipMemsetAsync(counter)");
     }
     return VSEL_OK;

@@ -10,6 +10,7 @@
 // exponentials and dS in the gaps of the OTHER query block's 32 MFMAs, transposed fragments and per-query lse2 / D read ahead -- as one
 // GENERATED inline-asm statement per item (tools/gen_attn_bwd_dkdv64.py; hipcc cannot hold the register plan: attn_fwd64.hip).
 #include "attn_common.h"
+#include <atomic>
 #ifndef VSEL_DKDV64_BODY
 #define VSEL_DKDV64_BODY "attn_bwd_dkdv64_body.inc"
 #endif
@@ -112,10 +113,10 @@ int dkdv64_launch(hipStream_t st, const void* q, const void* k, const void* v, c
   const int k_blocks = (int)cdiv(max_seqlen, 128);
   const int64_t n_items = (int64_t)k_blocks * (split ? hq : hkv) * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
-  static unsigned next_slot = 0;
+  static std::atomic<unsigned> next_slot{0};      // (host threads may launch concurrently: a slot per launch, 64 in rotation)
   int slot = -1;
   if (n_items > 256) {
-    slot = (int)(next_slot++ & 63u);
+    slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 63u);
     int* counters = nullptr;
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_dkdv64_work_counter)));
     VSEL_HIP_CHECK(hipMemsetAsync(counters + 8 * slot, 0, 8 * sizeof(int), st));

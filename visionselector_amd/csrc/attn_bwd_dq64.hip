@@ -11,6 +11,7 @@
 // rows arrive by whole-row direct-to-LDS loads, dQ leaves as whole rows through the ring.
 // The per-item body is one GENERATED inline-asm statement (hipcc cannot hold the register plan: attn_fwd64.hip).
 #include "attn_common.h"
+#include <atomic>
 #ifndef VSEL_DQ64_BODY
 #define VSEL_DQ64_BODY "attn_bwd_dq64_body.inc"
 #endif
@@ -131,10 +132,10 @@ int dq64_launch(hipStream_t st, const void* q, const void* k, const void* v, con
   const int q_tiles = (int)cdiv(max_seqlen, kBlockQ);
   const int64_t n_items = (int64_t)q_tiles * hq * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
-  static unsigned next_slot = 0;
+  static std::atomic<unsigned> next_slot{0};      // (host threads may launch concurrently: a slot per launch, 64 in rotation)
   int slot = -1;
   if (n_items > 256) {
-    slot = (int)(next_slot++ & 63u);
+    slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 63u);
     int* counters = nullptr;
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_dq64_work_counter)));
     VSEL_HIP_CHECK(hipMemsetAsync(counters + 8 * slot, 0, 8 * sizeof(int), st));

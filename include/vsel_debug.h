@@ -52,7 +52,11 @@ typedef enum vsel_debug_knob {
   VSEL_KNOB_ATTN_BWD_DKDV64 = 16, /* dK / dV pass by the one-wave-per-SIMD kernel with the unit pipeline (csrc/attn_bwd_dkdv64.hip, generated
                                      body; either item form): -1 from 1024 tokens in the longest sequence, 2048 in the per-q-head split form
                                      (default), 0 never, 1 always; env VSEL_ATTN_BWD_DKDV64; dK / dV as the 4-wave form's, bit for bit */
-  VSEL_KNOB_COUNT = 17
+  VSEL_KNOB_ATTN_STATIC = 17,     /* forward, 4- / 8-wave workgroups: work items dealt out statically (workgroup b takes items b, 2 G - 1 - b,
+                                     2 G + b, ... of the heaviest-first list: no atomic, no hand-over barriers, the next item known in advance):
+                                     -1 by item count and sequence length (default), 0 / 1 force; env VSEL_ATTN_STATIC; placement only,
+                                     outputs bit-identical */
+  VSEL_KNOB_COUNT = 18
 } vsel_debug_knob;
 
 /* Set knob to value (clamped to the knob's range).  *previous (may be NULL) receives the value it had.

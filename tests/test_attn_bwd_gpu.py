@@ -183,6 +183,28 @@ def test_xcd_local_work_queues_do_not_change_results(ops):
         assert torch.equal(a, b)
 
 
+def test_static_deal_of_work_items_does_not_change_results(ops):
+    """Work items handed out by the atomic queue (knob attn_static = 0) or dealt out statically (1: workgroup b takes items b, 2 G - 1 - b,
+    2 G + b, ... of the heaviest-first list; attn_common.h static_deal_item): placement only -- forward output, log-sum-exp, dQ, dK, dV
+    bit-identical in the 32-rows-per-wave kernels (both dK / dV item forms) and in the 64-rows forms, for ragged batches whose item
+    lists hold empty items, and the library's own rule (-1) takes the static deal on a grid with few rounds of items."""
+    from visionselector_amd import _native as N
+    for lens, hq, hkv in (([524] * 5, 28, 4), ([700, 130, 1500, 64, 900, 333, 1100, 257, 640, 1024, 12, 777, 1300], 28, 4),
+                          ([2368], 28, 4), ([1622, 620, 993], 8, 2)):
+        res = {}
+        for mode in (0, 1, -1):
+            for form in ("w4", "w4split", "r64"):
+                new = int(form == "r64")
+                with N.debug_knob(attn_static=mode, attn_bwd_waves=4, attn_bwd_split=int(form == "w4split"), attn_bwd_dq64=new,
+                                  attn_bwd_dkdv64=new, attn_rows64=new):
+                    _, out, lse, g = _run(ops, lens, hq, hkv, True, seed=23)
+                    res[(mode, form)] = (out, lse) + tuple(g)
+        for form in ("w4", "w4split", "r64"):
+            for mode in (1, -1):
+                for a, b in zip(res[(0, form)], res[(mode, form)]):
+                    assert torch.equal(a, b), (lens, form, mode)
+
+
 def test_flash_attn_compat_functions(ops):
     """flash_attn_varlen_func / flash_attn_func with the flash-attn call shapes: same packing (differentiable), different
     query / key packings (forward only, bottom-right causal) and the batched dense form."""

@@ -157,7 +157,10 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
   XcdQueue wq{&g_attn_work_counter[8 * (max(slot, 0) & 0xff)], n_seq * hkv, q_tiles * rep, xcc_id(), 0};
   for (int round = 0;; ++round) {
   int item;
-  if (slot < 0) {                       // one item per workgroup (n_items <= resident slots): no counter needed
+  if (slot == -2) {                     // static deal of the heaviest-first list (attn_common.h): packed batches with few rounds of items
+    item = static_deal_item(round);
+    if (item >= n_items) return;
+  } else if (slot < 0) {                // one item per workgroup (n_items <= resident slots): no counter needed
     if (round > 0) return;
     item = blockIdx.x;
     if (item >= n_items) return;
@@ -692,7 +695,15 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   const int64_t slots = (big || split2) ? 256 : 512;               // resident workgroups (64 KiB LDS each; 128 KiB with two streams)
   static std::atomic<unsigned> next_slot{0};      // (host threads may launch concurrently: a slot per launch, 64 in rotation)
   int slot = -1;                                                   // -1: direct mapping, one item per workgroup
-  if (n_items > slots) {
+  // Few rounds of items (slots < n_items <= 2.35 slots, 4-wave form): the work queue's atomic round trip and hand-over barriers in front of
+  // every item cost more than its balancing wins -- the heaviest-first list is dealt out statically instead, alternate rounds mirrored.
+  // tools/exp_attn_static.py, profiles/r04_attn_static.txt (queue -> static, us): 4 x 524 30.6 -> 23.6, 6 x 524 41.6 -> 35.6, 8 x 524
+  // 47.0 -> 42.0, 3 x 1100 53.1 -> 43.6, 4 x 1100 64.0 -> 57.4, 2 x 2000 85.5 -> 77.1, ragged batches of 3 - 6 compressed prompts +0 ... +18 %;
+  // beyond that the queue wins (10 x 524 -3 %, 32 x 524 -7 %, 64 ragged prompts -14 %).  Also measured there and not kept: the next item's
+  // Q rows prefetched into L2 by one load per lane (-1 ... -5 %: the load sits in front of the next tile's in the in-order return queue).
+  if (!pack && !split2 && attn_static_deal(n_items, slots, !big && d == 128)) {
+    slot = -2;                                                     // static deal (knob attn_static)
+  } else if (n_items > slots) {
     slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 63u);
     int* counters = nullptr;
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_attn_work_counter)));

@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
   for (int round = 0;; ++round) {
     int t_end, head, seq;
     if (slot < 0 || !xcd_local) {
-      if (slot < 0 && round > 0) return;
-      const int item = slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
+      if (slot == -1 && round > 0) return;
+      const int item = slot == -2 ? static_deal_item(round) : slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
       if (item < 0 || item >= n_items) return;
       t_end = item / (hq * n_seq);                               // query tile counted from the heaviest one
       const int rest = item % (hq * n_seq);
@@ -351,8 +351,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
   for (int round = 0;; ++round) {
     int kblock, hsel, seq;
     if (slot < 0 || !xcd_local) {
-      if (slot < 0 && round > 0) return;
-      const int item = slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
+      if (slot == -1 && round > 0) return;
+      const int item = slot == -2 ? static_deal_item(round) : slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
       if (item < 0 || item >= n_items) return;
       kblock = item / (heads_per_item_dim * n_seq);
       const int rest = item % (heads_per_item_dim * n_seq);
@@ -618,8 +618,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
   for (int round = 0;; ++round) {
     int kblock, hsel, seq;
     if (slot < 0 || !xcd_local) {
-      if (slot < 0 && round > 0) return;
-      const int item = slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
+      if (slot == -1 && round > 0) return;
+      const int item = slot == -2 ? static_deal_item(round) : slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
       if (item < 0 || item >= n_items) return;
       kblock = item / (heads_per_item_dim * n_seq);
       const int rest = item % (heads_per_item_dim * n_seq);
@@ -984,7 +984,9 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
   static std::atomic<unsigned> next_slot{0};      // (host threads may launch concurrently: a slot per launch, 64 in rotation)
   auto take_slot = [&](int64_t n_items, int64_t resident, int& slot) -> int {
     slot = -1;
-    if (n_items > resident) {
+    if (attn_static_deal(n_items, resident, true)) {
+      slot = -2;
+    } else if (n_items > resident) {
       slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 63u);
       if (hipMemsetAsync(counters + 8 * slot, 0, 8 * sizeof(int), st) != hipSuccess) return fail(VSEL_ERR_HIP, "hipMemsetAsync(counter)");
     }

@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
   for (int round = 0;; ++round) {
     int kblock, hsel, seq;
     if (slot < 0 || !xcd_local) {
-      if (slot < 0 && round > 0) return;
-      const int item = slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
+      if (slot == -1 && round > 0) return;
+      const int item = slot == -2 ? static_deal_item(round) : slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
       if (item < 0 || item >= n_items) return;
       kblock = item / (heads_dim * n_seq);
       const int rest = item % (heads_dim * n_seq);
@@ -115,7 +115,9 @@ int dkdv64_launch(hipStream_t st, const void* q, const void* k, const void* v, c
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
   static std::atomic<unsigned> next_slot{0};      // (host threads may launch concurrently: a slot per launch, 64 in rotation)
   int slot = -1;
-  if (n_items > 256) {
+  if (attn_static_deal(n_items, 256, true, 36)) {
+    slot = -2;
+  } else if (n_items > 256) {
     slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 63u);
     int* counters = nullptr;
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_dkdv64_work_counter)));

@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(
   for (int round = 0;; ++round) {
     int t_end, head, seq;
     if (slot < 0 || !xcd_local) {
-      if (slot < 0 && round > 0) return;
-      const int item = slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
+      if (slot == -1 && round > 0) return;
+      const int item = slot == -2 ? static_deal_item(round) : slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
       if (item < 0 || item >= n_items) return;
       t_end = item / (hq * n_seq);                               // query tile counted from the heaviest one
       const int rest = item % (hq * n_seq);
@@ -134,7 +134,9 @@ int dq64_launch(hipStream_t st, const void* q, const void* k, const void* v, con
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
   static std::atomic<unsigned> next_slot{0};      // (host threads may launch concurrently: a slot per launch, 64 in rotation)
   int slot = -1;
-  if (n_items > 256) {
+  if (attn_static_deal(n_items, 256, true, 36)) {
+    slot = -2;
+  } else if (n_items > 256) {
     slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 63u);
     int* counters = nullptr;
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_dq64_work_counter)));

@@ -119,6 +119,12 @@ __device__ __forceinline__ int global_queue_next(int* counter, int n_items, int*
   __syncthreads();
   return __builtin_amdgcn_readfirstlane(item);
 }
+// static deal (slot == -2; few rounds of items, knob attn_static): workgroup b takes items b, 2 G - 1 - b, 2 G + b, ... of the
+// heaviest-first list -- no atomic round trip and no hand-over barriers in front of an item
+__device__ __forceinline__ int static_deal_item(int round) {
+  const int g = (int)gridDim.x, b = (int)blockIdx.x;
+  return round * g + ((round & 1) ? g - 1 - b : b);
+}
 __device__ __forceinline__ int xcc_id() {
   int v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));

@@ -51,6 +51,10 @@ int knob(int id);
 // kernel (same-binary A/B on MI355X, profiles/r04_attn_xcd_queue.txt): a pair-major list is a worse load balance than heaviest-
 // first over all pairs when a pair has few items, so short / few sequences keep the single queue.
 int attn_use_xcd_queues(int64_t max_seqlen, int64_t n_pairs, int64_t min_len, int64_t min_pairs);
+// static deal of the work items instead of the atomic queue (attn_common.h::static_deal_item; knob attn_static): forced by the knob, else
+// when `auto_ok` and the grid has few rounds of items: n_items <= rounds20 / 20 slots (2.35 rounds for the 32-rows-per-wave kernels, 1.8
+// for the 64-rows forms, whose ragged batches balance worse: tools/exp_attn_static_all.py, profiles/r04_attn_static.txt)
+bool attn_static_deal(int64_t n_items, int64_t slots, bool auto_ok, int rounds20 = 47);
 
 // ---- error plumbing --------------------------------------------------------------------------
 void set_error(const std::string& msg);

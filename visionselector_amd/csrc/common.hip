@@ -47,6 +47,7 @@ constexpr KnobSpec kKnobs[VSEL_KNOB_COUNT] = {
     {"VSEL_ATTN_ROWS64", -1, -1, 1},     // VSEL_KNOB_ATTN_ROWS64
     {"VSEL_ATTN_BWD_DQ64", -1, -1, 1},   // VSEL_KNOB_ATTN_BWD_DQ64
     {"VSEL_ATTN_BWD_DKDV64", -1, -1, 1}, // VSEL_KNOB_ATTN_BWD_DKDV64
+    {"VSEL_ATTN_STATIC", -1, -1, 1},     // VSEL_KNOB_ATTN_STATIC
 };
 int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 int knob_default(int id) {
@@ -67,6 +68,11 @@ int knob(int id) { return knobs().v[id].load(std::memory_order_relaxed); }
 int attn_use_xcd_queues(int64_t max_seqlen, int64_t n_pairs, int64_t min_len, int64_t min_pairs) {
   const int k = knob(VSEL_KNOB_ATTN_XCD_QUEUE);
   return k >= 0 ? k : ((max_seqlen >= min_len && n_pairs >= min_pairs) ? 1 : 0);
+}
+bool attn_static_deal(int64_t n_items, int64_t slots, bool auto_ok, int rounds20) {
+  if (n_items <= slots) return false;
+  const int k = knob(VSEL_KNOB_ATTN_STATIC);
+  return k >= 0 ? k != 0 : (auto_ok && 20 * n_items <= rounds20 * slots);
 }
 }  // namespace vsel
 

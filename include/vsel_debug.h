@@ -56,7 +56,10 @@ typedef enum vsel_debug_knob {
                                      2 G + b, ... of the heaviest-first list: no atomic, no hand-over barriers, the next item known in advance):
                                      -1 by item count and sequence length (default), 0 / 1 force; env VSEL_ATTN_STATIC; placement only,
                                      outputs bit-identical */
-  VSEL_KNOB_COUNT = 18
+  VSEL_KNOB_ATTN_SKIP_EMPTY = 18, /* single work queue on ragged batches: the shared counter jumps over runs of EMPTY items (levels a shorter
+                                     sequence does not reach) instead of handing each one out: 1 (default) / 0; env VSEL_ATTN_SKIP_EMPTY;
+                                     placement only, outputs bit-identical */
+  VSEL_KNOB_COUNT = 19
 } vsel_debug_knob;
 
 /* Set knob to value (clamped to the knob's range).  *previous (may be NULL) receives the value it had.

@@ -205,6 +205,29 @@ def test_static_deal_of_work_items_does_not_change_results(ops):
                     assert torch.equal(a, b), (lens, form, mode)
 
 
+def test_queue_skipping_empty_runs_does_not_change_results(ops):
+    """Ragged batches on the single work queue: the shared counter jumping over runs of empty items (knob attn_skip_empty = 1, default;
+    attn_common.h queue_skip_empty_run) or every item handed out (0): placement only -- forward output, log-sum-exp, dQ, dK, dV
+    bit-identical in the 32-rows-per-wave kernels (both dK / dV item forms) and the 64-rows forms, on a bimodal batch (long empty runs),
+    on short runs and when the LAST sequences are the short ones (runs that end a level)."""
+    from visionselector_amd import _native as N
+    for lens, hq, hkv in (([300] * 30 + [1800] * 6, 8, 2), ([1500, 90, 700, 64, 1100, 257, 40, 1024, 12, 777, 1300, 130], 28, 4),
+                          ([2100] + [150] * 70, 4, 4)):
+        res = {}
+        for mode in (0, 1):
+            for form in ("w4", "w4split", "r64"):
+                new = int(form == "r64")
+                with N.debug_knob(attn_skip_empty=mode, attn_static=0, attn_xcd_queue=0, attn_bwd_waves=4, attn_bwd_split=int(form == "w4split"),
+                                  attn_bwd_dq64=new, attn_bwd_dkdv64=new, attn_rows64=new):
+                    _, out, lse, g = _run(ops, lens, hq, hkv, True, seed=29)
+                    res[(mode, form)] = (out, lse) + tuple(g)
+        for form in ("w4", "w4split", "r64"):
+            for a, b in zip(res[(0, form)], res[(1, form)]):
+                assert torch.equal(a, b), (lens[:3], form)
+        for a, b in zip(res[(0, "w4")], res[(0, "r64")]):
+            assert torch.equal(a, b)
+
+
 def test_flash_attn_compat_functions(ops):
     """flash_attn_varlen_func / flash_attn_func with the flash-attn call shapes: same packing (differentiable), different
     query / key packings (forward only, bottom-right causal) and the batched dense form."""

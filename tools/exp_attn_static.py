@@ -13,7 +13,7 @@ def ragged(n, lo, hi, seed):
 cases = [(f"{n}x{l}", [l] * n) for n, l in ((3, 524), (4, 524), (7, 524), (9, 524), (5, 1100), (3, 1500))]
 cases += [(f"c5_{n}_{sd}", ragged(n, 131, 947, sd)) for n in (3, 4, 5, 6) for sd in (1, 2)]
 cases += [(f"mix_{n}_{sd}", ragged(n, 64, 2040, sd)) for n in (2, 3) for sd in (1, 2)]
-MODES = (0, 1, 2)
+MODES = (0, 1, 1)        # (the third column was the static deal + L2 prefetch of the next item's Q rows, removed: profiles/r04_attn_static.txt)
 for name, lens in cases:
     g = torch.Generator(device="cuda").manual_seed(7)
     T, L = sum(lens), max(lens)

@@ -202,14 +202,22 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
   //     one tile-round per query tile less in all.  Pays when the grid is throughput-bound (many items per workgroup: packed
   //     batches of compressed sequences), not when one sequence's longest chain is the run time.
   int q0, q_lim;                        // this tile's queries: [q0, min(q0 + kBlockQ, q_lim))
+  // an empty item of the single queue (a level this sequence does not reach): move the shared counter past the whole empty run
+  auto skip_run = [&]() {
+    if constexpr (!PACK)
+      if (slot >= 0 && (slot & 0x200) && head == 0)            // (one scan per empty (level, sequence) group, by whoever drew its first head)
+        queue_skip_empty_run(wq.counters, tid, cu, n_seq, hq, qtile, seq, [&](int level, int ql) {
+          return TAIL ? ql - level * kBlockQ > 0 : (q_tiles - 1 - level) * kBlockQ < ql;
+        });
+  };
   if constexpr (TAIL) {
     q_lim = qlen - qtile * kBlockQ;
-    if (q_lim <= 0) continue;
+    if (q_lim <= 0) { skip_run(); continue; }
     q0 = max(0, q_lim - kBlockQ);
   } else {
     q_lim = qlen;
     q0 = (PACK ? 0 : q_tiles - 1 - qtile) * kBlockQ;
-    if (q0 >= qlen) continue;
+    if (q0 >= qlen) { skip_run(); continue; }
   }
   // keys: same rows as the queries (prefill), or their own length / base / page table (KV cache).  Causal masking is
   // bottom-right aligned when the key sequence is longer: query i sees keys <= i + (klen - qlen)  (flash-attn >= 2.1).
@@ -711,6 +719,7 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
     // forward: +1.4 ... +3 % from 2048 tokens x 16 pairs (16 x 4096 982 -> 1011 TFLOP/s, 4 x 8192 1070 -> 1099, 16 x 2368 810 -> 822,
     // 4 x 2368 746 -> 760); one sequence (4 pairs) -12 %, 524-token sequences -40 %: those keep the single queue
     if (!pack && attn_use_xcd_queues(max_seqlen_q, n_seq * hkv, 2048, 16)) slot |= 0x100;
+    else if (!pack && n_seq > 1 && knob(VSEL_KNOB_ATTN_SKIP_EMPTY) != 0) slot |= 0x200;
   }
   const dim3 grid((unsigned)std::min<int64_t>(n_items, slots));
   const float sl2 = scale * 1.4426950408889634f;

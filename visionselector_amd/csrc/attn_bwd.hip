@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
   XcdQueue wq{&g_bwd_counter[8 * max(slot, 0)], n_seq * hkv, q_tiles * rep_q, xcc_id(), 0};
   for (int round = 0;; ++round) {
     int t_end, head, seq;
-    if (slot < 0 || !xcd_local) {
+    if (slot < 0 || xcd_local != 1) {
       if (slot == -1 && round > 0) return;
       const int item = slot == -2 ? static_deal_item(round) : slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
       if (item < 0 || item >= n_items) return;
@@ -116,14 +116,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     // (one or two key tiles) instead of the last (len / 64 of them for a handful of queries) -- attn.hip, TAIL; a query's
     // arithmetic does not depend on its tile: bit-identical dQ.
     int q0, q_lim;                                               // this tile's queries: [q0, min(q0 + 128, q_lim))
+    // an empty item of the single queue: one workgroup per empty (level, sequence) group moves the counter past the empty run (attn_common.h)
+    auto skip_run = [&]() {
+      if (slot >= 0 && xcd_local == 2 && head == 0)
+        queue_skip_empty_run(wq.counters, tid, cu, n_seq, hq, t_end, seq, [&](int level, int ql) {
+          return causal ? ql - level * 128 > 0 : (q_tiles - 1 - level) * 128 < ql;
+        });
+    };
     if (causal) {
       q_lim = len - t_end * 128;
-      if (q_lim <= 0) continue;
+      if (q_lim <= 0) { skip_run(); continue; }
       q0 = max(0, q_lim - 128);
     } else {
       q_lim = len;
       q0 = (q_tiles - 1 - t_end) * 128;
-      if (q0 >= len) continue;
+      if (q0 >= len) { skip_run(); continue; }
     }
     const int kvh = head / (hq / hkv);
     const int my_q = min(q0 + wave * 32 + j, q_lim - 1);
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
   XcdQueue wq{&g_bwd_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * (SPLIT ? rep : 1), xcc_id(), 0};
   for (int round = 0;; ++round) {
     int kblock, hsel, seq;
-    if (slot < 0 || !xcd_local) {
+    if (slot < 0 || xcd_local != 1) {
       if (slot == -1 && round > 0) return;
       const int item = slot == -2 ? static_deal_item(round) : slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
       if (item < 0 || item >= n_items) return;
@@ -369,7 +376,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
     const int qs = cu[seq];
     const int len = cu[seq + 1] - qs;
     const int k0 = kblock * 128;
-    if (k0 >= len) continue;
+    if (k0 >= len) {      // empty item of the single queue: move the counter past the empty run (attn_common.h), once per (level, sequence) group
+      if (slot >= 0 && xcd_local == 2 && hsel == 0)
+        queue_skip_empty_run(wq.counters, tid, cu, n_seq, heads_per_item_dim, kblock, seq, [&](int level, int ql) { return level * 128 < ql; });
+      continue;
+    }
     const int kw0 = k0 + 32 * wave;
     const int my_k = min(kw0 + j, len - 1);
     const bool k_valid = (kw0 + j) < len;
@@ -617,7 +628,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
   XcdQueue wq{&g_bwd_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * (SPLIT ? rep : 1), xcc_id(), 0};
   for (int round = 0;; ++round) {
     int kblock, hsel, seq;
-    if (slot < 0 || !xcd_local) {
+    if (slot < 0 || xcd_local != 1) {
       if (slot == -1 && round > 0) return;
       const int item = slot == -2 ? static_deal_item(round) : slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
       if (item < 0 || item >= n_items) return;
@@ -636,7 +647,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
     const int qs = cu[seq];
     const int len = cu[seq + 1] - qs;
     const int k0 = kblock * 128;
-    if (k0 >= len) continue;
+    if (k0 >= len) {      // empty item of the single queue: move the counter past the empty run (attn_common.h), once per (level, sequence) group
+      if (slot >= 0 && xcd_local == 2 && hsel == 0)
+        queue_skip_empty_run(wq.counters, tid, cu, n_seq, heads_per_item_dim, kblock, seq, [&](int level, int ql) { return level * 128 < ql; });
+      continue;
+    }
     const int kw0 = k0 + 32 * kb;
     const int my_k = min(kw0 + j, len - 1);
     const bool k_valid = (kw0 + j) < len;
@@ -995,8 +1010,10 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
   // dQ: on from 2048 tokens x 32 pairs (16 x 2368 1078 -> 1041 us, 16 x 4096 2912 -> 2866; 4 x 2368 +8 %, 4 x 8192 +0.7 % stay off);
   // dK / dV: from 4096 tokens x 16 pairs (16 x 4096 3950 -> 3865 us, 4 x 8192 3820 -> 3810; 16 x 2368 -- 19 key blocks per pair, a
   // ragged fit on 32 CUs -- +8.5 % stays off)
-  const int xcd_local_dq = attn_use_xcd_queues(max_seqlen, n_seq * hkv, 2048, 32);
-  const int xcd_local_dkdv = attn_use_xcd_queues(max_seqlen, n_seq * hkv, 4096, 16);
+  // (2 = single queue whose counter jumps over runs of empty items: ragged batches, knob attn_skip_empty)
+  const int skip_empty = n_seq > 1 && knob(VSEL_KNOB_ATTN_SKIP_EMPTY) != 0 ? 2 : 0;
+  const int xcd_local_dq = attn_use_xcd_queues(max_seqlen, n_seq * hkv, 2048, 32) ? 1 : skip_empty;
+  const int xcd_local_dkdv = attn_use_xcd_queues(max_seqlen, n_seq * hkv, 4096, 16) ? 1 : skip_empty;
   // dQ first: it also leaves D = rowsum(dO * O) and the exp2-domain log-sum-exp in the workspace for the dK / dV kernel
   const int g_dq64 = knob(VSEL_KNOB_ATTN_BWD_DQ64);
   if (g_dq64 == 1 || (g_dq64 < 0 && kDq64FromTokens > 0 && max_seqlen >= kDq64FromTokens)) {

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
   XcdQueue wq{&g_dkdv64_work_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * (split ? rep : 1), xcc_id(), 0};
   for (int round = 0;; ++round) {
     int kblock, hsel, seq;
-    if (slot < 0 || !xcd_local) {
+    if (slot < 0 || xcd_local != 1) {
       if (slot == -1 && round > 0) return;
       const int item = slot == -2 ? static_deal_item(round) : slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
       if (item < 0 || item >= n_items) return;
@@ -71,7 +71,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
     const int qs = cu[seq];
     const int len = cu[seq + 1] - qs;
     const int k0 = kblock * 128;
-    if (k0 >= len) continue;
+    if (k0 >= len) {      // empty item of the single queue: move the counter past the empty run (attn_common.h), once per (level, sequence) group
+      if (slot >= 0 && xcd_local == 2 && hsel == 0)
+        queue_skip_empty_run(wq.counters, tid, cu, n_seq, heads_dim, kblock, seq, [&](int level, int ql) { return level * 128 < ql; });
+      continue;
+    }
     const int kw0 = __builtin_amdgcn_readfirstlane(k0 + 32 * wave);
     const int my_k = min(kw0 + j, len - 1);
     const int kvalid = (kw0 + j) < len ? 1 : 0;

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(
   XcdQueue wq{&g_dq64_work_counter[8 * max(slot, 0)], n_seq * hkv, q_tiles * rep, xcc_id(), 0};
   for (int round = 0;; ++round) {
     int t_end, head, seq;
-    if (slot < 0 || !xcd_local) {
+    if (slot < 0 || xcd_local != 1) {
       if (slot == -1 && round > 0) return;
       const int item = slot == -2 ? static_deal_item(round) : slot < 0 ? (int)blockIdx.x : global_queue_next(wq.counters, n_items, &s_item, tid);
       if (item < 0 || item >= n_items) return;
@@ -72,14 +72,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(
     const int len = cu[seq + 1] - qs;
     // query tiles aligned to the END of the sequence under the causal mask (the partial tile is the cheap first one), as attn_bwd_dq_kernel
     int q0, q_lim;
+    auto skip_run = [&]() {      // empty item of the single queue: move the counter past the empty run (attn_common.h)
+      if (slot >= 0 && xcd_local == 2 && head == 0)
+        queue_skip_empty_run(wq.counters, tid, cu, n_seq, hq, t_end, seq, [&](int level, int ql) {
+          return causal ? ql - level * kBlockQ > 0 : (q_tiles - 1 - level) * kBlockQ < ql;
+        });
+    };
     if (causal) {
       q_lim = len - t_end * kBlockQ;
-      if (q_lim <= 0) continue;
+      if (q_lim <= 0) { skip_run(); continue; }
       q0 = max(0, q_lim - kBlockQ);
     } else {
       q_lim = len;
       q0 = (q_tiles - 1 - t_end) * kBlockQ;
-      if (q0 >= len) continue;
+      if (q0 >= len) { skip_run(); continue; }
     }
     const int kvh = head / rep;
     const int wave_qmin = q0 + 64 * wave;

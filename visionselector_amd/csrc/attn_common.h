@@ -125,6 +125,38 @@ __device__ __forceinline__ int static_deal_item(int round) {
   const int g = (int)gridDim.x, b = (int)blockIdx.x;
   return round * g + ((round & 1) ? g - 1 - b : b);
 }
+// The single queue on RAGGED batches.  The item list is (level, sequence, head) with `width` heads per (level, sequence) and as many
+// levels as the LONGEST sequence has tiles, so a shorter sequence owns empty items at the levels it does not reach -- 40 % of the list
+// for prompts of 131 ... 947 tokens -- and every empty item costs the workgroup that draws it an atomic round trip, two barriers and the
+// cu_seqlens loads.  A workgroup that has drawn an empty item therefore moves the shared counter past the whole empty RUN before it draws
+// again: the 64 lanes of wave 0 look at the following sequences of that level (ballot) and one atomicMax sets the counter to the first item
+// with work (only empty items are ever skipped: everything below the counter's old value was taken, everything from the drawn item up to
+// the new value is empty).  `nonempty(level, qlen)` is the kernel's own rule.  Placement only.  (Checking BEFORE handing an item over --
+// the cu loads in front of every draw's barrier -- was measured first: -3 ... -9 % on prompts of 131 ... 947 tokens, the extra round trip
+// sits on every item's critical path.)
+// Lane 0's atomicMax is ONE asm statement with EXEC narrowed inside: under `if (tid == 0)` in a loop the structurizer let lane 0 leave
+// for its atomic while lanes 1 .. 63 ran on without it -- ballot / readfirstlane then saw a wave without lane 0 and never terminated;
+// with per-lane neutral operands the atomic optimizer emits a 64-step readlane loop.
+__device__ __forceinline__ void lane0_atomic_max(int* p, int v) {
+  uint64_t save;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_smax %1, %2, off\n\ts_mov_b64 exec, %0" : "=&s"(save) : "v"(p), "v"(v) : "memory");
+}
+template <class NonEmpty>
+__device__ __forceinline__ void queue_skip_empty_run(int* counter, int tid, const int32_t* __restrict__ cu, int n_seq, int width, int level,
+                                                     int seq, NonEmpty nonempty) {
+  if (tid < 64) {
+    int s0 = seq + 1;
+    unsigned long long m;
+    for (;;) {
+      const int s = s0 + tid;
+      const bool ne = s < n_seq && nonempty(level, cu[s + 1] - cu[s]);
+      m = __ballot(ne);
+      if (m != 0 || s0 + 64 >= n_seq) break;
+      s0 += 64;
+    }
+    lane0_atomic_max(counter, m != 0 ? (level * n_seq + s0 + (int)__builtin_ctzll(m)) * width : (level + 1) * n_seq * width);
+  }
+}
 __device__ __forceinline__ int xcc_id() {
   int v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));

@@ -48,6 +48,7 @@ constexpr KnobSpec kKnobs[VSEL_KNOB_COUNT] = {
     {"VSEL_ATTN_BWD_DQ64", -1, -1, 1},   // VSEL_KNOB_ATTN_BWD_DQ64
     {"VSEL_ATTN_BWD_DKDV64", -1, -1, 1}, // VSEL_KNOB_ATTN_BWD_DKDV64
     {"VSEL_ATTN_STATIC", -1, -1, 1},     // VSEL_KNOB_ATTN_STATIC
+    {"VSEL_ATTN_SKIP_EMPTY", 1, 0, 1},   // VSEL_KNOB_ATTN_SKIP_EMPTY
 };
 int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 int knob_default(int id) {

@@ -354,6 +354,57 @@ def test_dkdv64_pass_is_bit_identical_to_the_four_wave_dkdv_kernel(lens, hq, hkv
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("lens,hq,hkv", [([1100, 1300], 28, 4), ([1025, 129, 64, 2000], 8, 2), ([1500], 16, 2), ([1100, 700], 32, 8)])
+def test_dkdv_group_in_parts_matches_the_formula_and_the_other_item_forms(lens, hq, hkv):
+    """dK / dV with a group's q heads cut in 2 / 3 / 4 PARTS (knob attn_bwd_split = k; csrc/attn_bwd_dkdv64.hip: a part = one item that
+    loops over its heads and leaves an fp32 partial in the rows of its first head, attn_bwd_group_sum_kernel adds the parts in ascending
+    order): against the fp64 eager formula at the backward test's bound, dQ bit-identical to the other forms (the dQ pass does not
+    depend on it), dK / dV within a bf16 rounding of the unsplit form, reruns bit-identical, ragged key blocks / rep = 4, 7, 8."""
+    import torch
+    from visionselector_amd import _native as N, ops
+    g = torch.Generator(device="cuda").manual_seed(31 + len(lens))
+    T = sum(lens)
+    q = torch.randn(T, hq, 128, device="cuda", generator=g).bfloat16()
+    k = torch.randn(T, hkv, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(T, hkv, 128, device="cuda", generator=g).bfloat16()
+    do = torch.randn(T, hq, 128, device="cuda", generator=g).bfloat16()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
+    out, lse = ops.varlen_attn_fwd_lse(q, k, v, cu, max(lens))
+    refs, o = [], 0
+    for L in lens:
+        sl = slice(o, o + L)
+        qq, kk, vv = (t[sl].double().transpose(0, 1).requires_grad_(True) for t in (q, k, v))
+        kr, vr = (t.repeat_interleave(hq // hkv, 0) for t in (kk, vv))
+        sc = qq @ kr.transpose(1, 2) / 128 ** 0.5
+        sc = sc.masked_fill(torch.ones(L, L, device="cuda", dtype=torch.bool).triu(1), float("-inf"))
+        (torch.softmax(sc, -1) @ vr).backward(do[sl].double().transpose(0, 1))
+        refs.append((sl, kk.grad.transpose(0, 1), vv.grad.transpose(0, 1)))
+        o += L
+    res = {}
+    for split in (0, 1, 2, 3, 4):
+        with N.debug_knob(attn_bwd_split=split, attn_bwd_dkdv64=1):
+            N.profile_start()
+            res[split] = ops.varlen_attn_bwd(do, q, k, v, out, lse, cu, max(lens))
+            prof = N.profile_stop()
+            assert "attn_bwd_dkdv64_kernel" in prof and ("attn_bwd_group_sum_kernel" in prof) == bool(split), prof
+            again = ops.varlen_attn_bwd(do, q, k, v, out, lse, cu, max(lens))
+            for a, b in zip(res[split], again):
+                assert torch.equal(a, b)
+        assert torch.equal(res[split][0], res[0][0])
+        for sl, rk, rv in refs:
+            for got, ref in ((res[split][1], rk), (res[split][2], rv)):
+                assert ((got[sl].double() - ref).abs().max() / ref.abs().max()).item() <= 2 ** -6
+        for i in (1, 2):
+            assert float((res[split][i].float() - res[0][i].float()).abs().max()) <= 2 ** -7 * float(res[0][i].float().abs().max())
+    if hq // hkv >= 4:          # by itself: these grids have less than a round or two of unsplit items -> per-head or part form (partials + group sum)
+        with N.debug_knob(attn_bwd_dkdv64=1):      # (the per-head form below 2048 tokens is otherwise the 8-wave kernel's: another fp32 association)
+            N.profile_start()
+            auto = ops.varlen_attn_bwd(do, q, k, v, out, lse, cu, max(lens))
+            prof = N.profile_stop()
+        assert "attn_bwd_group_sum_kernel" in prof, prof
+        assert any(all(torch.equal(a, b) for a, b in zip(auto, res[sp])) for sp in (1, 2, 3, 4))
+
+
 def test_long_sequences_take_the_64_row_passes_by_default_and_match_the_oracle_bound():
     """From 1024 tokens in the longest sequence the library picks attn_bwd_dq64_kernel and attn_bwd_dkdv64_kernel (the per-q-head
     split form of the latter from 2048) by itself; gradients against the fp64 eager formula on the bf16-rounded inputs, at the backward test's bound."""

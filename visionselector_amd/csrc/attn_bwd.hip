@@ -901,7 +901,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
 // One thread per 4 consecutive d.
 __global__ __launch_bounds__(256) void attn_bwd_group_sum_kernel(const float* __restrict__ dk_part, const float* __restrict__ dv_part,
                                                                  int64_t total, int hq, int hkv, float scale,
-                                                                 uint16_t* __restrict__ dk, uint16_t* __restrict__ dv) {
+                                                                 uint16_t* __restrict__ dk, uint16_t* __restrict__ dv, int step) {
+  // step = q heads per item of the launch in front: partial rows exist for heads 0, step, 2 step, ... of a group
   const int rep = hq / hkv;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // over total * hkv * 32
   if (idx >= total * hkv * 32) return;
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(256) void attn_bwd_group_sum_kernel(const float* __
   const int g = (int)(tg % hkv);
   const int64_t t = tg / hkv;
   f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-  for (int r = 0; r < rep; ++r) {
+  for (int r = 0; r < rep; r += step) {
     const int64_t o = ((t * hq + g * rep + r) * kD) + 4 * c;
     a += *reinterpret_cast<const f32x4*>(dk_part + o);
     b += *reinterpret_cast<const f32x4*>(dv_part + o);
@@ -941,6 +942,7 @@ extern "C" int vsel_debug_read_bwd_trace(unsigned long long* out) {
 // 2 x 2368 (152) 377 / 552 / 369, 8 x 524 (160) 175 / 173 / 165, 8 x 1100 (288) 443 / 383 / 438, 4 x 2368 (304) 728 / 738 / 725,
 // 3 x 4096 (384) 1426 / 1398 / 1414, 6 x 2368 (456) 1086 / 940 / 1099: the crossover is below 288 items now.
 static constexpr int64_t kSplitBelowItems = 288;
+static constexpr int64_t kPartItemsTarget = 400;     // (dkdv64) groups are cut in the fewest parts that give this many items
 // knob VSEL_KNOB_ATTN_BWD_SPLIT (include/vsel_debug.h): -1 = choose by item count, 0 / 1 = force (tests)
 
 namespace vsel { namespace bwd {
@@ -949,7 +951,7 @@ int dq64_launch(hipStream_t st, const void* q, const void* k, const void* v, con
                 int causal, void* dq, int xcd_local);          // attn_bwd_dq64.hip
 int dkdv64_launch(hipStream_t st, const void* q, const void* k, const void* v, const void* dout, const float* lse2, const float* dvec,
                   const int32_t* cu, int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv, float scale, int causal, void* dk, void* dv,
-                  float* dk_part, float* dv_part, int xcd_local);   // attn_bwd_dkdv64.hip (dk_part != NULL: the per-q-head split form)
+                  float* dk_part, float* dv_part, int split, int xcd_local);   // attn_bwd_dkdv64.hip (split = q heads per item, 0 = the group)
 } }
 
 // the 64-rows-per-wave dQ pass from this many tokens in the longest sequence (same-process A/B, tools/exp_dq64_shapes.py,
@@ -958,12 +960,29 @@ constexpr int64_t kDq64FromTokens = 1024;         // (profiles/r04_dq64_shapes.t
 constexpr int64_t kDkdv64FromTokens = 1024;       // q heads inside the item (profiles/r04_dkdv64_shapes.txt: +4 ... +8 % at 1100, +15 ... +22 % from 2368, level at 524)
 constexpr int64_t kDkdv64SplitFromTokens = 2048;  // per-q-head split form (few items): +5 % at 1 x 2368, +12 % at 1 x 4096, +15 % at 1 x 8192
 
-static bool bwd_use_split(int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv) {
-  if (hq == hkv) return false;
+// -> q heads per dK / dV item: 0 = the whole group inside the item, 1 = one q head per item, k > 1 = the group in ceil(rep / k) PARTS (the
+// one-wave-per-SIMD kernel only).  The unsplit grid is causal-imbalanced while it has fewer than ~2 rounds of items (heaviest item / mean
+// load = 128 / (n_seq * key blocks)): the heaviest item IS the run time.  Splitting a group's heads over P items shortens it P x at the
+// price of P fp32 partial rows per key and the group-sum launch; measured (tools/exp_dkdv_parts.py, profiles/r04_dkdv_parts.txt; us, group /
+// per head / best part form): 3 x 1100 186 / 115 / 95 (4 parts), 4 x 1100 183 / 143 / 114 (4), 5 x 1100 183 / 178 / 137 (2 - 3), 6 x 1100
+// 187 / 215 / 149 (2), 4 x 2000 326 / 349 / 260 (2), 4 x 2368 364 / 401 / 318 (2), 3 x 4096 693 / 742 / 633 (2); from 400 items (320 below
+// 2048 tokens) the unsplit form wins, below ~100 the per-head form.  Rule: the fewest parts that give >= kPartItemsTarget items.
+static int bwd_split_heads(int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv) {
+  if (hq == hkv) return 0;
+  const int rep = (int)(hq / hkv);
   const int forced = knob(VSEL_KNOB_ATTN_BWD_SPLIT);
-  if (forced >= 0) return forced != 0;
-  return cdiv(max_seqlen, 128) * hkv * n_seq < kSplitBelowItems;
+  const int g_dkdv64 = knob(VSEL_KNOB_ATTN_BWD_DKDV64);
+  const bool parts_ok = rep >= 4 && g_dkdv64 != 0 && (g_dkdv64 == 1 || max_seqlen >= kDkdv64FromTokens);   // (the kernel that has the part form)
+  if (forced >= 0) return forced >= 2 ? (parts_ok ? (rep + forced - 1) / forced : 0) : forced;       // (forced k >= 2: k parts per group)
+  const int64_t items = cdiv(max_seqlen, 128) * hkv * n_seq;
+  if (!parts_ok) return items < kSplitBelowItems ? 1 : 0;
+  if (items >= kPartItemsTarget) return 0;
+  const int parts = (int)cdiv(kPartItemsTarget, items);
+  if (parts > 4) return 1;
+  if (parts == 2 && items >= 320 && max_seqlen < 2048) return 0;
+  return (rep + parts - 1) / parts;                 // (1 when rep <= parts: the per-head form)
 }
+static bool bwd_use_split(int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv) { return bwd_split_heads(n_seq, max_seqlen, hq, hkv) != 0; }
 
 extern "C" size_t vsel_varlen_attn_bwd_workspace_bytes(int64_t total, int64_t hq, int64_t hkv, int64_t n_seq, int64_t max_seqlen) {
   if (total < 1 || hq < 1 || hkv < 1 || n_seq < 1 || max_seqlen < 1) return 0;
@@ -1035,17 +1054,18 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
   }
   const int g_dkdv64 = knob(VSEL_KNOB_ATTN_BWD_DKDV64);
   {
-    const bool split = bwd_use_split(n_seq, max_seqlen, hq, hkv);
-    const bool dkdv64 = g_dkdv64 == 1 || (g_dkdv64 < 0 && max_seqlen >= (split ? kDkdv64SplitFromTokens : kDkdv64FromTokens));
+    const int split_heads = bwd_split_heads(n_seq, max_seqlen, hq, hkv);
+    const bool split = split_heads != 0;
+    const bool dkdv64 = g_dkdv64 == 1 || (g_dkdv64 < 0 && max_seqlen >= (split_heads == 1 ? kDkdv64SplitFromTokens : kDkdv64FromTokens));
     const int k_blocks = (int)cdiv(max_seqlen, 128);
-    const int64_t n_items = (int64_t)k_blocks * (split ? hq : hkv) * n_seq;
+    const int64_t n_items = (int64_t)k_blocks * (split ? hq : hkv) * n_seq;             // (the 4- / 8-wave kernels: per-head items only)
     if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
     float* dk_part = split ? (float*)((char*)workspace + 2 * d_bytes) : nullptr;
     float* dv_part = split ? dk_part + (size_t)rows * bwd::kD : nullptr;
     if (dkdv64) {
       // long sequences: one wave per SIMD with the unit pipeline (attn_bwd_dkdv64.hip), either item form; dK / dV as the 4-wave kernel's
       if (int rc = bwd::dkdv64_launch(st, q, k, v, dout, lse2, dvec, cu_seqlens, n_seq, max_seqlen, hq, hkv, scale, causal, dk, dv, dk_part,
-                                      dv_part, xcd_local_dkdv))
+                                      dv_part, split_heads, xcd_local_dkdv))
         return rc;
     } else {
       int slot;
@@ -1067,7 +1087,7 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
     if (split) {
       // rows past a sequence's end never exist in the packed layout, so every (t, h) partial row was written
       hipLaunchKernelGGL(bwd::attn_bwd_group_sum_kernel, dim3((unsigned)cdiv(total * hkv * 32, 256)), dim3(256), 0, st, dk_part,
-                         dv_part, total, (int)hq, (int)hkv, scale, (uint16_t*)dk, (uint16_t*)dv);
+                         dv_part, total, (int)hq, (int)hkv, scale, (uint16_t*)dk, (uint16_t*)dv, split_heads);
       VSEL_AFTER_LAUNCH(st, "attn_bwd_group_sum_kernel");
     }
   }

@@ -40,16 +40,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
     int k_blocks, int n_seq, int slot, int xcd_local) {
   __shared__ __attribute__((aligned(1024))) char smem[VSEL_DKDV64_LDS_BYTES + 16];
   int& s_item = *reinterpret_cast<int*>(smem + VSEL_DKDV64_LDS_BYTES);
-  // split (few items: attn_bwd.hip bwd_use_split): item = (key block, Q head, sequence) writing its fp32 partial [T, hq, 128];
-  // attn_bwd_group_sum_kernel adds the heads of a group -- the item numbering of attn_bwd_dkdv_kernel<SPLIT>
-  const int heads_dim = split ? hq : hkv;
+  // split = q heads per item (attn_bwd.hip bwd_split_heads; 0: the whole group inside the item).  1 (few items): item = (key block, Q head,
+  // sequence) writing its fp32 partial [T, hq, 128], attn_bwd_group_sum_kernel adds the heads of a group -- the item numbering of
+  // attn_bwd_dkdv_kernel<SPLIT>.  k > 1 (an unsplit grid of 1 - 2 rounds, where the heaviest item is the run time): a group's heads in
+  // ceil(rep / k) PARTS, each part one item that loops over its heads and leaves its fp32 partial in the rows of its FIRST head; the group sum
+  // adds the parts' rows in ascending order.
+  const int parts = split ? (hq / hkv + split - 1) / split : 1;
+  const int heads_dim = hkv * parts;
   const int n_items = k_blocks * heads_dim * n_seq;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
   const int lds_base = (int)lds_u32(smem);
   const int rep = hq / hkv;
-  XcdQueue wq{&g_dkdv64_work_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * (split ? rep : 1), xcc_id(), 0};
+  XcdQueue wq{&g_dkdv64_work_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * parts, xcc_id(), 0};
   for (int round = 0;; ++round) {
     int kblock, hsel, seq;
     if (slot < 0 || xcd_local != 1) {
@@ -65,9 +69,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
       const int pair = item / wq.per_pair, r = item % wq.per_pair;
       seq = pair / hkv;
       kblock = r % k_blocks;
-      hsel = split ? (pair % hkv) * rep + r / k_blocks : pair % hkv;
+      hsel = (pair % hkv) * parts + r / k_blocks;
     }
-    const int kvh = split ? hsel / rep : hsel;
+    const int kvh = hsel / parts;
+    const int first_head = kvh * rep + (hsel % parts) * split;                                  // (split == 0: parts == 1, the group's first head)
+    const int n_heads = split ? min(split, rep - (hsel % parts) * split) : rep;
     const int qs = cu[seq];
     const int len = cu[seq + 1] - qs;
     const int k0 = kblock * 128;
@@ -81,8 +87,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
     const int kvalid = (kw0 + j) < len ? 1 : 0;
     const int q_begin = causal ? k0 : 0;                         // a multiple of 128, hence of the 64-query tile
     const int tiles_per_head = (len - q_begin + kTileK - 1) / kTileK;
-    const int n_iter = __builtin_amdgcn_readfirstlane(split ? tiles_per_head : tiles_per_head * rep);
-    const int head0 = __builtin_amdgcn_readfirstlane(split ? hsel : kvh * rep);
+    const int n_iter = __builtin_amdgcn_readfirstlane(tiles_per_head * n_heads);
+    const int head0 = __builtin_amdgcn_readfirstlane(first_head);
 
     const void* const qbase = uniform_ptr(q + (int64_t)qs * hq * kD);
     const void* const dobase = uniform_ptr(dout + (int64_t)qs * hq * kD);
@@ -91,10 +97,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
     const int64_t ro = ((int64_t)(qs + my_k) * hkv + kvh) * kD;
     const uint16_t* const kptr = k + ro + 8 * hh;
     const uint16_t* const vptr = v + ro + 8 * hh;
-    const int64_t po = ((int64_t)(qs + my_k) * hq + hsel) * kD + 4 * hh;
+    const int64_t po = ((int64_t)(qs + my_k) * hq + first_head) * kD + 4 * hh;
     void* const dkptr = split ? (void*)(dk_part + po) : (void*)(dk + ro + 4 * hh);
     void* const dvptr = split ? (void*)(dv_part + po) : (void*)(dv + ro + 4 * hh);
-    const int split_u = __builtin_amdgcn_readfirstlane(split);
+    const int split_u = __builtin_amdgcn_readfirstlane(split != 0 ? 1 : 0);
     const int qrs2 = hq * kD * 2, fstride = hq * 4;
     const int len_u = __builtin_amdgcn_readfirstlane(len), qbeg_u = __builtin_amdgcn_readfirstlane(q_begin);
     asm volatile(VSEL_DKDV64_ASM_TEXT
@@ -112,10 +118,10 @@ namespace bwd {
 // attn_bwd.hip's launcher hands the dK / dV pass over here (knob attn_bwd_dkdv64) when the group's q heads are looped inside an item
 int dkdv64_launch(hipStream_t st, const void* q, const void* k, const void* v, const void* dout, const float* lse2, const float* dvec,
                   const int32_t* cu, int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv, float scale, int causal, void* dk, void* dv,
-                  float* dk_part, float* dv_part, int xcd_local) {
-  const int split = dk_part != nullptr;                          // the caller runs attn_bwd_group_sum_kernel behind a split launch
+                  float* dk_part, float* dv_part, int split, int xcd_local) {
+  // split = q heads per item (0: the group inside the item); the caller runs attn_bwd_group_sum_kernel behind a split launch
   const int k_blocks = (int)cdiv(max_seqlen, 128);
-  const int64_t n_items = (int64_t)k_blocks * (split ? hq : hkv) * n_seq;
+  const int64_t n_items = (int64_t)k_blocks * hkv * (split ? cdiv(hq / hkv, split) : 1) * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
   static std::atomic<unsigned> next_slot{0};      // (host threads may launch concurrently: a slot per launch, 64 in rotation)
   int slot = -1;

@@ -38,7 +38,7 @@ constexpr KnobSpec kKnobs[VSEL_KNOB_COUNT] = {
     {nullptr, 2, 0, 2},                // VSEL_KNOB_ATTN_PACK
     {nullptr, 2, 0, 2},                // VSEL_KNOB_ATTN_SPLIT
     {nullptr, 1, 0, 1},                // VSEL_KNOB_ATTN_SPLIT_Q64
-    {nullptr, -1, -1, 1},              // VSEL_KNOB_ATTN_BWD_SPLIT
+    {nullptr, -1, -1, 4},              // VSEL_KNOB_ATTN_BWD_SPLIT
     {"VSEL_SPLICE_FUSED", 1, 0, 1},    // VSEL_KNOB_LIS_SPLICE_FUSED
     {"VSEL_ATTN_BWD_WAVES", 8, 4, 8},  // VSEL_KNOB_ATTN_BWD_WAVES
     {nullptr, -1, -1, 1},              // VSEL_KNOB_ATTN_TAIL_FIRST

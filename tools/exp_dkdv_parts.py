@@ -13,6 +13,13 @@ def ragged(n, lo, hi, seed):
 
 cases = [(f"{n}x{l}", [l] * n) for n, l in ((2, 1100), (3, 1100), (4, 1100), (5, 1100), (6, 1100), (7, 1100), (9, 1100), (2, 2000), (3, 2000), (4, 2000), (1, 2368), (2, 2368), (3, 2368),
                                             (1, 3000), (1, 4096), (2, 4096), (1, 8192))]
+if len(sys.argv) > 1 and sys.argv[1] == "short":       # below 1024 tokens: the 8-wave kernel
+    cases = [(f"{n}x{l}", [l] * n) for n, l in ((4, 524), (6, 524), (8, 524), (10, 524), (12, 524), (16, 524), (20, 524), (24, 524), (32, 524), (12, 300), (16, 300), (24, 300), (32, 300), (48, 300),
+                                                (4, 800), (6, 800), (8, 800), (12, 800), (16, 800))]
+    cases += [("c5_8", ragged(8, 131, 947, 4)), ("c5_12", ragged(12, 131, 947, 12)), ("c5_16", ragged(16, 131, 947, 16)), ("c5_24", ragged(24, 131, 947, 24))]
+if len(sys.argv) > 1 and sys.argv[1] == "ragged":
+    cases = [(f"c5_{n}", ragged(n, 131, 947, n)) for n in (6, 8, 12, 16, 24, 32)] + [(f"mix2k_{n}", ragged(n, 512, 2040, n)) for n in (4, 6, 9, 14)]
+    cases += [(f"mix4k_{n}", ragged(n, 1024, 4096, n)) for n in (2, 3, 5, 8)] + [("two_classes", [300] * 30 + [1800] * 6), ("long_short", [4000] + [200] * 40)]
 if len(sys.argv) > 1 and sys.argv[1] == "wide":
     cases = [(f"{n}x{l}", [l] * n) for n, l in ((6, 1100), (8, 1100), (10, 1100), (12, 1100), (14, 1100), (6, 1500), (3, 2368), (4, 2368), (5, 2368), (6, 2368),
                                                 (2, 4096), (3, 4096), (4, 4096), (1, 8192), (2, 8192), (16, 2368))]

@@ -23,6 +23,7 @@
 #include <atomic>
 
 #include <algorithm>
+#include <cmath>
 #include <type_traits>
 
 namespace vsel {
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
     const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dvec,
     const int32_t* __restrict__ cu, int hq, int hkv, float scale, int causal, uint16_t* __restrict__ dk,
     uint16_t* __restrict__ dv, float* __restrict__ dk_part, float* __restrict__ dv_part, int k_blocks, int n_seq, int slot,
-    int xcd_local) {
+    int xcd_local, int split_heads) {
   constexpr int kKV = 2 * kTileB;                               // one 128-key tile
   __shared__ __attribute__((aligned(16))) char smem[2 * kKV + 4 * kTileB + 4 * kTile * sizeof(float) + 16];
   char* const k_sm = smem;
@@ -596,7 +597,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
   float (*lse_sm)[kTile] = reinterpret_cast<float (*)[kTile]>(smem + 2 * kKV + 4 * kTileB);
   float (*d_sm)[kTile] = reinterpret_cast<float (*)[kTile]>(smem + 2 * kKV + 4 * kTileB + 2 * kTile * sizeof(float));
   int& s_item = *reinterpret_cast<int*>(smem + 2 * kKV + 4 * kTileB + 4 * kTile * sizeof(float));
-  const int heads_per_item_dim = SPLIT ? hq : hkv;
+  // SPLIT: split_heads q heads per item (1: one head; k > 1: the group in ceil(rep / k) parts, a part's partial in its first head's rows --
+  // attn_bwd_dkdv64.hip, bwd_split_heads below)
+  const int parts = SPLIT ? (hq / hkv + split_heads - 1) / split_heads : 1;
+  const int heads_per_item_dim = hkv * parts;
   const int n_items = k_blocks * heads_per_item_dim * n_seq;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kb = wave & 3, qh = wave >> 2;
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
 
   // work items: (sequence, kv head) pairs on XCD-local queues; a pair's items = (SPLIT: q head of the group, outer) key blocks,
   // block 0 first -- under the causal mask it is seen by the most queries
-  XcdQueue wq{&g_bwd_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * (SPLIT ? rep : 1), xcc_id(), 0};
+  XcdQueue wq{&g_bwd_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * parts, xcc_id(), 0};
   for (int round = 0;; ++round) {
     int kblock, hsel, seq;
     if (slot < 0 || xcd_local != 1) {
@@ -641,9 +645,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
       const int pair = item / wq.per_pair, r = item % wq.per_pair;
       seq = pair / hkv;
       kblock = r % k_blocks;
-      hsel = SPLIT ? (pair % hkv) * rep + r / k_blocks : pair % hkv;
+      hsel = (pair % hkv) * parts + r / k_blocks;
     }
-    const int kvh = SPLIT ? hsel / rep : hsel;
+    const int kvh = hsel / parts;
+    const int first_head = kvh * rep + (SPLIT ? (hsel % parts) * split_heads : 0);
+    const int n_heads = SPLIT ? min(split_heads, rep - (hsel % parts) * split_heads) : rep;
     const int qs = cu[seq];
     const int len = cu[seq + 1] - qs;
     const int k0 = kblock * 128;
@@ -680,8 +686,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
 
     const int q_begin = causal ? k0 : 0;
     const int tiles_per_head = (len - q_begin + kTile - 1) / kTile;
-    const int n_iter = SPLIT ? tiles_per_head : tiles_per_head * rep;
-    int ld_qt = q_begin, ld_head = SPLIT ? hsel : kvh * rep;
+    const int n_iter = tiles_per_head * n_heads;
+    int ld_qt = q_begin, ld_head = first_head;
     auto load_tile = [&](int buf) {
       if (ld_qt + kTile <= len) {
         // full tile: a wave-uniform 64-bit row base on the scalar ALU plus the per-lane 32-bit offset computed once per item
@@ -864,7 +870,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
         }
       if (SPLIT) {
         if (k_valid) {
-          const int64_t ro = ((int64_t)(qs + my_k) * hq + hsel) * kD;
+          const int64_t ro = ((int64_t)(qs + my_k) * hq + first_head) * kD;
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -965,29 +971,39 @@ constexpr int64_t kDkdv64SplitFromTokens = 2048;  // per-q-head split form (few 
 // load = 128 / (n_seq * key blocks)): the heaviest item IS the run time.  Splitting a group's heads over P items shortens it P x at the
 // price of P fp32 partial rows per key and the group-sum launch; measured (tools/exp_dkdv_parts.py, profiles/r04_dkdv_parts.txt; us, group /
 // per head / best part form): 3 x 1100 186 / 115 / 95 (4 parts), 4 x 1100 183 / 143 / 114 (4), 5 x 1100 183 / 178 / 137 (2 - 3), 6 x 1100
-// 187 / 215 / 149 (2), 4 x 2000 326 / 349 / 260 (2), 4 x 2368 364 / 401 / 318 (2), 3 x 4096 693 / 742 / 633 (2); from 400 items (320 below
-// 2048 tokens) the unsplit form wins, below ~100 the per-head form.  Rule: the fewest parts that give >= kPartItemsTarget items.
-static int bwd_split_heads(int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv) {
+// 187 / 215 / 149 (2), 4 x 2000 326 / 349 / 260 (2), 4 x 2368 364 / 401 / 318 (2), 3 x 4096 693 / 742 / 633 (2); 8-wave kernel: 6 x 524
+// 115 / 88 / 69 (4), 10 x 524 114 / 134 / 87 (2), 8 x 800 161 / 180 / 119 (2), 12 x 300 70 / 88 / 59 (2); from 400 items (fewer for shorter
+// sequences) the unsplit form wins, below ~100 the per-head form.  Rule: the fewest parts that give >= kPartItemsTarget items.
+static int bwd_split_heads(int64_t total, int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv) {
   if (hq == hkv) return 0;
   const int rep = (int)(hq / hkv);
   const int forced = knob(VSEL_KNOB_ATTN_BWD_SPLIT);
   const int g_dkdv64 = knob(VSEL_KNOB_ATTN_BWD_DKDV64);
-  const bool parts_ok = rep >= 4 && g_dkdv64 != 0 && (g_dkdv64 == 1 || max_seqlen >= kDkdv64FromTokens);   // (the kernel that has the part form)
+  // (the kernels that have the part form: dkdv64 and the 8-wave kernel)
+  const bool parts_ok = rep >= 4 && (g_dkdv64 == 1 || (g_dkdv64 < 0 && max_seqlen >= kDkdv64FromTokens) || knob(VSEL_KNOB_ATTN_BWD_WAVES) == 8);
   if (forced >= 0) return forced >= 2 ? (parts_ok ? (rep + forced - 1) / forced : 0) : forced;       // (forced k >= 2: k parts per group)
-  const int64_t items = cdiv(max_seqlen, 128) * hkv * n_seq;
+  int64_t items = cdiv(max_seqlen, 128) * hkv * n_seq;
   if (!parts_ok) return items < kSplitBelowItems ? 1 : 0;
-  if (items >= kPartItemsTarget) return 0;
-  const int parts = (int)cdiv(kPartItemsTarget, items);
+  // ragged batches: the list's length comes from the LONGEST sequence, the load from all of them -- heaviest item / mean load =
+  // 512 nb_max / (hkv sum nb_i^2), between [512 / (hkv n nb_mean)] and that times nb_max / nb_mean: count the items a uniform batch of the
+  // MEAN length would have and divide by sqrt(max / mean) (uniform batches: unchanged; dividing by max / mean itself over-split 24 - 32
+  // prompts of 131 ... 947 tokens, -2 ... -11 %; counting by the longest sequence missed +10 ... +25 % on 4 - 16 of them)
+  const int64_t mean_len = cdiv(total, n_seq);
+  if (mean_len < max_seqlen)
+    items = std::max<int64_t>(1, (int64_t)((double)(cdiv(mean_len, 128) * hkv * n_seq) / std::sqrt((double)max_seqlen / (double)mean_len)));
+  // the unsplit form from this many items (short items carry more fixed cost each: the crossover falls with the sequence length)
+  const int64_t group_from = max_seqlen >= 2048 ? 400 : max_seqlen >= 1024 ? 320 : max_seqlen >= 450 ? 300 : 250;
+  if (items >= group_from) return 0;
+  const int parts = (int)cdiv(max_seqlen >= 450 ? kPartItemsTarget : 250, items);
   if (parts > 4) return 1;
-  if (parts == 2 && items >= 320 && max_seqlen < 2048) return 0;
   return (rep + parts - 1) / parts;                 // (1 when rep <= parts: the per-head form)
 }
-static bool bwd_use_split(int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv) { return bwd_split_heads(n_seq, max_seqlen, hq, hkv) != 0; }
+static bool bwd_use_split(int64_t total, int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv) { return bwd_split_heads(total, n_seq, max_seqlen, hq, hkv) != 0; }
 
 extern "C" size_t vsel_varlen_attn_bwd_workspace_bytes(int64_t total, int64_t hq, int64_t hkv, int64_t n_seq, int64_t max_seqlen) {
   if (total < 1 || hq < 1 || hkv < 1 || n_seq < 1 || max_seqlen < 1) return 0;
   size_t bytes = (((size_t)total * (size_t)hq * sizeof(float) + 255) & ~(size_t)255) * 2;   // D, lse * log2(e)
-  if (bwd_use_split(n_seq, max_seqlen, hq, hkv))
+  if (bwd_use_split(total, n_seq, max_seqlen, hq, hkv))
     bytes += 2 * (size_t)total * (size_t)hq * bwd::kD * sizeof(float);             // dK / dV partials per q head
   return bytes;
 }
@@ -1054,11 +1070,12 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
   }
   const int g_dkdv64 = knob(VSEL_KNOB_ATTN_BWD_DKDV64);
   {
-    const int split_heads = bwd_split_heads(n_seq, max_seqlen, hq, hkv);
+    int split_heads = bwd_split_heads(total, n_seq, max_seqlen, hq, hkv);
     const bool split = split_heads != 0;
     const bool dkdv64 = g_dkdv64 == 1 || (g_dkdv64 < 0 && max_seqlen >= (split_heads == 1 ? kDkdv64SplitFromTokens : kDkdv64FromTokens));
+    if (!dkdv64 && split_heads > 1 && knob(VSEL_KNOB_ATTN_BWD_WAVES) != 8) split_heads = 1;     // (the 4-wave kernel: per-head items only)
     const int k_blocks = (int)cdiv(max_seqlen, 128);
-    const int64_t n_items = (int64_t)k_blocks * (split ? hq : hkv) * n_seq;             // (the 4- / 8-wave kernels: per-head items only)
+    const int64_t n_items = (int64_t)k_blocks * hkv * (split ? cdiv(hq / hkv, split_heads) : 1) * n_seq;
     if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
     float* dk_part = split ? (float*)((char*)workspace + 2 * d_bytes) : nullptr;
     float* dv_part = split ? dk_part + (size_t)rows * bwd::kD : nullptr;
@@ -1075,8 +1092,8 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
 #define VSEL_DKDV_ARGS (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu_seqlens, (int)hq, \
                          (int)hkv, scale, causal, (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, k_blocks, (int)n_seq, slot, xcd_local_dkdv
       if (w8) {
-        if (split) hipLaunchKernelGGL((bwd::attn_bwd_dkdv2_kernel<true>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS);
-        else hipLaunchKernelGGL((bwd::attn_bwd_dkdv2_kernel<false>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS);
+        if (split) hipLaunchKernelGGL((bwd::attn_bwd_dkdv2_kernel<true>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS, split_heads);
+        else hipLaunchKernelGGL((bwd::attn_bwd_dkdv2_kernel<false>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS, 0);
       } else {
         if (split) hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<true>), grid, dim3(256), 0, st, VSEL_DKDV_ARGS);
         else hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<false>), grid, dim3(256), 0, st, VSEL_DKDV_ARGS);

@@ -583,6 +583,37 @@ def bench_attention(ops, k, text=64, hq=28, hkv=4, dh=128, layers=28, iters=200)
     except Exception as e:  # optional
         out.setdefault("packed_16x4096", {"error": str(e)[:200]})
         out.setdefault("packed_16x4096_backward", {"error": str(e)[:200]})
+    # ... and the packed batches a deployment of the compressed prompts serves (config 5): 8 / 32 prompts of L' = k + 64
+    # tokens (forward), and 4 training sequences of the uncompressed length (forward + backward)
+    for tag, n_seq, L, bwd in (("packed_8xLc", 8, k + text, False), ("packed_32xLc", 32, k + text, False), ("packed_4xL_train", 4, N_VIS + text, True)):
+        try:
+            gen = torch.Generator(device="cuda").manual_seed(9)
+            q = torch.randn(n_seq * L, hq, dh, device="cuda", generator=gen).bfloat16()
+            kk = torch.randn(n_seq * L, hkv, dh, device="cuda", generator=gen).bfloat16()
+            v = torch.randn(n_seq * L, hkv, dh, device="cuda", generator=gen).bfloat16()
+            cu = torch.arange(0, n_seq * L + 1, L, dtype=torch.int32, device="cuda")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def timed(fn, n):
+                for _ in range(10):
+                    fn()
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / n
+            ms = timed(lambda: ops.varlen_attn(q, kk, v, cu, L), 100)
+            fl = 4.0 * L * L * hq * dh / 2 * n_seq
+            out[tag] = {"n_seq": n_seq, "L": L, "fwd_ms": ms, "fwd_tflops": fl / (ms * 1e-3) / 1e12}
+            if bwd:
+                do = torch.randn(n_seq * L, hq, dh, device="cuda", generator=gen).bfloat16()
+                o, lse = ops.varlen_attn_fwd_lse(q, kk, v, cu, L)
+                ms = timed(lambda: ops.varlen_attn_bwd(do, q, kk, v, o, lse, cu, L), 30)
+                out[tag].update({"bwd_ms": ms, "bwd_tflops_algorithmic": 2.5 * fl / (ms * 1e-3) / 1e12})
+        except Exception as e:  # optional
+            out[tag] = {"error": str(e)[:200]}
     return out
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Packed short / medium sequences in the 4- / 8-wave forward: atomic work queue (attn_static = 0) against the static deal of the
-heaviest-first item list (1) and the static deal with the next item's Q rows prefetched into L2 (2).  Same process, alternating;
+heaviest-first item list (1).  Same process, alternating;
 outputs must be bit-identical (placement only)."""
 import os, sys, json, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,7 @@ def ragged(n, lo, hi, seed):
 cases = [(f"{n}x{l}", [l] * n) for n, l in ((3, 524), (4, 524), (7, 524), (9, 524), (5, 1100), (3, 1500))]
 cases += [(f"c5_{n}_{sd}", ragged(n, 131, 947, sd)) for n in (3, 4, 5, 6) for sd in (1, 2)]
 cases += [(f"mix_{n}_{sd}", ragged(n, 64, 2040, sd)) for n in (2, 3) for sd in (1, 2)]
-MODES = (0, 1, 1)        # (the third column was the static deal + L2 prefetch of the next item's Q rows, removed: profiles/r04_attn_static.txt)
+MODES = (0, 1)        # (a third column was the static deal + L2 prefetch of the next item's Q rows, removed: profiles/r04_attn_static.txt)
 for name, lens in cases:
     g = torch.Generator(device="cuda").manual_seed(7)
     T, L = sum(lens), max(lens)
@@ -40,6 +40,5 @@ for name, lens in cases:
                 outs[m] = o
     same = all(torch.equal(outs[0], outs[m]) for m in MODES)
     b = {m: min(res[m]) for m in MODES}
-    print(json.dumps({"case": name, "tokens": T, "us_queue": b[0], "us_static": b[1], "us_static_prefetch": b[2],
-                      "ratio_static": round(b[0] / b[1], 3), "ratio_prefetch": round(b[0] / b[2], 3),
+    print(json.dumps({"case": name, "tokens": T, "us_queue": b[0], "us_static": b[1], "ratio_static": round(b[0] / b[1], 3),
                       "TFLOPs_queue": round(fl / b[0] / 1e6, 1), "TFLOPs_best": round(fl / min(b.values()) / 1e6, 1), "bit_identical": same}), flush=True)

@@ -968,12 +968,15 @@ inline int launch_score(hipStream_t st, const T* h, const SegView& sv, const vse
 // 128 bf16 columns) gives knob LIS_SEG_SUMS (segment, slab) pairs = waves (default 896 = 3.5 per CU; 0 = never; measured per call at
 // the 7B geometry, chunked vs this: B = 32 231 vs 228 us, 64 446 vs 428, 96 721 vs 685, 128 848-895 vs 826-830; with 672 pairs no
 // gain, with one 512-column slab per wave at B = 64 a loss: 483 vs 442), never for the <= 8 segments the small-batch form may take
-// (its kernels rebuild x-bar from chunk partials), more than one chunk, and no segment far longer than the average (its waves
-// would finish last).  Same sums bit for bit either way: batch invariance is untouched.
+// (its kernels rebuild x-bar from chunk partials), more than one chunk, and no segment longer than 1.375 x the average: a wave
+// streams its (segment, slab) alone, at most twice as fast once the others are done, so the longest segment's waves finish last --
+// tools/exp_ragged_lis.py, profiles/r04_ragged_lis.txt, call time chunked vs this form by max / mean: 1.0 +1.5 %, 1.13 +1.8 ... +3.2 %,
+// 1.33 +1.2 ... 0 %, 1.5 - 1.7 (N_i ~ U{576..4096}) -4 % (32 prompts), -7 % (64), -10 % (128: sweep 1 446 -> 336 us).  Same sums bit for
+// bit either way: batch invariance is untouched.
 inline bool seg_sums_form(const LisPlan& p, const vsel_segments* seg) {
   const int mn = knob(VSEL_KNOB_LIS_SEG_SUMS);
   // (pairs counted for the narrowest slab of bf16 tokens, 128 columns, whatever the token type: the projection stage does not know it)
-  return mn > 0 && p.S > 8 && p.S * cdiv(p.d, 128) >= mn && p.row_splits > 1 && p.d % 8 == 0 && seg->total_rows * 2 >= p.S * p.maxn;
+  return mn > 0 && p.S > 8 && p.S * cdiv(p.d, 128) >= mn && p.row_splits > 1 && p.d % 8 == 0 && seg->total_rows * 11 >= (int64_t)p.S * p.maxn * 8;
 }
 
 template <typename T>

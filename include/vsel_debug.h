@@ -30,9 +30,10 @@ typedef enum vsel_debug_knob {
   VSEL_KNOB_ATTN_SPLIT = 6,       /* two-KV-stream form for one short sequence: 0 never, 1 whenever <= 256 items, 2 (default) ... and
                                      the sequences are not tiny; inference only, sums in a different order (bf16-rounding agreement) */
   VSEL_KNOB_ATTN_SPLIT_Q64 = 7,   /* 0 / 1: 64-query workgroups in the two-stream form when they fit one per CU (default 1) */
-  VSEL_KNOB_ATTN_BWD_SPLIT = 8,   /* dK/dV items: -1 by item count (default), 0 the group's q heads inside the item, 1 one q head per item, 2 the
-                                     group in two parts (the one-wave-per-SIMD kernel only, else 0); fp32 partials + ordered group sum in
-                                     forms 1 / 2; deterministic in every form, fp32 association differs between them */
+  VSEL_KNOB_ATTN_BWD_SPLIT = 8,   /* dK/dV items: -1 by item count, sequence length and raggedness (default), 0 the group's q heads inside the
+                                     item, 1 one q head per item, 2 / 3 / 4 the group in that many parts (not in the 4-wave kernel: 1 there);
+                                     fp32 partials + ordered group sum in forms >= 1; deterministic in every form, fp32 association
+                                     differs between them (dK / dV agree to a bf16 rounding) */
   VSEL_KNOB_LIS_SPLICE_FUSED = 9, /* 0 / 1: vsel_lis_select_splice writes kept rows straight into inputs_embeds' (default 1) or runs
                                      select then splice as two steps; bit-identical */
   VSEL_KNOB_ATTN_BWD_WAVES = 10,  /* 4 / 8: dK/dV workgroup: four waves with K/V operands in registers, or eight (two per SIMD, query tile split

@@ -948,7 +948,7 @@ extern "C" int vsel_debug_read_bwd_trace(unsigned long long* out) {
 // 2 x 2368 (152) 377 / 552 / 369, 8 x 524 (160) 175 / 173 / 165, 8 x 1100 (288) 443 / 383 / 438, 4 x 2368 (304) 728 / 738 / 725,
 // 3 x 4096 (384) 1426 / 1398 / 1414, 6 x 2368 (456) 1086 / 940 / 1099: the crossover is below 288 items now.
 static constexpr int64_t kSplitBelowItems = 288;
-static constexpr int64_t kPartItemsTarget = 400;     // (dkdv64) groups are cut in the fewest parts that give this many items
+static constexpr int64_t kPartItemsTarget = 400;     // groups are cut in the fewest parts that give this many items (bwd_split_heads)
 // knob VSEL_KNOB_ATTN_BWD_SPLIT (include/vsel_debug.h): -1 = choose by item count, 0 / 1 = force (tests)
 
 namespace vsel { namespace bwd {
@@ -967,7 +967,7 @@ constexpr int64_t kDkdv64FromTokens = 1024;       // q heads inside the item (pr
 constexpr int64_t kDkdv64SplitFromTokens = 2048;  // per-q-head split form (few items): +5 % at 1 x 2368, +12 % at 1 x 4096, +15 % at 1 x 8192
 
 // -> q heads per dK / dV item: 0 = the whole group inside the item, 1 = one q head per item, k > 1 = the group in ceil(rep / k) PARTS (the
-// one-wave-per-SIMD kernel only).  The unsplit grid is causal-imbalanced while it has fewer than ~2 rounds of items (heaviest item / mean
+// one-wave-per-SIMD kernel and the 8-wave kernel; the 4-wave kernel falls back to 1).  The unsplit grid is causal-imbalanced while it has fewer than ~2 rounds of items (heaviest item / mean
 // load = 128 / (n_seq * key blocks)): the heaviest item IS the run time.  Splitting a group's heads over P items shortens it P x at the
 // price of P fp32 partial rows per key and the group-sum launch; measured (tools/exp_dkdv_parts.py, profiles/r04_dkdv_parts.txt; us, group /
 // per head / best part form): 3 x 1100 186 / 115 / 95 (4 parts), 4 x 1100 183 / 143 / 114 (4), 5 x 1100 183 / 178 / 137 (2 - 3), 6 x 1100

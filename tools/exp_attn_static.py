@@ -5,6 +5,8 @@ outputs must be bit-identical (placement only)."""
 import os, sys, json, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visionselector_amd import _native, ops
+if os.environ.get("VSEL_LIB"):            # a variant build (tools/build_variant.sh) for same-box A/B runs
+    _native.LIB_PATH = os.path.abspath(os.environ["VSEL_LIB"])
 
 def ragged(n, lo, hi, seed):
     g = torch.Generator().manual_seed(seed)
@@ -13,6 +15,9 @@ def ragged(n, lo, hi, seed):
 cases = [(f"{n}x{l}", [l] * n) for n, l in ((3, 524), (4, 524), (7, 524), (9, 524), (5, 1100), (3, 1500))]
 cases += [(f"c5_{n}_{sd}", ragged(n, 131, 947, sd)) for n in (3, 4, 5, 6) for sd in (1, 2)]
 cases += [(f"mix_{n}_{sd}", ragged(n, 64, 2040, sd)) for n in (2, 3) for sd in (1, 2)]
+if len(sys.argv) > 1 and sys.argv[1] == "packed":        # throughput-bound packed batches
+    cases = [(f"{n}x{l}", [l] * n) for n, l in ((8, 524), (16, 524), (32, 524), (64, 524), (64, 300), (16, 1100), (32, 1100), (16, 1900))]
+    cases += [(f"c5_{n}", ragged(n, 131, 947, n)) for n in (16, 32, 64)] + [("mix_24", ragged(24, 64, 2040, 7))]
 MODES = (0, 1)        # (a third column was the static deal + L2 prefetch of the next item's Q rows, removed: profiles/r04_attn_static.txt)
 for name, lens in cases:
     g = torch.Generator(device="cuda").manual_seed(7)

@@ -405,6 +405,62 @@ def test_dkdv_group_in_parts_matches_the_formula_and_the_other_item_forms(lens, 
         assert any(all(torch.equal(a, b) for a, b in zip(auto, res[sp])) for sp in (1, 2, 3, 4))
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_scheduling_rules_on_random_batches(seed):
+    """The library's own choices (static deal on few rounds of items, the counter jumping over empty runs, the dK / dV item form by item
+    count / sequence length / raggedness, 32- vs 64-rows-per-wave kernels) on random packed batches -- 1 .. 40 sequences of 0 .. 2600
+    tokens (a zero-length sequence included), GQA 7 / 4 / 8 / 1 -- against the same call with every scheduling rule switched off (atomic
+    queue, every item handed out, the group's heads inside the dK / dV item): forward output, log-sum-exp and dQ bit-identical, dK / dV
+    within a bf16 rounding, and all gradients against the fp64 eager formula at the backward test's bound."""
+    import random
+    import torch
+    from visionselector_amd import _native as N, ops
+    rnd = random.Random(1000 + seed)
+    hq, hkv = rnd.choice([(28, 4), (8, 2), (32, 8), (4, 4), (16, 2)])
+    n_seq = rnd.choice([1, 2, 3, 5, 8, 13, 24, 40])
+    hi = rnd.choice([300, 700, 1300, 2600]) if n_seq <= 13 else rnd.choice([200, 500])
+    lens = [rnd.randint(1, hi) for _ in range(n_seq)]
+    if n_seq >= 3:
+        lens[rnd.randrange(n_seq)] = 0
+    if seed % 3 == 0:
+        lens[rnd.randrange(n_seq)] = hi                                  # one long sequence among short ones
+    if sum(lens) == 0:
+        lens[0] = 17
+    T = sum(lens)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = torch.randn(T, hq, 128, device="cuda", generator=g).bfloat16()
+    k = torch.randn(T, hkv, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(T, hkv, 128, device="cuda", generator=g).bfloat16()
+    do = torch.randn(T, hq, 128, device="cuda", generator=g).bfloat16()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
+    L = max(lens)
+
+    def run():
+        out, lse = ops.varlen_attn_fwd_lse(q, k, v, cu, L)
+        return (out, lse) + tuple(ops.varlen_attn_bwd(do, q, k, v, out, lse, cu, L))
+    auto = run()
+    with N.debug_knob(attn_static=0, attn_skip_empty=0, attn_bwd_split=0):
+        base = run()
+    for i in range(3):
+        assert torch.equal(auto[i], base[i]), (lens, hq, hkv, i)
+    for i in (3, 4):
+        assert float((auto[i].float() - base[i].float()).abs().max()) <= 2 ** -7 * float(base[i].float().abs().max()), (lens, hq, hkv, i)
+    assert all(bool(torch.isfinite(t.float()).all()) for t in (auto[0], auto[2], auto[3], auto[4]))
+    o = 0
+    for Ls in lens:
+        sl = slice(o, o + Ls)
+        o += Ls
+        if Ls == 0:
+            continue
+        qq, kk, vv = (t[sl].double().transpose(0, 1).requires_grad_(True) for t in (q, k, v))
+        kr, vr = (t.repeat_interleave(hq // hkv, 0) for t in (kk, vv))
+        sc = (qq @ kr.transpose(1, 2) / 128 ** 0.5).masked_fill(torch.ones(Ls, Ls, device="cuda", dtype=torch.bool).triu(1), float("-inf"))
+        (torch.softmax(sc, -1) @ vr).backward(do[sl].double().transpose(0, 1))
+        for got, ref in ((auto[2], qq.grad), (auto[3], kk.grad), (auto[4], vv.grad)):
+            ref = ref.transpose(0, 1)
+            assert ((got[sl].double() - ref).abs().max() / max(ref.abs().max().item(), 1e-3)).item() <= 2 ** -6, (lens, hq, hkv)
+
+
 def test_long_sequences_take_the_64_row_passes_by_default_and_match_the_oracle_bound():
     """From 1024 tokens in the longest sequence the library picks attn_bwd_dq64_kernel and attn_bwd_dkdv64_kernel (the per-q-head
     split form of the latter from 2048) by itself; gradients against the fp64 eager formula on the bf16-rounded inputs, at the backward test's bound."""

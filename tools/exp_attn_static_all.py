@@ -7,6 +7,8 @@ alternating.  `rounds` = work items / resident workgroups of that kernel.  Outpu
 import os, sys, json, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visionselector_amd import _native as N, ops
+if os.environ.get("VSEL_LIB"):            # a variant build for same-box A/B runs
+    N.LIB_PATH = os.path.abspath(os.environ["VSEL_LIB"])
 
 def ragged(n, lo, hi, seed):
     g = torch.Generator().manual_seed(seed)

@@ -62,7 +62,11 @@ typedef enum vsel_debug_knob {
   VSEL_KNOB_ATTN_SKIP_EMPTY = 18, /* single work queue on ragged batches: the shared counter jumps over runs of EMPTY items (levels a shorter
                                      sequence does not reach) instead of handing each one out: 1 (default) / 0; env VSEL_ATTN_SKIP_EMPTY;
                                      placement only, outputs bit-identical */
-  VSEL_KNOB_COUNT = 19
+  VSEL_KNOB_ATTN_GQA = 19,        /* forward for head_dim 128, prefill over the queries' own keys, 2 <= hq / hkv <= 8: ONE 8-wave workgroup serves a
+                                     kv head's whole q-head group on a 32-query tile (K / V tiles loaded once per group, 32-key causal granularity,
+                                     the next item's rows in flight under the last tile; csrc/attn_fwd_gqa.hip): -1 for throughput-bound grids of
+                                     sequences below 2048 tokens (default), 0 never, 1 whenever it applies; env VSEL_ATTN_GQA; bit-identical outputs */
+  VSEL_KNOB_COUNT = 20
 } vsel_debug_knob;
 
 /* Set knob to value (clamped to the knob's range).  *previous (may be NULL) receives the value it had.

@@ -472,3 +472,94 @@ def test_rows64_forward_on_head_major_strided_tensors(ops, b, hq, hkv, lq, lk, c
             prof = N.profile_stop()
             assert ("attn_fwd64_kernel" in prof) == bool(r64), prof
     assert torch.equal(outs[0], outs[1])
+
+
+# ---- group-shared forward for short sequences (csrc/attn_fwd_gqa.hip, round 5) ----------------------------------------------------------
+def _gqa_pair(ops, q, k, v, cu, L, causal, lse=False):
+    """(per-head 4- / 8-wave form, group-shared form) on the same inputs; the profile proves which kernel ran"""
+    from visionselector_amd import _native as N
+    outs = []
+    for g in (0, 1):
+        with N.debug_knob(attn_gqa=g, attn_split=0, attn_rows64=0):
+            N.profile_start()
+            outs.append(ops.varlen_attn_fwd_lse(q, k, v, cu, L, causal=causal) if lse else ops.varlen_attn(q, k, v, cu, L, causal=causal))
+            prof = N.profile_stop()
+            assert ("attn_fwd_gqa_kernel" in prof) == bool(g), prof
+    return outs
+
+
+@pytest.mark.parametrize("lens,hq,hkv", [([524], 28, 4), ([1], 28, 4), ([31, 32, 33, 64, 65, 1, 127, 300], 28, 4), ([524] * 5, 28, 4),
+                                         ([793, 210, 17], 32, 8), ([300, 129, 64], 16, 2), ([257, 96], 4, 2), ([100, 333], 6, 2),
+                                         ([1230, 64], 12, 2)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_gqa_shared_forward_matches_oracle_and_per_head_forms_bit_for_bit(ops, lens, hq, hkv, causal):
+    """One workgroup per (query tile, kv head) serving the whole q-head group: same arithmetic per query row as the per-head kernels
+    (64-key tiles from key 0, skipped blocks are exactly the fully masked ones) -> outputs and log-sum-exps bit-identical, and within
+    the usual gate of the fp64 oracle.  Group sizes 7 (7B: 7 head waves + a helper), 4 (LLaVA-OV: two 32-query slices), 8 (3B),
+    2 / 3 / 5 / 6; ragged lengths exercise empty items (levels a shorter sequence does not reach), partial query tiles, partial key
+    tiles, single-tile items and the item-to-item prefetch across sequences."""
+    q, k, v = make_qkv(sum(lens), hq, hkv, 211 + len(lens) + hq)
+    cu = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    cu_t = torch.from_numpy(cu).cuda()
+    (ao, al), (bo, bl) = _gqa_pair(ops, q.cuda(), k.cuda(), v.cuda(), cu_t, max(lens), causal, lse=True)
+    assert torch.equal(ao, bo)
+    assert torch.equal(al, bl)
+    ref = oattn.varlen_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu, causal=causal)
+    check(bo.float().cpu().numpy(), ref)
+
+
+def test_gqa_shared_forward_rescale_and_lazy_exponent(ops):
+    lens = [900, 333, 1500]
+    total = sum(lens)
+    q, k, v = make_qkv(total, 8, 2, 31, spike=True)
+    ramp = torch.linspace(0.2, 2.5, total).view(-1, 1, 1)
+    k = (k.float() * ramp).bfloat16()
+    k[700] *= 5
+    cu = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    cu_t = torch.from_numpy(cu).cuda()
+    for causal in (True, False):
+        (ao, al), (bo, bl) = _gqa_pair(ops, q.cuda(), k.cuda(), v.cuda(), cu_t, max(lens), causal, lse=True)
+        assert torch.equal(ao, bo) and torch.equal(al, bl)
+        ref = oattn.varlen_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu, causal=causal)
+        check(bo.float().cpu().numpy(), ref, f"[causal={causal}]")
+
+
+def test_gqa_shared_forward_many_ragged_prompts_is_deterministic_and_default(ops):
+    """Config 5's shape: 64 compressed prompts of 131 .. 947 tokens at 7B heads -- more items than workgroups (work queue drawn two items
+    ahead, runs of empty items skipped), the default form for such grids; two runs and the per-head form agree bit for bit."""
+    from visionselector_amd import _native as N
+    rng = np.random.default_rng(5)
+    lens = [int(x) for x in rng.integers(131, 948, size=64)]
+    total = sum(lens)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    q = torch.randn(total, 28, 128, device="cuda", generator=g).bfloat16()
+    k = torch.randn(total, 4, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(total, 4, 128, device="cuda", generator=g).bfloat16()
+    cu = torch.from_numpy(np.concatenate(([0], np.cumsum(lens))).astype(np.int32)).cuda()
+    N.profile_start()
+    a = ops.varlen_attn(q, k, v, cu, max(lens))
+    prof = N.profile_stop()
+    assert "attn_fwd_gqa_kernel" in prof, prof
+    b = ops.varlen_attn(q, k, v, cu, max(lens))
+    assert torch.equal(a, b)
+    with N.debug_knob(attn_gqa=0):
+        c = ops.varlen_attn(q, k, v, cu, max(lens))
+    assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("b,hq,hkv,l,causal", [(3, 28, 4, 524, True), (2, 32, 8, 300, True), (2, 16, 2, 257, False)])
+def test_gqa_shared_forward_on_head_major_strided_tensors(ops, b, hq, hkv, l, causal):
+    """HuggingFace-layout tensors [B, H, L, d] through the group-shared form: bit-identical to the per-head form on the same views."""
+    from visionselector_amd import _native as N
+    rng = np.random.default_rng(5 * b + l)
+    f = lambda *sh: torch.from_numpy(rng.standard_normal(sh, dtype=np.float32)).bfloat16().cuda()  # noqa: E731
+    q, k = f(b, hq, l, 128), f(b, hkv, l, 128)
+    v = f(b, l, hkv, 128).transpose(1, 2)
+    outs = []
+    for g in (0, 1):
+        with N.debug_knob(attn_gqa=g, attn_split=0, attn_rows64=0, attn_pack=0):
+            N.profile_start()
+            outs.append(ops.attn_head_major(q, k, v, causal=causal))
+            prof = N.profile_stop()
+            assert ("attn_fwd_gqa_kernel" in prof) == bool(g), prof
+    assert torch.equal(outs[0], outs[1])

@@ -35,7 +35,8 @@ def _stale() -> bool:
 # (source file, mangled-name fragment).  The 8-wave dK/dV kernel (both instantiations) is on the list since round 4: its output
 # epilogue converts with v_cvt_pk_bf16_f32 instead of the software rounding whose constants pushed it to 256 + 25 registers.
 ASM_READ_KERNELS = (("attn.hip", "varlen_attn_fwd_kernelILb1E"), ("attn_bwd.hip", "attn_bwd_dkdv2_kernelILb0E"),
-                    ("attn_bwd.hip", "attn_bwd_dkdv2_kernelILb1E"), ("attn_bwd.hip", "attn_bwd_dq_kernel"))
+                    ("attn_bwd.hip", "attn_bwd_dkdv2_kernelILb1E"), ("attn_bwd.hip", "attn_bwd_dq_kernel"),
+                    ("attn_fwd_gqa.hip", "attn_fwd_gqa_kernel"))
 
 
 def extra_flags() -> list:

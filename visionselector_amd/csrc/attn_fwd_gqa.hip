@@ -56,6 +56,15 @@ __device__ __forceinline__ int opaque_lane() {
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
   return l;
 }
+// {x, x of lane ^ 32} in some order without the LDS crossbar round trip of __shfl_xor (ds_bpermute_b32): v_permlane32_swap exchanges
+// lanes 32..63 of its first operand with lanes 0..31 of its second.  Enough for a commutative combine (max; a + b and b + a are the same
+// float).  Inline asm: __builtin_amdgcn_permlane32_swap(u, u) has its two results folded into one by hipcc (ROCm 7.2) -- max(r0, r1)
+// became r0.  (s_nop 1: a VALU write needs 2 wait states in front of the swap; the compiler does not see into the asm.)
+__device__ __forceinline__ void both_halves(float x, float& a, float& b) {
+  a = x;
+  b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
@@ -251,33 +260,47 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
   GQA_STAMP(1);
 
   // one 64-key tile out of ring slot CUR; nkb = visible 32-key blocks of it for this wave's queries (1 or 2, wave-uniform)
-  auto tile_body = [&](auto cur_c, int tt, int nkb) {
+  auto tile_body = [&](auto cur_c, int tt, int nkb, auto&& issue_loads) {
     constexpr int CUR = decltype(cur_c)::value;
     const bool two = nkb == 2;
     const int len = cur.qlen;
+    // ---- S^T = K Q^T: the second block's K fragments are on their way while the first block's MFMAs run; the direct-to-LDS loads of
+    // the next tile are issued behind those MFMAs (their issue costs ~100 cycles each, free while the matrix pipe works).  The second
+    // block's reads are issued whether or not it is visible (no counted wait may sit in one arm of a branch, see below).
     f32x16 s[2];                      // s[1] stays undefined when the second block is skipped (a zero fill outside the branch would be 16 moves)
-    auto s_block = [&](auto kb_c) {
-      constexpr int KB = decltype(kb_c)::value;
-      u32x4 ka[8];
+    u32x4 ka0[8], ka1[8];
 #pragma unroll
-      for (int st = 0; st < 8; ++st) ka[st] = lds_read_b128_asm<CUR * kBuf + KB * 32 * kRowBytes>(row_addr_u[st]);
-      lds_wait8<0>(ka);
+    for (int st = 0; st < 8; ++st) ka0[st] = lds_read_b128_asm<CUR * kBuf>(row_addr_u[st]);
+#pragma unroll
+    for (int st = 0; st < 7; ++st) ka1[st] = lds_read_b128_asm<CUR * kBuf + 32 * kRowBytes>(row_addr_u[st]);
+    lds_wait8<7>(ka0);
+    {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int st = 0; st < 8; ++st)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq_bf16x8(ka[st]), gq_bf16x8(qf[st]), acc, 0, 0, 0);
-      s[KB] = acc;
-    };
-    s_block(std::integral_constant<int, 0>{});
-    if (two) s_block(std::integral_constant<int, 1>{});
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq_bf16x8(ka0[st]), gq_bf16x8(qf[st]), acc, 0, 0, 0);
+      s[0] = acc;
+    }
+    issue_loads();
+    ka1[7] = lds_read_b128_asm<CUR * kBuf + 32 * kRowBytes>(row_addr_u[7]);
     // the first group of V fragments does not depend on P: its transpose reads fly under the softmax
-    u32x2 vr0[8], vr1[8], vr2[8], vr3[8];     // (vr2 / vr3: the second block's groups, defined and used under `two` only)
+    u32x2 vr0[8], vr1[8], vr2[8], vr3[8];     // (vr2 / vr3: the second block's groups)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       vr0[2 * dt] = lds_read_tr16_b64_asm<(2 + CUR) * kBuf>(tr_addr_u[dt][0]);
       vr0[2 * dt + 1] = lds_read_tr16_b64_asm<(2 + CUR) * kBuf>(tr_addr_u[dt][1]);
+    }
+    lds_wait8<8>(ka1);
+    if (two) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int st = 0; st < 8; ++st)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq_bf16x8(ka1[st]), gq_bf16x8(qf[st]), acc, 0, 0, 0);
+      s[1] = acc;
     }
     // ---- mask + online softmax: attn.hip's arithmetic, element for element -------------------------------------------------------
     // a 32-key block needs the mask when its last key lies past the first query of the wave (causal) or past the end of the keys;
@@ -304,7 +327,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
     };
     mask_max(std::integral_constant<int, 0>{});
     if (two) mask_max(std::integral_constant<int, 1>{});
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    {
+      float ha, hb;
+      both_halves(mx, ha, hb);
+      mx = fmaxf(ha, hb);
+    }
     const float m_cand = fmaxf(m_run, mx * scale_log2e);
     const bool moves = m_cand > m_run + kLazyTau;
     if (__any(moves)) {
@@ -379,7 +406,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
   // tile goes through the wave's own staging area instead: the 16-byte chunk c of row r at position c ^ (r & 15), read back as whole
   // rows (4 rows per instruction) and stored as 8 x 1 KiB of whole 256-byte rows.  Wave-private: no barrier.
   auto epilogue = [&]() {
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_a, l_b;
+    both_halves(l_run, l_a, l_b);
+    const float l_tot = l_a + l_b;
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     const int el = opaque_lane();
     const int e_j = el & 31, e_hh = el >> 5, e_l4 = el >> 4, e_p = el & 15;
@@ -420,13 +449,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
     using NXT = std::integral_constant<int, 1 - CUR>;
     const bool last = t + 1 == cur.n_tiles;
     GQA_STAMP(2);
-    if (!last) {
-      load_tile(cur, t + 1, NXT{});
-    } else if (next.n_tiles > 0) {                   // the next item's rows and first tile fly under this item's last tile
-      load_q(next);
-      load_tile(next, 0, NXT{});
-    }
-    GQA_STAMP(3);
+    auto issue_loads = [&]() {
+      if (!last) {
+        load_tile(cur, t + 1, NXT{});
+      } else if (next.n_tiles > 0) {                 // the next item's rows and first tile fly under this item's last tile
+        load_q(next);
+        load_tile(next, 0, NXT{});
+      }
+    };
     // visible 32-key blocks of this tile for the wave's queries (uniform per wave)
     int nkb = 0;
     if (wave_has_rows) {
@@ -435,7 +465,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
       else nkb = (t * kTileK > wave_qmax) ? 0 : ((t * kTileK + 32 > wave_qmax) ? 1 : 2);
     }
     nkb = __builtin_amdgcn_readfirstlane(nkb);
-    if (nkb > 0) tile_body(cur_c, t, nkb);
+    if (nkb > 0) tile_body(cur_c, t, nkb, issue_loads);
+    else issue_loads();
     GQA_STAMP(4);
     if (last && tid == 0) s_cand[ipar] = pend;       // (drawn a whole item ago: no wait)
     __syncthreads();                                 // vmcnt(0) in front of it: every wave's direct loads have landed at the release

@@ -117,6 +117,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool head_wave = wave < QW * rep;          // (7 q heads: wave 7 only helps with the tile loads)
+#ifdef VSEL_GQA_LOADER
+  const bool one_loader = QW * rep == 7;           // exactly one spare wave: it issues every tile load
+#else
+  const bool one_loader = false;
+#endif
   const int qw = head_wave ? wave / rep : 0;       // this wave's 32-query slice
   const int hl = head_wave ? wave % rep : 0;       // ... and q head inside the group
   const int j = lane & 31, hh = lane >> 5;
@@ -189,6 +194,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
       const uint32_t row = (uint32_t)min(t * kTileK + 4 * i + (l >> 4), it.qlen - 1);
       __builtin_amdgcn_global_load_lds((gptr_t)(kp + (row * k_rs_b + kv_part_b)), (lptr_t)(smem + BUF * kBuf + i * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(vp + (row * v_rs_b + kv_part_b)), (lptr_t)(smem + (2 + BUF) * kBuf + i * 1024), 16, 0, 0);
+    }
+  };
+  // the whole tile by ONE wave (7 q heads per group: wave 7 has no head and nothing else to do -- the head waves then never stall on
+  // the vector-memory pipe, whose address stage a 32 KiB tile pair occupies for ~500 cycles per round)
+  auto load_tile_all = [&](const GqaItem& it, int t, auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+    const char* kp = reinterpret_cast<const char*>(k + (int64_t)it.qs * hkv * kHeadDim + it.kvh * kv_hs);
+    const char* vp = reinterpret_cast<const char*>(v + (int64_t)it.qs * hkv * kHeadDim + it.kvh * v_hs);
+    const int l = opaque_lane();
+    const uint32_t part0_b = (uint32_t)((l & 15) ^ ((l >> 4) << 2)) * 16u;
+    const int r0 = t * kTileK + (l >> 4);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t row = (uint32_t)min(r0 + 4 * i, it.qlen - 1);
+      const uint32_t part_b = part0_b ^ (uint32_t)(16 * (i & 3));
+      __builtin_amdgcn_global_load_lds((gptr_t)(kp + (row * k_rs_b + part_b)), (lptr_t)(smem + BUF * kBuf + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(vp + (row * v_rs_b + part_b)), (lptr_t)(smem + (2 + BUF) * kBuf + i * 1024), 16, 0, 0);
     }
   };
   // this wave's 32 query rows of `it` -> its staging area (rows past the end of the sequence replay the last query)
@@ -280,7 +302,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int st = 0; st < 8; ++st)
+#ifndef VSEL_GQA_KO_S
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq_bf16x8(ka0[st]), gq_bf16x8(qf[st]), acc, 0, 0, 0);
+#else
+        acc[st] += __builtin_bit_cast(float, ka0[st][0]) * __builtin_bit_cast(float, qf[st][0]);
+#endif
       s[0] = acc;
     }
     issue_loads();
@@ -299,7 +325,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int st = 0; st < 8; ++st)
+#ifndef VSEL_GQA_KO_S
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq_bf16x8(ka1[st]), gq_bf16x8(qf[st]), acc, 0, 0, 0);
+#else
+        acc[st] += __builtin_bit_cast(float, ka1[st][0]) * __builtin_bit_cast(float, qf[st][0]);
+#endif
       s[1] = acc;
     }
     // ---- mask + online softmax: attn.hip's arithmetic, element for element -------------------------------------------------------
@@ -325,8 +355,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[KB][r]);
       }
     };
+#ifndef VSEL_GQA_KO_MAX
     mask_max(std::integral_constant<int, 0>{});
     if (two) mask_max(std::integral_constant<int, 1>{});
+#else
+    mx = s[0][3];
+#endif
     {
       float ha, hb;
       both_halves(mx, ha, hb);
@@ -350,13 +384,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
       constexpr int KB = decltype(kb_c)::value;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#ifdef VSEL_GQA_KO_EXP
+        const float p = fmaf(s[KB][r], scale_log2e, -m_run);
+#else
         const float p = __builtin_amdgcn_exp2f(fmaf(s[KB][r], scale_log2e, -m_run));
+#endif
         psum += p;
         pf[KB][r >> 3][r & 7] = (__bf16)p;
       }
     };
+#ifndef VSEL_GQA_KO_PROBS
     probs(std::integral_constant<int, 0>{});
     if (two) probs(std::integral_constant<int, 1>{});
+#else
+    pf[0][0] = gq_bf16x8(qf[0]); pf[0][1] = gq_bf16x8(qf[1]); pf[1][0] = gq_bf16x8(qf[2]); pf[1][1] = gq_bf16x8(qf[3]); psum = s[0][0];
+#endif
     l_run += psum;
     // ---- O^T += V^T P^T: (32-key block, 16-key half) groups of 8 transpose reads feeding 4 MFMAs, the next group's reads in flight
     auto issue = [&](auto g_c, u32x2 (&dst)[8]) {
@@ -373,7 +415,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const u32x4 w = {src[2 * dt][0], src[2 * dt][1], src[2 * dt + 1][0], src[2 * dt + 1][1]};
+#ifndef VSEL_GQA_KO_PV
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq_bf16x8(w), pf[G >> 1][G & 1], o[dt], 0, 0, 0);
+#else
+        o[dt][0] += __builtin_bit_cast(float, w[0]) + (float)pf[G >> 1][G & 1][0];
+#endif
       }
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -450,6 +496,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
     const bool last = t + 1 == cur.n_tiles;
     GQA_STAMP(2);
     auto issue_loads = [&]() {
+#ifdef VSEL_GQA_KO_DMA
+      return;
+#endif
+      if (one_loader) {
+        if (!head_wave) {
+          if (!last) load_tile_all(cur, t + 1, NXT{});
+          else if (next.n_tiles > 0) load_tile_all(next, 0, NXT{});
+        } else if (last && next.n_tiles > 0) {
+          load_q(next);
+        }
+        return;
+      }
       if (!last) {
         load_tile(cur, t + 1, NXT{});
       } else if (next.n_tiles > 0) {                 // the next item's rows and first tile fly under this item's last tile
@@ -469,7 +527,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
     else issue_loads();
     GQA_STAMP(4);
     if (last && tid == 0) s_cand[ipar] = pend;       // (drawn a whole item ago: no wait)
+#ifndef VSEL_GQA_KO_BAR
     __syncthreads();                                 // vmcnt(0) in front of it: every wave's direct loads have landed at the release
+#endif
     GQA_STAMP(5);
     if (!last) {
       ++t;
@@ -480,7 +540,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
     const int next_qmin = next.q0 + qw * 32;
     const bool next_has_rows = head_wave && next.n_tiles > 0 && next_qmin < next.qlen;
     if (next_has_rows) read_q();                     // (the current item's fragments are dead: its last S is done)
+#ifndef VSEL_GQA_KO_EPI
     if (had_rows) epilogue();
+#else
+    if (had_rows && o[0][0] == 123.f) epilogue();
+#endif
     GQA_STAMP(6);
     if (next.n_tiles == 0) return false;
 #pragma unroll

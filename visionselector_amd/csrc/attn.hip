@@ -694,12 +694,16 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   // 1 x 4096 112 vs 125, 8 x 2048 +15 %, 16 x 4096 +11 %, 2 x 8192 +16 %; 16 x 1100 -2 %, 32 x 524 -20 %: those keep the 4-wave form)
   const int g_rows64 = knob(VSEL_KNOB_ATTN_ROWS64);
   // short sequences in throughput-bound grids (packed batches of compressed prompts): one workgroup per (query tile, kv head) serving
-  // the whole q-head group (attn_fwd_gqa.hip).  Prefill over the queries' own contiguous keys only.
+  // the whole q-head group (attn_fwd_gqa.hip).  Prefill over the queries' own contiguous keys only.  From three rounds of its items
+  // (same-process A/B, tools/exp_attn_gqa.py, profiles/r05_gqa_ab.txt, 28 / 4 heads: 16 x 524 78 -> 61 us, 32 x 524 145 -> 113, 32 x 294 71 -> 54,
+  // 64 ragged prompts 326 -> 275, 16 x 1100 216 -> 193, 32 x 1216 485 -> 452; LLaVA-OV 32 / 8 heads 32 x 1230 597 -> 518; 3B 16 / 2 heads
+  // 32 x 524 86 -> 63; below that the per-head forms win: 8 x 524 42.1 vs 41.8, 4 x 524 24.3 vs 28.9 -- one item per workgroup and nothing
+  // to pipeline across)
   const int g_gqa = knob(VSEL_KNOB_ATTN_GQA);
   const int64_t rep_ = hq / hkv;
   if (d == 128 && g_attn_use_tr && !pg.block_table && !pg.seqlens_k && !pg.cu_k && g_attn_nw == 0 && rep_ >= 2 && rep_ <= 8 &&
       max_seqlen_q <= 16384 && g_rows64 != 1 &&
-      (g_gqa == 1 || (g_gqa < 0 && max_seqlen_q < 2048 && !split2 && cdiv(max_seqlen_q, 32 * (8 / rep_)) * hkv * n_seq > 256)))
+      (g_gqa == 1 || (g_gqa < 0 && max_seqlen_q < 2048 && !split2 && cdiv(max_seqlen_q, 32 * (8 / rep_)) * hkv * n_seq >= 768)))
     return attn::attn_fwd_gqa_launch(st, q, k, v, cu_q, n_seq, max_seqlen_q, hq, hkv, scale, causal, out, pg, lse);
   if (d == 128 && g_attn_use_tr && !pack && !pg.block_table && g_attn_nw == 0 &&
       (g_rows64 == 1 || (g_rows64 < 0 && max_seqlen_q >= 2048 && !split2)))

@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (config C3: fwd + bwd + grad all-reduce)")
     ap.add_argument("--no-single-sweep", action="store_true", help="skip the producer-side column-sum leg (SURVEY 8f N2)")
     ap.add_argument("--no-batch1", action="store_true", help="skip the one-image-per-call leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE config sweep / config-5 legs")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -177,6 +178,17 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
     from visionselector_amd import _native, ops
+
+    # what the collective library itself saw (world > 1): the line's n_gpus is otherwise only the launcher's WORLD_SIZE
+    rccl = None
+    if dist:
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)
+        props = torch.cuda.get_device_properties(local_rank)
+        me = str(getattr(props, "uuid", "")) or f"{props.name}:{getattr(props, 'pci_bus_id', local_rank)}:{local_rank}"
+        ids = [None] * world
+        dist.all_gather_object(ids, me)
+        rccl = {"ranks_seen": int(ones.item()), "distinct_devices": len(set(ids)), "backend": dist.get_backend()}
 
     b, n, d, hd = args.images, N_VIS, D, HD
     k = max(1, int(n * args.budget))
@@ -288,6 +300,8 @@ def main():
         "roofline": roofline, "roofline_path": path, "kernels": kern, "parity": parity,
     }
 
+    if rccl is not None:
+        res["rccl"] = rccl
     if train is not None:
         res["train_step"] = train
     # ---- single-sweep LIS: column sums from the merger's GELU, sum production timed inside ----------
@@ -308,6 +322,18 @@ def main():
             res["prefill_attention"] = bench_attention(ops, k)
         except Exception as e:  # the attention kernel is optional for this line
             res["prefill_attention"] = {"error": str(e)[:200]}
+    # ---- the other BASELINE.json configurations on one GPU (parity-tested cases; timed here so that the driver's line carries them) ----
+    if not args.no_configs:
+        del h, out, idx, scores
+        torch.cuda.empty_cache()
+        try:
+            res["config_sweep"] = bench_config_sweep(ops)
+        except Exception as e:  # optional leg
+            res["config_sweep"] = {"error": str(e)[:300]}
+        try:
+            res["config5"] = bench_config5(ops, _native)
+        except Exception as e:  # optional leg
+            res["config5"] = {"error": str(e)[:300]}
     if not args.no_llm:
         try:
             res["prefill_llm"] = bench_llm_prefill(_native, k)
@@ -604,9 +630,16 @@ def bench_attention(ops, k, text=64, hq=28, hkv=4, dh=128, layers=28, iters=200)
                 e1.record()
                 torch.cuda.synchronize()
                 return e0.elapsed_time(e1) / n
+            from visionselector_amd import _native
+            _native.profile_start()
+            ops.varlen_attn(q, kk, v, cu, L)
+            kern = sorted(_native.profile_stop())
             ms = timed(lambda: ops.varlen_attn(q, kk, v, cu, L), 100)
             fl = 4.0 * L * L * hq * dh / 2 * n_seq
-            out[tag] = {"n_seq": n_seq, "L": L, "fwd_ms": ms, "fwd_tflops": fl / (ms * 1e-3) / 1e12}
+            tf_ = fl / (ms * 1e-3) / 1e12
+            out[tag] = {"n_seq": n_seq, "L": L, "fwd_ms": ms, "fwd_tflops": tf_, "kernel": kern,
+                        "roofline": {"bound": "mfma", "achieved": tf_, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": tf_ / MFMA_BF16_PEAK_TFLOPS, "traffic": None}}
             if bwd:
                 do = torch.randn(n_seq * L, hq, dh, device="cuda", generator=gen).bfloat16()
                 o, lse = ops.varlen_attn_fwd_lse(q, kk, v, cu, L)
@@ -614,6 +647,98 @@ def bench_attention(ops, k, text=64, hq=28, hkv=4, dh=128, layers=28, iters=200)
                 out[tag].update({"bwd_ms": ms, "bwd_tflops_algorithmic": 2.5 * fl / (ms * 1e-3) / 1e12})
         except Exception as e:  # optional
             out[tag] = {"error": str(e)[:200]}
+    return out
+
+
+def _ev_us(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def bench_config_sweep(ops, iters=10):
+    """BASELINE.json configs 2 (7B, 10 / 20 / 50 % retain), 1 / 2's 3B geometry at batch and 4 (LLaVA-OV-1.5-8B, 8 x 729 tokens scored
+    jointly): vsel_lis_select on resident tokens, us per step, tokens/s and the SURVEY 8(d) path bytes against 8 TB/s."""
+    rows = []
+    g = torch.Generator(device="cuda").manual_seed(5)
+    mk = lambda *sh: (0.02 * torch.randn(*sh, device="cuda", generator=g)).bfloat16()  # noqa: E731
+    for name, d, hd, n, b, budgets in (("Qwen2.5-VL-7B N=2304", 3584, 1792, 2304, 128, (0.1, 0.2, 0.5)),
+                                       ("Qwen2.5-VL-3B N=576", 2048, 1024, 576, 512, (0.2,)),
+                                       ("LLaVA-OV-1.5-8B 8x729 joint", 4096, 2048, 5832, 48, (0.2,))):
+        h = torch.randn(b, n, d, device="cuda", generator=g).bfloat16()
+        wq, bq, wk, bk = mk(hd, d), mk(hd), mk(hd, d), mk(hd)
+        for r in budgets:
+            k = max(1, int(n * r))
+            us = _ev_us(lambda: ops.lis_select(h, wq, bq, wk, bk, k), iters)
+            by = algorithmic_bytes(b, n, d, hd, k)
+            rows.append({"config": name, "images_per_step": b, "n_vis": n, "d": d, "hd": hd, "k": k, "us_per_step": us,
+                         "tokens_per_s": b * n / (us * 1e-6),
+                         "roofline_path": {"bound": "hbm", "algorithmic_bytes_per_step": by, "achieved_GBps": by / (us * 1e-6) / 1e9,
+                                           "frac_of_8TBps": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}})
+        del h
+    torch.cuda.empty_cache()
+    return rows
+
+
+def bench_config5(ops, _native, n_prompts=64, iters=5):
+    """BASELINE.json config 5 on one GPU: a dynamic-resolution batch of 64 prompts, N_i ~ U{576..4096} visual + T_i ~ U{16..128} text tokens,
+    k_i = int(0.2 N_i).  Ragged LIS select; scores -> spliced prompt in one call (vsel_lis_select_splice); var-len causal attention over the
+    compressed packing vs over the uncompressed one, per layer (7B heads).  The 8-GPU form shards prompts over ranks (no collective)."""
+    import numpy as np
+    IMG = 151655
+    d, hd, hq, hkv = D, HD, 28, 4
+    rng = np.random.default_rng(n_prompts)
+    n_vis = [int(x) for x in rng.integers(576, 4097, n_prompts)]
+    n_txt = [int(x) for x in rng.integers(16, 129, n_prompts)]
+    ks = [int(x * 0.2) for x in n_vis]
+    seq = [a + t for a, t in zip(n_vis, n_txt)]
+    seq_c = [a + t for a, t in zip(ks, n_txt)]
+    g = torch.Generator(device="cuda").manual_seed(6)
+    mk = lambda *sh: (0.02 * torch.randn(*sh, device="cuda", generator=g)).bfloat16()  # noqa: E731
+    wq, bq, wk, bk = mk(hd, d), mk(hd), mk(hd, d), mk(hd)
+    h = torch.randn(sum(n_vis), d, device="cuda", generator=g).bfloat16()
+    ids = torch.cat([torch.cat((torch.randint(10, 1000, (t // 2,)), torch.full((a,), IMG), torch.randint(10, 1000, (t - t // 2,))))
+                     for a, t in zip(n_vis, n_txt)]).cuda()
+    emb = torch.randn(sum(seq), d, device="cuda", generator=g).bfloat16()
+    pos = torch.arange(sum(seq), device="cuda")[None].expand(3, -1).contiguous()
+    e = 2
+    out = {"prompts": n_prompts, "visual_tokens": sum(n_vis), "kept": sum(ks), "packed_len": sum(seq), "packed_len_compressed": sum(seq_c)}
+    us = _ev_us(lambda: ops.lis_select_varlen(h, n_vis, ks, wq, bq, wk, bk), iters)
+    by = sum(n_vis) * d * e + sum(ks) * d * e + 2 * hd * d * e + 2 * hd * e + sum(n_vis) * 4 + sum(ks) * 8
+    out["lis_select_ragged"] = {"us": us, "tokens_per_s": sum(n_vis) / (us * 1e-6),
+                                "roofline": {"bound": "hbm", "algorithmic_bytes": by, "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                                             "unit": "GB/s", "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}}
+    us = _ev_us(lambda: ops.lis_select_splice(h, wq, bq, wk, bk, ids, emb, IMG, seq, n_vis, ks, position_ids=pos), iters)
+    # tokens read once + text rows read + the spliced prompt written + weights + scores
+    by = sum(n_vis) * d * e + sum(n_txt) * d * e + sum(seq_c) * d * e + 2 * hd * d * e + sum(n_vis) * 4 + sum(seq) * 8
+    out["lis_select_splice"] = {"us": us, "tokens_per_s": sum(n_vis) / (us * 1e-6),
+                                "roofline": {"bound": "hbm", "algorithmic_bytes": by, "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                                             "unit": "GB/s", "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}}
+    del h, emb
+    for tag, lens in (("attention_compressed", seq_c), ("attention_uncompressed", seq)):
+        t = sum(lens)
+        q = torch.randn(t, hq, 128, device="cuda", generator=g).bfloat16()
+        kk = torch.randn(t, hkv, 128, device="cuda", generator=g).bfloat16()
+        v = torch.randn(t, hkv, 128, device="cuda", generator=g).bfloat16()
+        cu = torch.tensor(np.concatenate(([0], np.cumsum(lens))), dtype=torch.int32, device="cuda")
+        _native.profile_start()
+        ops.varlen_attn(q, kk, v, cu, max(lens))
+        kern = sorted(_native.profile_stop())
+        us = _ev_us(lambda: ops.varlen_attn(q, kk, v, cu, max(lens)), iters)
+        fl = sum(4.0 * L * L * hq * 128 / 2 for L in lens)
+        tf = fl / (us * 1e-6) / 1e12
+        out[tag] = {"us_per_layer": us, "tflops": tf, "kernel": kern,
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS}}
+        del q, kk, v
+    out["attention_speedup"] = out["attention_uncompressed"]["us_per_layer"] / out["attention_compressed"]["us_per_layer"]
+    torch.cuda.empty_cache()
     return out
 
 
@@ -648,7 +773,7 @@ def bench_llm_prefill(_native, k, text=64, iters=5):
         model(inputs_embeds=x, position_ids=pos, use_cache=False)
         torch.cuda.synchronize()
         prof = _native.profile_stop()      # (from 2048 tokens the forward is attn_fwd64_kernel, csrc/attn_fwd64.hip)
-        calls = prof.get("varlen_attn_fwd_kernel", (0.0, 0))[1] + prof.get("attn_fwd64_kernel", (0.0, 0))[1]
+        calls = sum(prof.get(nm, (0.0, 0))[1] for nm in ("varlen_attn_fwd_kernel", "attn_fwd64_kernel", "attn_fwd_gqa_kernel"))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):

@@ -25,7 +25,9 @@ typedef enum {
   VSEL_ERR_INVALID = 1,      /* bad argument (shape, alignment, k out of range, null pointer) */
   VSEL_ERR_WORKSPACE = 2,    /* workspace too small: call the matching *_workspace_bytes()       */
   VSEL_ERR_HIP = 3,          /* a HIP runtime call / launch failed                               */
-  VSEL_ERR_UNSUPPORTED = 4   /* shape outside what the kernels implement                         */
+  VSEL_ERR_UNSUPPORTED = 4,  /* shape outside what the kernels implement                         */
+  VSEL_ERR_BUSY = 5          /* 64 launches of one attention kernel family are in flight on OTHER streams (every work-queue counter
+                                slot is taken): synchronise one of them and call again                                              */
 } vsel_status;
 
 typedef enum {
@@ -118,8 +120,11 @@ int vsel_gather_rows(void* stream, const void* h, vsel_dtype hdtype, int64_t d, 
                      const int64_t* idx, void* out);
 
 /* -------- differentiable top-k ------------------------------------------------------------------
- * TopK.forward / _find_ts (FT/compression_method/selector_model.py:53-58,72-86): 64 bisection steps
- * for t with sum(sigmoid(x + t)) = k, fp32.  xs [B, N] float32 -> ps [B, N], ts [B].
+ * TopK.forward / _find_ts (FT/compression_method/selector_model.py:53-58,72-86): the t with
+ * sum(sigmoid(x + t)) = k, fp32 -- the root the reference's 64 bisection steps converge to, found by
+ * bracketed Newton steps on the same bracket (|t - reference t| ~ 1e-6, not bit-equal; the fused
+ * training tail and this entry sum in different orders and agree to that noise too).
+ * xs [B, N] float32 -> ps [B, N], ts [B].
  * Reference asserts 0 < k < N (:75) -> VSEL_ERR_INVALID.                                          */
 int vsel_soft_topk_fwd(void* stream, const float* xs, int64_t b, int64_t n, int64_t k, float* ps, float* ts);
 /* TopK.backward (FT/compression_method/selector_model.py:60-70).                                  */

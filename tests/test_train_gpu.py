@@ -77,6 +77,33 @@ def test_soft_topk_batched_and_edges(ops):
         ops.soft_topk_fwd(dev(xs), 0)
 
 
+def test_soft_topk_saturated_and_wide_spread_scores_converge(ops):
+    """Rows on which a Newton step is useless far from the root (f' = sum sigmoid (1 - sigmoid) ~ 0): two clusters 60 apart with k
+    between their sizes' boundary, scores spread over +-200, a single outlier, and a row that is constant.  The iteration must fall
+    back to a real bisection of the reference's bracket and still return the root: |sum(ps) - k| small and ps within the usual gate of
+    the reference's 64-step bisection (oracle/lis.py::find_ts)."""
+    rng = np.random.default_rng(11)
+    n = 2304
+    rows = []
+    a = np.concatenate((np.full(300, 30.0), np.full(n - 300, -30.0))) + 0.01 * rng.standard_normal(n)      # two saturated clusters
+    rows.append(a)
+    rows.append(rng.uniform(-200, 200, n))                                                                   # wide spread
+    b = 0.05 * rng.standard_normal(n)
+    b[7] = 500.0                                                                                             # one huge outlier
+    rows.append(b)
+    rows.append(np.full(n, 0.25))                                                                            # constant row
+    rows.append(np.concatenate((np.full(460, 80.0), np.full(n - 460, -80.0))))                               # k exactly at the cluster edge
+    xs = np.stack(rows).astype(np.float32)
+    for k in (1, 300, 460, 461, 1152, n - 1):
+        ps, ts = ops.soft_topk_fwd(dev(xs), k)
+        ps = ps.cpu().numpy()
+        assert np.isfinite(ps).all() and np.isfinite(ts.cpu().numpy()).all()
+        assert np.abs(ps.sum(1) - k).max() <= 5e-3 * max(1.0, k / 460), (k, ps.sum(1))
+        _, ps_ref = olis.find_ts(xs, k)
+        # (a plateau of f -- the cluster-edge rows -- leaves t undetermined over an interval: compare ps, not t)
+        assert np.abs(ps - ps_ref).max() <= 2e-4, (k, np.abs(ps - ps_ref).max())
+
+
 # ---------------------------------------------------------------------------------------------------
 # training block forward
 # ---------------------------------------------------------------------------------------------------

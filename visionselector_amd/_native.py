@@ -8,7 +8,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libvsel.so")
 
 VSEL_BF16, VSEL_F32 = 0, 1
-STATUS = {0: "VSEL_OK", 1: "VSEL_ERR_INVALID", 2: "VSEL_ERR_WORKSPACE", 3: "VSEL_ERR_HIP", 4: "VSEL_ERR_UNSUPPORTED"}
+STATUS = {0: "VSEL_OK", 1: "VSEL_ERR_INVALID", 2: "VSEL_ERR_WORKSPACE", 3: "VSEL_ERR_HIP", 4: "VSEL_ERR_UNSUPPORTED", 5: "VSEL_ERR_BUSY"}
 
 
 class VselError(RuntimeError):

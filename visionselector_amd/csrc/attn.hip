@@ -713,8 +713,7 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   const int64_t n_items = pack ? hkv * n_seq : (int64_t)q_tiles * hq * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
   const int64_t slots = (big || split2) ? 256 : 512;               // resident workgroups (64 KiB LDS each; 128 KiB with two streams)
-  static std::atomic<unsigned> next_slot{0};      // (host threads may launch concurrently: a slot per launch, 64 in rotation)
-  int slot = -1;                                                   // -1: direct mapping, one item per workgroup
+  int slot = -1, taken = -1;                                       // -1: direct mapping, one item per workgroup; a counter slot per queued launch
   // Few rounds of items (slots < n_items <= 2.35 slots, 4-wave form): the work queue's atomic round trip and hand-over barriers in front of
   // every item cost more than its balancing wins -- the heaviest-first list is dealt out statically instead, alternate rounds mirrored.
   // tools/exp_attn_static.py, profiles/r04_attn_static.txt (queue -> static, us): 4 x 524 30.6 -> 23.6, 6 x 524 41.6 -> 35.6, 8 x 524
@@ -724,7 +723,8 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   if (!pack && !split2 && attn_static_deal(n_items, slots, !big && d == 128)) {
     slot = -2;                                                     // static deal (knob attn_static)
   } else if (n_items > slots) {
-    slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 63u);
+    if (int rc = queue_slot_acquire(kSlotFwd, st, &taken)) return rc;
+    slot = taken;
     int* counters = nullptr;
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_attn_work_counter)));
     VSEL_HIP_CHECK(hipMemsetAsync(counters + 8 * slot, 0, 8 * sizeof(int), st));
@@ -774,6 +774,7 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
     if (big) VSEL_ATTN_LAUNCH(true, 8, 64); else VSEL_ATTN_LAUNCH(true, 4, 64);
   }
 #undef VSEL_ATTN_LAUNCH
+  queue_slot_launched(kSlotFwd, taken, st);
   VSEL_AFTER_LAUNCH(st, "varlen_attn_fwd_kernel");
   return VSEL_OK;
 }

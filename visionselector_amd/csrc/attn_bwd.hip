@@ -1000,12 +1000,14 @@ static int bwd_split_heads(int64_t total, int64_t n_seq, int64_t max_seqlen, int
 }
 static bool bwd_use_split(int64_t total, int64_t n_seq, int64_t max_seqlen, int64_t hq, int64_t hkv) { return bwd_split_heads(total, n_seq, max_seqlen, hq, hkv) != 0; }
 
+static size_t bwd_workspace_bytes_for(int64_t total, int64_t hq, bool split) {
+  size_t bytes = (((size_t)total * (size_t)hq * sizeof(float) + 255) & ~(size_t)255) * 2;   // D, lse * log2(e)
+  if (split) bytes += 2 * (size_t)total * (size_t)hq * bwd::kD * sizeof(float);             // dK / dV partials per q head
+  return bytes;
+}
 extern "C" size_t vsel_varlen_attn_bwd_workspace_bytes(int64_t total, int64_t hq, int64_t hkv, int64_t n_seq, int64_t max_seqlen) {
   if (total < 1 || hq < 1 || hkv < 1 || n_seq < 1 || max_seqlen < 1) return 0;
-  size_t bytes = (((size_t)total * (size_t)hq * sizeof(float) + 255) & ~(size_t)255) * 2;   // D, lse * log2(e)
-  if (bwd_use_split(total, n_seq, max_seqlen, hq, hkv))
-    bytes += 2 * (size_t)total * (size_t)hq * bwd::kD * sizeof(float);             // dK / dV partials per q head
-  return bytes;
+  return bwd_workspace_bytes_for(total, hq, bwd_use_split(total, n_seq, max_seqlen, hq, hkv));
 }
 
 extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* q, const void* k, const void* v, const void* out,
@@ -1021,7 +1023,12 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
   if (((uintptr_t)dout | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)dq | (uintptr_t)dk |
        (uintptr_t)dv | (uintptr_t)workspace) & 15)
     return fail(VSEL_ERR_INVALID, "attention tensors must be 16-byte aligned");
-  if (workspace_bytes < vsel_varlen_attn_bwd_workspace_bytes(total, hq, hkv, n_seq, max_seqlen))
+  // the dK / dV item form is decided ONCE per call (the knobs are read here and nowhere below): the workspace check and the launch cannot
+  // disagree when a knob changes on another thread in between.  NOTE: the form depends on the call's total / mean / longest length, and each
+  // form associates the fp32 sums of a group's q heads differently -- unlike the forward, a sequence's dK / dV may differ by one bf16
+  // rounding with what it is packed with (every form is deterministic and within the gradient gate of the fp64 oracle).
+  const int split_heads0 = bwd_split_heads(total, n_seq, max_seqlen, hq, hkv);
+  if (workspace_bytes < bwd_workspace_bytes_for(total, hq, split_heads0 != 0))
     return fail(VSEL_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
   VSEL_PROF_BEGIN(st);
@@ -1031,13 +1038,15 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
   float* lse2 = (float*)((char*)workspace + d_bytes);
   int* counters = nullptr;
   VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(bwd::g_bwd_counter)));
-  static std::atomic<unsigned> next_slot{0};      // (host threads may launch concurrently: a slot per launch, 64 in rotation)
-  auto take_slot = [&](int64_t n_items, int64_t resident, int& slot) -> int {
+  // (a counter slot per queued launch: common.h, queue_slot_acquire; `taken` = the slot to report as launched, or -1)
+  auto take_slot = [&](int64_t n_items, int64_t resident, int& slot, int& taken) -> int {
     slot = -1;
+    taken = -1;
     if (attn_static_deal(n_items, resident, true)) {
       slot = -2;
     } else if (n_items > resident) {
-      slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 63u);
+      if (int rc = queue_slot_acquire(kSlotBwd, st, &taken)) return rc;
+      slot = taken;
       if (hipMemsetAsync(counters + 8 * slot, 0, 8 * sizeof(int), st) != hipSuccess) return fail(VSEL_ERR_HIP, "hipMemsetAsync(counter)");
     }
     return VSEL_OK;
@@ -1060,17 +1069,18 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
     const int q_tiles = (int)cdiv(max_seqlen, 128);
     const int64_t n_items = (int64_t)q_tiles * hq * n_seq;
     if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
-    int slot;
-    if (int rc = take_slot(n_items, 512, slot)) return rc;
+    int slot, taken;
+    if (int rc = take_slot(n_items, 512, slot, taken)) return rc;
     hipLaunchKernelGGL(bwd::attn_bwd_dq_kernel, dim3((unsigned)std::min<int64_t>(n_items, 512)), dim3(256), 0, st,
                        (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, (const uint16_t*)out, lse, dvec, lse2,
                        cu_seqlens,
                        (int)hq, (int)hkv, scale, causal, (uint16_t*)dq, q_tiles, (int)n_seq, slot, xcd_local_dq);
+    queue_slot_launched(kSlotBwd, taken, st);
     VSEL_AFTER_LAUNCH(st, "attn_bwd_dq_kernel");
   }
   const int g_dkdv64 = knob(VSEL_KNOB_ATTN_BWD_DKDV64);
   {
-    int split_heads = bwd_split_heads(total, n_seq, max_seqlen, hq, hkv);
+    int split_heads = split_heads0;
     const bool split = split_heads != 0;
     const bool dkdv64 = g_dkdv64 == 1 || (g_dkdv64 < 0 && max_seqlen >= (split_heads == 1 ? kDkdv64SplitFromTokens : kDkdv64FromTokens));
     if (!dkdv64 && split_heads > 1 && knob(VSEL_KNOB_ATTN_BWD_WAVES) != 8) split_heads = 1;     // (the 4-wave kernel: per-head items only)
@@ -1085,8 +1095,8 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
                                       dv_part, split_heads, xcd_local_dkdv))
         return rc;
     } else {
-      int slot;
-      if (int rc = take_slot(n_items, 256, slot)) return rc;
+      int slot, taken;
+      if (int rc = take_slot(n_items, 256, slot, taken)) return rc;
       const dim3 grid((unsigned)std::min<int64_t>(n_items, 256));
       const bool w8 = knob(VSEL_KNOB_ATTN_BWD_WAVES) == 8;
 #define VSEL_DKDV_ARGS (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu_seqlens, (int)hq, \
@@ -1099,6 +1109,7 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
         else hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<false>), grid, dim3(256), 0, st, VSEL_DKDV_ARGS);
       }
 #undef VSEL_DKDV_ARGS
+      queue_slot_launched(kSlotBwd, taken, st);
       VSEL_AFTER_LAUNCH(st, "attn_bwd_dkdv_kernel");
     }
     if (split) {

@@ -123,12 +123,12 @@ int dkdv64_launch(hipStream_t st, const void* q, const void* k, const void* v, c
   const int k_blocks = (int)cdiv(max_seqlen, 128);
   const int64_t n_items = (int64_t)k_blocks * hkv * (split ? cdiv(hq / hkv, split) : 1) * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
-  static std::atomic<unsigned> next_slot{0};      // (host threads may launch concurrently: a slot per launch, 64 in rotation)
-  int slot = -1;
+  int slot = -1, taken = -1;                      // (a counter slot per queued launch: common.h, queue_slot_acquire)
   if (attn_static_deal(n_items, 256, true, 36)) {
     slot = -2;
   } else if (n_items > 256) {
-    slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 63u);
+    if (int rc = queue_slot_acquire(kSlotDkdv64, st, &taken)) return rc;
+    slot = taken;
     int* counters = nullptr;
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_dkdv64_work_counter)));
     VSEL_HIP_CHECK(hipMemsetAsync(counters + 8 * slot, 0, 8 * sizeof(int), st));
@@ -137,6 +137,7 @@ int dkdv64_launch(hipStream_t st, const void* q, const void* k, const void* v, c
                      (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu, (int)hq, (int)hkv, scale,
                      scale * 1.4426950408889634f, causal, (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, split, k_blocks, (int)n_seq, slot,
                      xcd_local);
+  queue_slot_launched(kSlotDkdv64, taken, st);
   VSEL_AFTER_LAUNCH(st, "attn_bwd_dkdv64_kernel");
   return VSEL_OK;
 }

@@ -138,12 +138,12 @@ int dq64_launch(hipStream_t st, const void* q, const void* k, const void* v, con
   const int q_tiles = (int)cdiv(max_seqlen, kBlockQ);
   const int64_t n_items = (int64_t)q_tiles * hq * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
-  static std::atomic<unsigned> next_slot{0};      // (host threads may launch concurrently: a slot per launch, 64 in rotation)
-  int slot = -1;
+  int slot = -1, taken = -1;                      // (a counter slot per queued launch: common.h, queue_slot_acquire)
   if (attn_static_deal(n_items, 256, true, 36)) {
     slot = -2;
   } else if (n_items > 256) {
-    slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 63u);
+    if (int rc = queue_slot_acquire(kSlotDq64, st, &taken)) return rc;
+    slot = taken;
     int* counters = nullptr;
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_dq64_work_counter)));
     VSEL_HIP_CHECK(hipMemsetAsync(counters + 8 * slot, 0, 8 * sizeof(int), st));
@@ -151,6 +151,7 @@ int dq64_launch(hipStream_t st, const void* q, const void* k, const void* v, con
   hipLaunchKernelGGL(attn_bwd_dq64_kernel, dim3((unsigned)std::min<int64_t>(n_items, 256)), dim3(256), 0, st, (const uint16_t*)q,
                      (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, (const uint16_t*)out, lse, dvec, lse2, cu, (int)hq, (int)hkv,
                      scale, scale * 1.4426950408889634f, causal, (uint16_t*)dq, q_tiles, (int)n_seq, slot, xcd_local);
+  queue_slot_launched(kSlotDq64, taken, st);
   VSEL_AFTER_LAUNCH(st, "attn_bwd_dq64_kernel");
   return VSEL_OK;
 }

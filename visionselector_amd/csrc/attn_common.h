@@ -146,6 +146,8 @@ __device__ __forceinline__ void lane0_atomic_max(int* p, int v) {
   uint64_t save;
   asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_smax %1, %2, off\n\ts_mov_b64 exec, %0" : "=&s"(save) : "v"(p), "v"(v) : "memory");
 }
+// CALLERS: every thread of the workgroup calls it (workgroups of >= 64 threads; the single-wave PACK form never does); the work is done
+// by wave 0 with all 64 lanes active -- lane0_atomic_max narrows EXEC by hand and the ballot needs the whole wave.
 template <class NonEmpty>
 __device__ __forceinline__ void queue_skip_empty_run(int* counter, int tid, const int32_t* __restrict__ cu, int n_seq, int width, int level,
                                                      int seq, NonEmpty nonempty) {

@@ -581,14 +581,15 @@ int attn_fwd_gqa_launch(hipStream_t st, const void* q, const void* k, const void
   const int64_t q_tiles = cdiv(max_seqlen_q, block_q);
   const int64_t n_items = q_tiles * hkv * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
-  static std::atomic<unsigned> next_slot{0};
-  const int slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 63u);
+  int slot = -1;                                  // (a counter slot per launch: common.h, queue_slot_acquire)
+  if (int rc = queue_slot_acquire(kSlotGqa, st, &slot)) return rc;
   int* counters = nullptr;
   VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_gqa_work_counter)));
   const int grid = (int)std::min<int64_t>(n_items, 256);                      // 128 KiB of LDS: one workgroup per CU
   VSEL_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(counters + slot), grid, 1, st));
   hipLaunchKernelGGL(attn_fwd_gqa_kernel, dim3(grid), dim3(512), 0, st, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, cu_q,
                      (int)hq, (int)hkv, scale * 1.4426950408889634f, causal, (uint16_t*)out, (int)q_tiles, (int)n_seq, counters + slot, pg, lse);
+  queue_slot_launched(kSlotGqa, slot, st);
   VSEL_AFTER_LAUNCH(st, "attn_fwd_gqa_kernel");
   return VSEL_OK;
 }

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <atomic>
+#include <mutex>
 #include <string.h>
 #include <utility>
 #include <vector>
@@ -95,6 +96,68 @@ extern "C" void vsel_debug_reset(void) {
   using namespace vsel;
   for (int i = 0; i < VSEL_KNOB_COUNT; ++i) knobs().v[i].store(knob_default(i), std::memory_order_relaxed);
 }
+
+namespace vsel {
+namespace {
+struct SlotRing {
+  hipEvent_t ev[64];
+  hipStream_t last_stream[64];
+  unsigned char state[64];      // 0 free / never used, 1 launched (event recorded), 2 reserved by a call in progress, 3 launched untracked
+  unsigned next = 0;
+  bool have_events = false;
+};
+std::mutex g_slot_mu;
+SlotRing g_slot_rings[16][kSlotFamilies];
+}  // namespace
+int queue_slot_acquire(int family, hipStream_t st, int* slot) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(VSEL_ERR_HIP, "hipGetDevice");
+  std::lock_guard<std::mutex> lock(g_slot_mu);
+  SlotRing& r = g_slot_rings[dev][family];
+  if (!r.have_events) {
+    for (int i = 0; i < 64; ++i) {
+      if (hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) != hipSuccess) return fail(VSEL_ERR_HIP, "hipEventCreate(queue slot)");
+      r.state[i] = 0;
+      r.last_stream[i] = nullptr;
+    }
+    r.have_events = true;
+  }
+  for (int i = 0; i < 64; ++i) {
+    const int s = (int)((r.next + i) & 63u);
+    bool ok = r.state[s] == 0 || r.state[s] == 3;           // (3: a captured launch -- untracked, rotation only)
+    if (r.state[s] == 1) {
+      if (r.last_stream[s] == st) ok = true;                // stream order: the counter's previous user is done when this launch starts
+      else {
+        const hipError_t q = hipEventQuery(r.ev[s]);
+        if (q == hipSuccess) ok = true;
+        else if (q != hipErrorNotReady) { (void)hipGetLastError(); ok = true; }   // (the event's stream is gone: nothing in flight)
+      }
+    }
+    if (ok) {
+      r.state[s] = 2;
+      r.next = (unsigned)s + 1u;
+      *slot = s;
+      return VSEL_OK;
+    }
+  }
+  return fail(VSEL_ERR_BUSY, "64 launches of this attention kernel are in flight on other streams: every work-queue counter is taken");
+}
+void queue_slot_launched(int family, int slot, hipStream_t st) {
+  int dev = 0;
+  if (slot < 0 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
+  std::lock_guard<std::mutex> lock(g_slot_mu);
+  SlotRing& r = g_slot_rings[dev][family];
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  if (capturing || hipEventRecord(r.ev[slot], st) != hipSuccess) {
+    (void)hipGetLastError();
+    r.state[slot] = 3;
+  } else {
+    r.state[slot] = 1;
+  }
+  r.last_stream[slot] = st;
+}
+}  // namespace vsel
 
 namespace vsel {
 // Per-kernel timing with HIP events recorded on the launch stream between kernels.  Off by default;

@@ -103,7 +103,9 @@ __global__ __launch_bounds__(kSpliceThreads) void select_splice_small_kernel(
     // same scores, with vsel_soft_topk_fwd's arithmetic (bit-identical), beside the select / splice workgroups instead of in a
     // launch of its own behind them (24 us of one CU at 2304 tokens before round 4, then 2 launches -> 1)
     __shared__ float soft_red[6][NW];
-    if (g.sane) soft_topk_row_256x16<NW>(scores + g.rb, g.nvis, g.ko, soft.ps + g.rb, soft.ts + s, soft_red);
+    // (rows, n and k come from the host-validated segment view, not from the prompt: a prompt whose placeholder count does not
+    // match -- !g.sane, reported through stats[3] -- still gets the soft top-k of its scores instead of uninitialised memory)
+    if (g.nvis >= 2 && g.ko >= 1 && g.ko < g.nvis) soft_topk_row_256x16<NW>(scores + g.rb, g.nvis, g.ko, soft.ps + g.rb, soft.ts + s, soft_red);
     return;
   }
   if (b == 0 && tid == 0 && cu_out) {

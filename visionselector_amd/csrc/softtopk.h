@@ -61,7 +61,7 @@ __device__ __forceinline__ float find_ts_newton(const float (&xr)[E], float sx, 
   // iteration until a step is shorter than 1e-4, the reference-accurate one (expf + division, ~30 instructions) finishes it --
   // the returned t is a fixed point of the ACCURATE iteration; the switch is block-uniform (every thread holds the same st, dt).
   bool accurate = false;
-  for (int it = 0; it < 48; ++it) {
+  for (int it = 0; it < 64; ++it) {
     float s = 0.f, d = 0.f;
     if (accurate) {
 #pragma unroll
@@ -81,11 +81,15 @@ __device__ __forceinline__ float find_ts_newton(const float (&xr)[E], float sx, 
     float st, dt;
     block_sum2(s, d, 2 + 2 * (it & 1), st, dt);      // slots alternate: one barrier per step is enough
     float tn = t - (st - kf) / fmaxf(dt, 1e-30f);
-    if (accurate) {
-      if (st < kf) lo = t; else hi = t;              // the bracket of :82-84, kept valid by every ACCURATE evaluation
+    // the bracket of :82-84.  Every ACCURATE evaluation updates it; a fast one (relative error < 1e-6 per term, < 1e-6 n on the sum)
+    // only when the sum is further from k than that error can explain -- so the root never leaves (lo, hi), and rows whose sigmoids are
+    // saturated or whose scores are spread wide (f' ~ 0: the Newton step shoots out of the bracket) fall back to a true bisection
+    // instead of sitting on a clamped end until the iteration cap.
+    if (accurate || fabsf(st - kf) > 8e-6f * nf) {
+      if (st < kf) lo = t; else hi = t;
     }
     // (non-strict: st == k exactly gives tn == t == the bracket end just set -- that is convergence, not an escape)
-    if (!(tn >= lo && tn <= hi)) tn = accurate ? 0.5f * (lo + hi) : fminf(fmaxf(tn, lo), hi);
+    if (!(tn >= lo && tn <= hi)) tn = 0.5f * (lo + hi);
     const float step = fabsf(tn - t);
     // converged: a Newton step from an accurate evaluation no longer moves t by more than ~8 ulps.  (Not 1 ulp: the fp32 sum of n
     // sigmoids carries ~1e-4 of rounding noise, i.e. steps of ~3e-7 for ever; quadratic convergence means the step BEFORE a

@@ -1,7 +1,7 @@
 // Training LIS block (reference: qwen-vl-finetune/compression_method/selector_model.py:158-173 forward,
 // :308-311 constraint loss, :60-70 TopK.backward; llava-ov-15/compression_method/selector_model.py:127-142).
 //
-// forward : scores (lis_kernels.h) -> soft top-k (64-step bisection) -> h_new = ps * h -> hard mask y -> BCE
+// forward : scores (lis_kernels.h) -> soft top-k (the root of _find_ts by bracketed Newton steps, softtopk.h) -> h_new = ps * h -> hard mask y -> BCE
 // backward: closed form of autograd through the scorer (SURVEY.md section 7 hard part 4).  With g = dL/dscores,
 //           rs = 1/sqrt(Hd), xbar = mean x, kbar = Wk xbar + bk:
 //             dWq = (kbar rs) (x) sum_i g_i x_i        dbq = kbar rs sum_i g_i

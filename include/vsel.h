@@ -26,8 +26,8 @@ typedef enum {
   VSEL_ERR_WORKSPACE = 2,    /* workspace too small: call the matching *_workspace_bytes()       */
   VSEL_ERR_HIP = 3,          /* a HIP runtime call / launch failed                               */
   VSEL_ERR_UNSUPPORTED = 4,  /* shape outside what the kernels implement                         */
-  VSEL_ERR_BUSY = 5          /* 64 launches of one attention kernel family are in flight on OTHER streams (every work-queue counter
-                                slot is taken): synchronise one of them and call again                                              */
+  VSEL_ERR_BUSY = 5          /* more than 64 streams have launches of one attention kernel family in flight (a work-queue counter
+                                slot per stream): synchronise one of them and call again                                            */
 } vsel_status;
 
 typedef enum {

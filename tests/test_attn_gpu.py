@@ -563,3 +563,27 @@ def test_gqa_shared_forward_on_head_major_strided_tensors(ops, b, hq, hkv, l, ca
             prof = N.profile_stop()
             assert ("attn_fwd_gqa_kernel" in prof) == bool(g), prof
     assert torch.equal(outs[0], outs[1])
+
+
+def test_work_queue_slots_across_streams(ops):
+    """Queued attention launches on many streams at once: every stream owns a work-queue counter slot (csrc/common.hip), so concurrent
+    launches never share a counter -- results equal the single-stream result on each of 70 streams (more than the 64 slots: idle streams'
+    slots are taken over)."""
+    lens = [524] * 16
+    total = sum(lens)
+    g = torch.Generator(device="cuda").manual_seed(21)
+    q = torch.randn(total, 28, 128, device="cuda", generator=g).bfloat16()
+    k = torch.randn(total, 4, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(total, 4, 128, device="cuda", generator=g).bfloat16()
+    cu = torch.arange(0, total + 1, 524, dtype=torch.int32, device="cuda")
+    ref = ops.varlen_attn(q, k, v, cu, 524)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(70)]
+    outs = []
+    for rnd in range(2):
+        for st in streams:
+            with torch.cuda.stream(st):
+                outs.append(ops.varlen_attn(q, k, v, cu, 524))
+        torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, ref)

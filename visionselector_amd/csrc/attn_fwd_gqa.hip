@@ -98,8 +98,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
   constexpr int kSteps = 8, kDTiles = 4, kHeadDim = 128;
   // ONE __shared__ object (attn.hip: a second one makes hipcc drain vmcnt in front of every tile's first ds_read)
   __shared__ __attribute__((aligned(1024))) char smem[kLds];
-  // control words: s_cand[item parity] = the candidate drawn two items ahead, published in front of an item's last barrier and read
-  // behind it (two slots: a wave may reach the next item's last round -- a single-tile item -- while another has not read yet);
+  // control words: s_cand[item parity] = the candidate drawn two items ahead, published in front of an item's FIRST barrier and read
+  // behind it (two slots: a wave may reach the next item's first barrier -- after a single-tile item -- while another has not read yet);
   // s_slow = the redraw of the (rare) empty-candidate path, which has its own two barriers
   int* const s_cand = reinterpret_cast<int*>(smem + kCtl);
   int& s_slow = *reinterpret_cast<int*>(smem + kCtl + 8);
@@ -116,7 +116,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
   const int64_t v_hs = pg.v_row_stride ? pg.v_head_stride : kv_hs;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef VSEL_GQA_KO_HALF
+  const bool head_wave = wave < 4;                 // timing experiment (WRONG results): one computing wave per SIMD
+#else
   const bool head_wave = wave < QW * rep;          // (7 q heads: wave 7 only helps with the tile loads)
+#endif
 #ifdef VSEL_GQA_LOADER
   const bool one_loader = QW * rep == 7;           // exactly one spare wave: it issues every tile load
 #else
@@ -125,6 +129,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
   const int qw = head_wave ? wave / rep : 0;       // this wave's 32-query slice
   const int hl = head_wave ? wave % rep : 0;       // ... and q head inside the group
   const int j = lane & 31, hh = lane >> 5;
+#ifdef VSEL_GQA_PRIO
+  // waves w and w + 4 share a SIMD and the older one wins every arbitration: static priority for the younger half
+  if (wave >= 4) __builtin_amdgcn_s_setprio(VSEL_GQA_PRIO);
+#endif
 #ifdef VSEL_GQA_TRACE
   const bool tr_on = blockIdx.x < 8 && (wave == 0 || wave == 5) && lane == 0;
   int tr_n = 0;
@@ -254,7 +262,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
   int cand = __builtin_amdgcn_readfirstlane(s_slow);
   __syncthreads();
   GqaItem next = validate(cand);
-  int pend = 0;                                     // thread 0: the draw for the item after `next`, in flight
+  GqaItem next2{0, 0, 0, 0, 0, 0};                  // the item after `next`: decoded during the current item's first round
+  int pend = 0;                                     // thread 0: the draw for that item, in flight
   if (tid == 0) pend = atomicAdd(counter, 1);
   int ipar = 0;                                     // item parity (slot of s_cand)
   int t = 0;                                        // tile of the current item
@@ -494,6 +503,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
     constexpr int CUR = decltype(cur_c)::value;
     using NXT = std::integral_constant<int, 1 - CUR>;
     const bool last = t + 1 == cur.n_tiles;
+    const bool first = t == 0;
     GQA_STAMP(2);
     auto issue_loads = [&]() {
 #ifdef VSEL_GQA_KO_DMA
@@ -526,11 +536,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
     if (nkb > 0) tile_body(cur_c, t, nkb, issue_loads);
     else issue_loads();
     GQA_STAMP(4);
-    if (last && tid == 0) s_cand[ipar] = pend;       // (drawn a whole item ago: no wait)
+    if (first && tid == 0) s_cand[ipar] = pend;      // (drawn at the item switch, a whole tile ago)
 #ifndef VSEL_GQA_KO_BAR
     __syncthreads();                                 // vmcnt(0) in front of it: every wave's direct loads have landed at the release
 #endif
     GQA_STAMP(5);
+    if (first) {
+      // the item after next: index arithmetic, two dependent cu_seqlens loads and (rarely) the empty-candidate path -- here, in the
+      // shadow of the item's remaining tiles, not between two items where every wave would wait for it
+      cand = __builtin_amdgcn_readfirstlane(s_cand[ipar]);
+      ipar ^= 1;
+      next2 = validate(cand);
+    }
     if (!last) {
       ++t;
       return true;
@@ -558,9 +575,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
     wave_qmin = next_qmin;
     wave_has_rows = next_has_rows;
     my_q = min(wave_qmin + j, cur.qlen - 1);
-    cand = __builtin_amdgcn_readfirstlane(s_cand[ipar]);   // published in front of the last barrier
-    ipar ^= 1;
-    next = validate(cand);
+    next = next2;
     if (tid == 0) pend = atomicAdd(counter, 1);
     GQA_STAMP(7);
     return true;

@@ -57,11 +57,11 @@ int attn_use_xcd_queues(int64_t max_seqlen, int64_t n_pairs, int64_t min_len, in
 bool attn_static_deal(int64_t n_items, int64_t slots, bool auto_ok, int rounds20 = 47);
 
 // ---- work-queue counter slots of the persistent attention kernels ---------------------------------------------------------------
-// Every queued launch zeroes and then drains a small device counter; each kernel family owns 64 of them ("slots").  A slot may be handed
-// out again when its previous launch ran on the SAME stream (stream order protects the counter), was never used, or has completed (a HIP
-// event recorded behind it says so); when all 64 are in flight on other streams the call fails with VSEL_ERR_BUSY instead of letting two
-// concurrent launches share a counter.  Launches recorded into a stream capture cannot be tracked (an event recorded during capture cannot
-// be queried): they take slots in rotation, and a captured graph must not be replayed concurrently with itself.
+// Every queued launch zeroes and then drains a small device counter; each kernel family owns 64 of them ("slots").  A slot belongs to a
+// STREAM: launches of one stream reuse that stream's slot (stream order protects the counter), a new stream takes a free slot, and when
+// 64 other streams hold them all a slot is taken over from a stream with nothing in flight (hipStreamQuery) -- else the call fails with
+// VSEL_ERR_BUSY instead of letting two concurrent launches share a counter.  Not covered: a captured graph bakes in the slot of its
+// capture stream, so it must not be replayed concurrently with itself or with eager launches on that stream.
 enum QueueFamily { kSlotFwd = 0, kSlotFwd64, kSlotGqa, kSlotBwd, kSlotDq64, kSlotDkdv64, kSlotFamilies };
 int queue_slot_acquire(int family, hipStream_t st, int* slot);       // VSEL_OK, VSEL_ERR_BUSY, VSEL_ERR_HIP
 void queue_slot_launched(int family, int slot, hipStream_t st);      // after the launch that uses `slot` has been enqueued on st

@@ -99,64 +99,41 @@ extern "C" void vsel_debug_reset(void) {
 
 namespace vsel {
 namespace {
-struct SlotRing {
-  hipEvent_t ev[64];
-  hipStream_t last_stream[64];
-  unsigned char state[64];      // 0 free / never used, 1 launched (event recorded), 2 reserved by a call in progress, 3 launched untracked
-  unsigned next = 0;
-  bool have_events = false;
+// slot -> owning stream.  Launches of one stream always take that stream's slot (stream order protects the counter: the memset that
+// re-arms it runs behind the previous launch), so the common cases -- one stream, or a handful -- cost a table lookup and put nothing
+// into the stream (a HIP event per launch, the first form of this, added ~6 us of marker packets to every 25 us launch).
+struct SlotTable {
+  hipStream_t owner[64];
+  bool used[64];
 };
 std::mutex g_slot_mu;
-SlotRing g_slot_rings[16][kSlotFamilies];
+SlotTable g_slot_tables[16][kSlotFamilies];
 }  // namespace
 int queue_slot_acquire(int family, hipStream_t st, int* slot) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(VSEL_ERR_HIP, "hipGetDevice");
   std::lock_guard<std::mutex> lock(g_slot_mu);
-  SlotRing& r = g_slot_rings[dev][family];
-  if (!r.have_events) {
-    for (int i = 0; i < 64; ++i) {
-      if (hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) != hipSuccess) return fail(VSEL_ERR_HIP, "hipEventCreate(queue slot)");
-      r.state[i] = 0;
-      r.last_stream[i] = nullptr;
-    }
-    r.have_events = true;
-  }
+  SlotTable& t = g_slot_tables[dev][family];
+  int free_slot = -1;
   for (int i = 0; i < 64; ++i) {
-    const int s = (int)((r.next + i) & 63u);
-    bool ok = r.state[s] == 0 || r.state[s] == 3;           // (3: a captured launch -- untracked, rotation only)
-    if (r.state[s] == 1) {
-      if (r.last_stream[s] == st) ok = true;                // stream order: the counter's previous user is done when this launch starts
-      else {
-        const hipError_t q = hipEventQuery(r.ev[s]);
-        if (q == hipSuccess) ok = true;
-        else if (q != hipErrorNotReady) { (void)hipGetLastError(); ok = true; }   // (the event's stream is gone: nothing in flight)
-      }
-    }
-    if (ok) {
-      r.state[s] = 2;
-      r.next = (unsigned)s + 1u;
-      *slot = s;
-      return VSEL_OK;
-    }
+    if (t.used[i] && t.owner[i] == st) { *slot = i; return VSEL_OK; }
+    if (!t.used[i] && free_slot < 0) free_slot = i;
   }
-  return fail(VSEL_ERR_BUSY, "64 launches of this attention kernel are in flight on other streams: every work-queue counter is taken");
-}
-void queue_slot_launched(int family, int slot, hipStream_t st) {
-  int dev = 0;
-  if (slot < 0 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
-  std::lock_guard<std::mutex> lock(g_slot_mu);
-  SlotRing& r = g_slot_rings[dev][family];
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-  if (capturing || hipEventRecord(r.ev[slot], st) != hipSuccess) {
-    (void)hipGetLastError();
-    r.state[slot] = 3;
-  } else {
-    r.state[slot] = 1;
+  if (free_slot < 0) {
+    // 64 other streams hold the slots: take over one whose stream has nothing in flight (or no longer exists)
+    for (int i = 0; i < 64 && free_slot < 0; ++i) {
+      const hipError_t q = hipStreamQuery(t.owner[i]);
+      if (q != hipErrorNotReady) { (void)hipGetLastError(); free_slot = i; }
+    }
+    if (free_slot < 0)
+      return fail(VSEL_ERR_BUSY, "64 other streams have launches of this attention kernel in flight: every work-queue counter is taken");
   }
-  r.last_stream[slot] = st;
+  t.used[free_slot] = true;
+  t.owner[free_slot] = st;
+  *slot = free_slot;
+  return VSEL_OK;
 }
+void queue_slot_launched(int, int, hipStream_t) {}      // (nothing to record: ownership is per stream)
 }  // namespace vsel
 
 namespace vsel {

@@ -704,7 +704,8 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   if (d == 128 && g_attn_use_tr && !pg.block_table && !pg.seqlens_k && !pg.cu_k && g_attn_nw == 0 && rep_ >= 2 && rep_ <= 8 &&
       max_seqlen_q <= 16384 && g_rows64 != 1 &&
       (g_gqa == 1 || (g_gqa < 0 && max_seqlen_q < 2048 && !split2 && cdiv(max_seqlen_q, 32 * (8 / rep_)) * hkv * n_seq >= 768)))
-    return attn::attn_fwd_gqa_launch(st, q, k, v, cu_q, n_seq, max_seqlen_q, hq, hkv, scale, causal, out, pg, lse);
+    return (knob(VSEL_KNOB_ATTN_GQA_PIPE) != 0 ? attn::attn_fwd_gqap_launch : attn::attn_fwd_gqa_launch)(st, q, k, v, cu_q, n_seq, max_seqlen_q, hq, hkv,
+                                                                                                         scale, causal, out, pg, lse);
   if (d == 128 && g_attn_use_tr && !pack && !pg.block_table && g_attn_nw == 0 &&
       (g_rows64 == 1 || (g_rows64 < 0 && max_seqlen_q >= 2048 && !split2)))
     return attn::attn_fwd64_launch(st, q, k, v, cu_q, n_seq, max_seqlen_q, hq, hkv, scale, causal, out, pg, lse);

@@ -176,21 +176,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
   };
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  // K / V tile t of `it` -> ring slot BUF: rows past the end of the sequence replay its last row (finite values, masked later)
-  auto load_tile = [&](const GqaItem& it, int t, auto buf_c) {
+  // K / V tile t of the (sequence, kv head) whose row 0 is at kp / vp (qlen rows) -> ring slot BUF: rows past the end of the sequence
+  // replay its last row (finite values, masked later).  kp / vp are per-ITEM values (item_bases below): recomputing the 64-bit
+  // products of the sequence base in every round cost ~50 scalar instructions per tile (PMC: 5.7 SALU per MFMA in this kernel).
+  auto item_kbase = [&](const GqaItem& it) { return reinterpret_cast<const char*>(k + (int64_t)it.qs * hkv * kHeadDim + it.kvh * kv_hs); };
+  auto item_vbase = [&](const GqaItem& it) { return reinterpret_cast<const char*>(v + (int64_t)it.qs * hkv * kHeadDim + it.kvh * v_hs); };
+  auto load_tile_at = [&](const char* kp, const char* vp, int qlen, int t, auto buf_c) {
     constexpr int BUF = decltype(buf_c)::value;
-    const char* kp = reinterpret_cast<const char*>(k + (int64_t)it.qs * hkv * kHeadDim + it.kvh * kv_hs);
-    const char* vp = reinterpret_cast<const char*>(v + (int64_t)it.qs * hkv * kHeadDim + it.kvh * v_hs);
-    if (t * kTileK + kTileK <= it.qlen) {
-      const int r = t * kTileK + 4 * wave;
-      const char* kt = kp + (int64_t)r * k_rs_b;
-      const char* vt = vp + (int64_t)r * v_rs_b;
+    if (t * kTileK + kTileK <= qlen) {
+      const uint32_t r = (uint32_t)(t * kTileK + 4 * wave);          // (row * stride < 2^32: max_seqlen <= 16384 rows of <= 64 KiB)
+      const char* kt = kp + r * k_rs_b;
+      const char* vt = vp + r * v_rs_b;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         __builtin_amdgcn_global_load_lds((gptr_t)(kt + lane_off_k), (lptr_t)(smem + BUF * kBuf + (wave + 8 * u) * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(vt + lane_off_v), (lptr_t)(smem + (2 + BUF) * kBuf + (wave + 8 * u) * 1024), 16, 0, 0);
-        kt += (int64_t)32 * k_rs_b;
-        vt += (int64_t)32 * v_rs_b;
+        kt += 32 * k_rs_b;
+        vt += 32 * v_rs_b;
       }
       return;
     }
@@ -199,11 +201,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int i = wave + 8 * u;
-      const uint32_t row = (uint32_t)min(t * kTileK + 4 * i + (l >> 4), it.qlen - 1);
+      const uint32_t row = (uint32_t)min(t * kTileK + 4 * i + (l >> 4), qlen - 1);
       __builtin_amdgcn_global_load_lds((gptr_t)(kp + (row * k_rs_b + kv_part_b)), (lptr_t)(smem + BUF * kBuf + i * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(vp + (row * v_rs_b + kv_part_b)), (lptr_t)(smem + (2 + BUF) * kBuf + i * 1024), 16, 0, 0);
     }
   };
+  auto load_tile = [&](const GqaItem& it, int t, auto buf_c) { load_tile_at(item_kbase(it), item_vbase(it), it.qlen, t, buf_c); };
   // the whole tile by ONE wave (7 q heads per group: wave 7 has no head and nothing else to do -- the head waves then never stall on
   // the vector-memory pipe, whose address stage a 32 KiB tile pair occupies for ~500 cycles per round)
   auto load_tile_all = [&](const GqaItem& it, int t, auto buf_c) {
@@ -272,6 +275,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
   u32x4 qf[kSteps];
   f32x16 o[kDTiles];
   float m_run = -1e30f, l_run = 0.f;
+  const char* cur_kp = item_kbase(cur);             // row 0 of the current item's (sequence, kv head) in K / V
+  const char* cur_vp = item_vbase(cur);
   int wave_qmin = cur.q0 + qw * 32;
   bool wave_has_rows = head_wave && wave_qmin < cur.qlen;
   int my_q = min(wave_qmin + j, cur.qlen - 1);
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
         return;
       }
       if (!last) {
-        load_tile(cur, t + 1, NXT{});
+        load_tile_at(cur_kp, cur_vp, cur.qlen, t + 1, NXT{});
       } else if (next.n_tiles > 0) {                 // the next item's rows and first tile fly under this item's last tile
         load_q(next);
         load_tile(next, 0, NXT{});
@@ -571,6 +576,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
     m_run = -1e30f;
     l_run = 0.f;
     cur = next;
+    cur_kp = item_kbase(cur);
+    cur_vp = item_vbase(cur);
     t = 0;
     wave_qmin = next_qmin;
     wave_has_rows = next_has_rows;

@@ -66,9 +66,9 @@ typedef enum vsel_debug_knob {
                                      kv head's whole q-head group on a 32-query tile (K / V tiles loaded once per group, 32-key causal granularity,
                                      the next item's rows in flight under the last tile; csrc/attn_fwd_gqa.hip): -1 for throughput-bound grids of
                                      sequences below 2048 tokens (default), 0 never, 1 whenever it applies; env VSEL_ATTN_GQA; bit-identical outputs */
-  VSEL_KNOB_ATTN_GQA_PIPE = 20,   /* the group-shared forward in its software-pipelined form (csrc/attn_fwd_gqap.hip: S of tile t + 1 beside the
-                                     exponentials of tile t, K two tiles ahead): 1 (default) / 0 the sequential form; env VSEL_ATTN_GQA_PIPE;
-                                     bit-identical outputs */
+  VSEL_KNOB_ATTN_GQA_FORM = 20,   /* which group-shared forward: -1 by item count and group size (default), 0 the 8-wave form (one head per wave,
+                                     items pipelined into each other; csrc/attn_fwd_gqa.hip), 1 the generated 64-rows-per-wave loop with two heads
+                                     per wave (csrc/attn_fwd_gqa64.hip); env VSEL_ATTN_GQA_FORM; bit-identical outputs */
   VSEL_KNOB_COUNT = 21
 } vsel_debug_knob;
 

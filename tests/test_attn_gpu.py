@@ -479,18 +479,19 @@ def _gqa_pair(ops, q, k, v, cu, L, causal, lse=False):
     """(per-head 4- / 8-wave form, group-shared form) on the same inputs; the profile proves which kernel ran"""
     from visionselector_amd import _native as N
     outs = []
-    for g, pipe, name in ((0, 0, None), (1, 1, "attn_fwd_gqap_kernel"), (1, 0, "attn_fwd_gqa_kernel")):
-        with N.debug_knob(attn_gqa=g, attn_gqa_pipe=pipe, attn_split=0, attn_rows64=0):
+    for g, form, name in ((0, 0, None), (1, 1, "attn_fwd_gqa64_kernel"), (1, 0, "attn_fwd_gqa_kernel")):
+        with N.debug_knob(attn_gqa=g, attn_gqa_form=form, attn_split=0, attn_rows64=0):
             N.profile_start()
             outs.append(ops.varlen_attn_fwd_lse(q, k, v, cu, L, causal=causal) if lse else ops.varlen_attn(q, k, v, cu, L, causal=causal))
             prof = N.profile_stop()
             assert [n for n in prof if "gqa" in n] == ([name] if name else []), prof
-    # the sequential and the software-pipelined group-shared forms agree bit for bit; the caller compares outs[0] (per head) with outs[1]
-    a, b = outs[1], outs[2]
-    if lse:
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    else:
-        assert torch.equal(a, b)
+    # the two group-shared forms agree bit for bit; the caller compares outs[0] (per head) with outs[1]
+    for b in outs[2:]:
+        a = outs[1]
+        if lse:
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        else:
+            assert torch.equal(a, b)
     return outs[:2]
 
 
@@ -545,7 +546,7 @@ def test_gqa_shared_forward_many_ragged_prompts_is_deterministic_and_default(ops
     N.profile_start()
     a = ops.varlen_attn(q, k, v, cu, max(lens))
     prof = N.profile_stop()
-    assert "attn_fwd_gqap_kernel" in prof, prof
+    assert "attn_fwd_gqa_kernel" in prof, prof
     b = ops.varlen_attn(q, k, v, cu, max(lens))
     assert torch.equal(a, b)
     with N.debug_knob(attn_gqa=0):
@@ -567,7 +568,7 @@ def test_gqa_shared_forward_on_head_major_strided_tensors(ops, b, hq, hkv, l, ca
             N.profile_start()
             outs.append(ops.attn_head_major(q, k, v, causal=causal))
             prof = N.profile_stop()
-            assert ("attn_fwd_gqap_kernel" in prof) == bool(g), prof
+            assert any("gqa" in n for n in prof) == bool(g), prof
     assert torch.equal(outs[0], outs[1])
 
 

@@ -43,15 +43,15 @@ def main():
         fl = sum(4.0 * l * l * hq * 128 / 2 for l in lens)
         res = {}
         outs = {}
-        for name, knobs in (("default", {}), ("per_head", dict(attn_gqa=0)), ("gqa", dict(attn_gqa=1, attn_gqa_pipe=0)), ("gqap", dict(attn_gqa=1, attn_gqa_pipe=1))):
+        for name, knobs in (("default", {}), ("per_head", dict(attn_gqa=0)), ("gqa", dict(attn_gqa=1, attn_gqa_form=0)), ("gqa64", dict(attn_gqa=1, attn_gqa_form=1))):
             with N.debug_knob(**knobs):
                 outs[name] = ops.varlen_attn(q, k, v, cu, L)
                 res[name] = timed(lambda: ops.varlen_attn(q, k, v, cu, L))
-        eqp = torch.equal(outs["per_head"], outs["gqap"])
+        eq64 = torch.equal(outs["per_head"], outs["gqa64"])
         eq = torch.equal(outs["per_head"], outs["gqa"])
         md = (outs["per_head"].float() - outs["gqa"].float()).abs().max().item()
         print(f"{tag:12s} default {res['default']:8.1f} us  per_head {res['per_head']:8.1f} us {fl / res['per_head'] / 1e6:7.0f} TF   "
-              f"gqa {res['gqa']:8.1f} us {fl / res['gqa'] / 1e6:7.0f} TF   x{res['per_head'] / res['gqa']:.2f}  equal={eq} | gqap {res['gqap']:8.1f} us {fl / res['gqap'] / 1e6:7.0f} TF x{res['per_head'] / res['gqap']:.2f} equal={eqp}", flush=True)
+              f"gqa {res['gqa']:8.1f} us {fl / res['gqa'] / 1e6:7.0f} TF   x{res['per_head'] / res['gqa']:.2f}  equal={eq} | gqa64 {res['gqa64']:8.1f} us {fl / res['gqa64'] / 1e6:7.0f} TF x{res['per_head'] / res['gqa64']:.2f} equal={eq64}", flush=True)
 
 
 if __name__ == "__main__":

@@ -54,6 +54,7 @@ S_TMP = 60                                        # 60..63
 S_EXEC = 64
 S_RING, S_QST, S_QRS2 = 66, 67, 68                # LDS base; this wave's Q staging area; Q row stride in bytes
 S_QPTR = 80                                       # 80..81 running Q row pointer
+S_QPTRB = 82                                      # 82..83 heads mode: block B's first Q row
 S_MV = 70                                         # 70..73: "moves" masks of blocks A / B
 S_M0SAVE, S_LENM1 = 74, 75
 S_TMP2 = 76                                       # 76..77
@@ -434,6 +435,9 @@ OPT = {
     "wgrp": 1,            # one s_waitcnt per group of four K fragments / per V key group instead of one per fragment
     "trace": 0,           # s_memtime stamps summed per wave and added to a global table at the end of every item (timing builds only)
     "ko": "",             # knock-outs for timing experiments (WRONG results): any of fin,max,dma,bar,lds,mfma joined by "+"
+    "heads": 0,           # 1: the wave's two 32-row blocks are the SAME 32 queries of TWO q heads of a GQA group (attn_fwd_gqa64.hip): block B's
+                          # Q rows / output rows sit %[qhs2] / %[ohs2] bytes behind block A's instead of 32 rows below, both blocks have
+                          # %[nvalid] / %[nvalidb] rows (nvalidb = 0: no second head, nothing stored for it)
 }
 for kv in os.environ.get("F64_OPTS", "").replace(";", ",").split(","):
     if "=" in kv:
@@ -809,9 +813,15 @@ def gen_body():
         e(f"v_lshl_add_u32 {v(V_QLO + kq)}, {v(V_QLO + kq)}, 4, {v(V_T)}")
     e(f"s_mov_b64 {sr(S_QPTR)}, %[qbase]")
     e(f"s_lshl_b32 {s(S_TMP + 1)}, {s(S_QRS2)}, 2")
-    e(f"s_cmp_gt_i32 %[nvalid], 63")
+    heads = OPT["heads"]
+    if heads:
+        e(f"s_add_u32 {s(S_QPTRB)}, {s(S_QPTR)}, %[qhs2]")
+        e(f"s_addc_u32 {s(S_QPTRB + 1)}, {s(S_QPTR + 1)}, 0")
+    e(f"s_cmp_gt_i32 %[nvalid], {31 if heads else 63}")
     e(f"s_cbranch_scc0 {g.lref('Lqpart')}")
     for i in range(16):
+        if heads and i == 8:                                   # block B: the same rows of the second head
+            e(f"s_mov_b64 {sr(S_QPTR)}, {sr(S_QPTRB)}")
         e(f"s_add_u32 m0, {s(S_QST)}, {1024 * i}")
         e("s_nop 0")
         e(f"global_load_lds_dwordx4 {v(V_QLO + (i & 3))}, {sr(S_QPTR)}")
@@ -823,14 +833,14 @@ def gen_body():
     e(f"s_cbranch_scc0 {g.lref('Lqdone')}")
     e(f"s_add_i32 {s(S_TMP2)}, %[nvalid], -1")
     for i in range(16):
-        e(f"v_add_u32 {v(V_U)}, {4 * i}, {v(V_LANE4)}")
+        e(f"v_add_u32 {v(V_U)}, {4 * (i & 7 if heads else i)}, {v(V_LANE4)}")
         e(f"v_min_i32 {v(V_U)}, {v(V_U)}, {s(S_TMP2)}")
         e(f"v_mul_lo_u32 {v(V_U)}, {v(V_U)}, {s(S_QRS2)}")
         e(f"v_sub_u32 {v(V_U + 1)}, {v(V_QLO + (i & 3))}, {v(V_T)}")          # the chunk term of this slice phase
         e(f"v_add_u32 {v(V_U)}, {v(V_U)}, {v(V_U + 1)}")
         e(f"s_add_u32 m0, {s(S_QST)}, {1024 * i}")
         e("s_nop 0")
-        e(f"global_load_lds_dwordx4 {v(V_U)}, {sr(S_QPTR)}")
+        e(f"global_load_lds_dwordx4 {v(V_U)}, {sr(S_QPTRB if heads and i >= 8 else S_QPTR)}")
     g.label("Lqdone")
     dma_tile(g, "k", 0, S_T, "pk0")
     dma_tile(g, "v", 0, S_T, "pv0")
@@ -984,6 +994,11 @@ def gen_body():
     for i in range(16):
         if i >= 4:
             e(f"s_waitcnt lgkmcnt({15 - i})")
+        if OPT["heads"] and i == 8:                                 # block B: the second head's rows (none when there is no second head)
+            e(f"s_mov_b64 {sr(S_TMP)}, %[obase]")
+            e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, %[ohs2]")
+            e(f"s_addc_u32 {s(S_TMP + 1)}, {s(S_TMP + 1)}, 0")
+            e(f"s_mov_b32 {s(S_TMP2 + 1)}, %[nvalidb]")
         e(f"v_cmp_gt_i32 vcc, {s(S_TMP2 + 1)}, {v(V_LANE4)}")        # row 4 i + (lane >> 4) of this wave exists
         e("s_mov_b64 exec, vcc")
         e(f"global_store_dwordx4 {v(VO[i % 4])}, {vr(V_SA + 4 * i, 4)}, {sr(S_TMP)}")
@@ -1017,12 +1032,13 @@ def main():
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_attn_fwd64.py -- do not edit; the per-item body of attn_fwd64_kernel as one inline-asm statement.\n")
         f.write(f"// {len(g.lines)} lines; options {OPT}\n")
-        f.write(f"#define VSEL_FWD64_LDS_BYTES {2 * 65536}\n")
-        f.write("#define VSEL_FWD64_ASM_TEXT \\\n")
+        pre = os.environ.get("F64_PREFIX", "VSEL_FWD64")
+        f.write(f"#define {pre}_LDS_BYTES {2 * 65536}\n")
+        f.write(f"#define {pre}_ASM_TEXT \\\n")
         for ln in g.lines:
             f.write(f'  "{ln}\\n\\t" \\\n')
         f.write('  ""\n')
-        f.write("#define VSEL_FWD64_ASM_CLOBBERS \\\n  ")
+        f.write(f"#define {pre}_ASM_CLOBBERS \\\n  ")
         cl = clobbers()
         f.write(", ".join(f'"{c}"' for c in cl))
         f.write("\n")

@@ -36,10 +36,10 @@ def _stale() -> bool:
 # epilogue converts with v_cvt_pk_bf16_f32 instead of the software rounding whose constants pushed it to 256 + 25 registers.
 ASM_READ_KERNELS = (("attn.hip", "varlen_attn_fwd_kernelILb1E"), ("attn_bwd.hip", "attn_bwd_dkdv2_kernelILb0E"),
                     ("attn_bwd.hip", "attn_bwd_dkdv2_kernelILb1E"), ("attn_bwd.hip", "attn_bwd_dq_kernel"),
-                    ("attn_fwd_gqa.hip", "attn_fwd_gqa_kernel"), ("attn_fwd_gqap.hip", "attn_fwd_gqap_kernel"),
+                    ("attn_fwd_gqa.hip", "attn_fwd_gqa_kernel"),
                     # the generated one-statement bodies clobber v32-255 / a0-255 / s40-99: everything the C++ around them keeps live must
                     # fit in what is left, without scratch
-                    ("attn_fwd64.hip", "attn_fwd64_kernel"), ("attn_bwd_dq64.hip", "attn_bwd_dq64_kernel"),
+                    ("attn_fwd64.hip", "attn_fwd64_kernel"), ("attn_fwd_gqa64.hip", "attn_fwd_gqa64_kernel"), ("attn_bwd_dq64.hip", "attn_bwd_dq64_kernel"),
                     ("attn_bwd_dkdv64.hip", "attn_bwd_dkdv64_kernel"))
 
 

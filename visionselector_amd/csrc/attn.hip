@@ -666,7 +666,7 @@ extern "C" int vsel_debug_read_attn_trace(unsigned long long* out, int clear) {
 
 static int attn_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
                        int64_t max_seqlen_q, int64_t hq, int64_t hkv, int64_t d, float scale, int causal, void* out,
-                       const PagedKV& pg, float* lse = nullptr) {
+                       const PagedKV& pg, float* lse = nullptr, int64_t total = 0) {
   const bool g_attn_use_tr = knob(VSEL_KNOB_ATTN_USE_TR) != 0, g_attn_split_q64 = knob(VSEL_KNOB_ATTN_SPLIT_Q64) != 0;
   const int g_attn_nw = knob(VSEL_KNOB_ATTN_WAVES), g_attn_pack = knob(VSEL_KNOB_ATTN_PACK), g_attn_split = knob(VSEL_KNOB_ATTN_SPLIT);
   // 8-wave workgroups (256 queries) when there is enough work to fill the chip with them, else 4-wave (128 queries)
@@ -693,19 +693,32 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   // sequence, whatever the batch (same-process A/B, tools/exp_fwd64_shapes.py, profiles/r04_fwd64_shapes.txt: 1 x 2368 59.8 vs 68.0 us,
   // 1 x 4096 112 vs 125, 8 x 2048 +15 %, 16 x 4096 +11 %, 2 x 8192 +16 %; 16 x 1100 -2 %, 32 x 524 -20 %: those keep the 4-wave form)
   const int g_rows64 = knob(VSEL_KNOB_ATTN_ROWS64);
-  // short sequences in throughput-bound grids (packed batches of compressed prompts): one workgroup per (query tile, kv head) serving
-  // the whole q-head group (attn_fwd_gqa.hip).  Prefill over the queries' own contiguous keys only.  From three rounds of its items
-  // (same-process A/B, tools/exp_attn_gqa.py, profiles/r05_gqa_ab.txt, 28 / 4 heads: 16 x 524 78 -> 61 us, 32 x 524 145 -> 113, 32 x 294 71 -> 54,
-  // 64 ragged prompts 326 -> 275, 16 x 1100 216 -> 193, 32 x 1216 485 -> 452; LLaVA-OV 32 / 8 heads 32 x 1230 597 -> 518; 3B 16 / 2 heads
-  // 32 x 524 86 -> 63; below that the per-head forms win: 8 x 524 42.1 vs 41.8, 4 x 524 24.3 vs 28.9 -- one item per workgroup and nothing
-  // to pipeline across)
+  // Short sequences (packed batches of compressed prompts): ONE workgroup per (query tile, kv head) serves the whole q-head group, so a
+  // K / V tile is loaded once per group.  Prefill over the queries' own contiguous keys only.  Two forms, bit-identical:
+  //   * attn_fwd_gqa.hip: 8 waves = the group's heads on a 32-query tile, items pipelined into each other (next item's rows in flight under
+  //     the last tile, queue drawn ahead) -- best when a workgroup runs many items (>= 3 rounds of them);
+  //   * attn_fwd_gqa64.hip: attn_fwd64's generated loop with two heads per wave (~8 instead of ~18 instructions per MFMA, but every item
+  //     pays its own prologue) -- best for few items per workgroup and for groups of <= 4 heads (64-query items).
+  // Same-process A/B (tools/exp_attn_gqa.py, profiles/r05_gqa_ab.txt; us per-head / 8-wave / generated, 28 / 4 heads): 2 x 524 19.8 / 25.4 /
+  // 19.4, 4 x 524 24.2 / 29.3 / 21.1, 8 x 524 42.5 / 42.8 / 41.3, 8 ragged 51.6 / 57.0 / 48.5, 16 x 524 77.5 / 62.0 / 78.5, 32 x 524 144 / 115 /
+  // 137, 32 x 294 70 / 54 / 63, 64 ragged 325 / 275 / 284, 16 x 1100 216 / 193 / 212, 32 x 1216 485 / 452 / 453; LLaVA-OV 32 / 8 heads
+  // 32 x 1230 597 / 518 / 484, 8 x 1230 148 / 130 / 130; 3B 16 / 2 heads 32 x 524 86 / 63 / 78.  One sequence (68 items) stays with the
+  // two-stream per-head form (13.5 vs 18.8 us).
   const int g_gqa = knob(VSEL_KNOB_ATTN_GQA);
   const int64_t rep_ = hq / hkv;
   if (d == 128 && g_attn_use_tr && !pg.block_table && !pg.seqlens_k && !pg.cu_k && g_attn_nw == 0 && rep_ >= 2 && rep_ <= 8 &&
-      max_seqlen_q <= 16384 && g_rows64 != 1 &&
-      (g_gqa == 1 || (g_gqa < 0 && max_seqlen_q < 2048 && !split2 && cdiv(max_seqlen_q, 32 * (8 / rep_)) * hkv * n_seq >= 768)))
-    return (knob(VSEL_KNOB_ATTN_GQA_PIPE) != 0 ? attn::attn_fwd_gqap_launch : attn::attn_fwd_gqa_launch)(st, q, k, v, cu_q, n_seq, max_seqlen_q, hq, hkv,
-                                                                                                         scale, causal, out, pg, lse);
+      max_seqlen_q <= 16384 && g_rows64 != 1) {
+    // items of the 8-wave form that hold work (ragged batches: from the token count when the entry point knows it -- the item LIST is
+    // sized by the longest sequence, but a shorter sequence's items at the levels it does not reach are skipped in runs)
+    const int64_t bq8 = 32 * (8 / rep_);
+    const int64_t items8 = (total > 0 ? std::min(cdiv(total, bq8) + n_seq, cdiv(max_seqlen_q, bq8) * n_seq) : cdiv(max_seqlen_q, bq8) * n_seq) * hkv;
+    if (g_gqa == 1 || (g_gqa < 0 && max_seqlen_q < 2048 && !split2 && items8 >= 128)) {
+      const int form = knob(VSEL_KNOB_ATTN_GQA_FORM);
+      const bool gen = form >= 0 ? form == 1 : (rep_ <= 4 || items8 < 768);
+      return (gen ? attn::attn_fwd_gqa64_launch : attn::attn_fwd_gqa_launch)(st, q, k, v, cu_q, n_seq, max_seqlen_q, hq, hkv, scale, causal, out,
+                                                                              pg, lse);
+    }
+  }
   if (d == 128 && g_attn_use_tr && !pack && !pg.block_table && g_attn_nw == 0 &&
       (g_rows64 == 1 || (g_rows64 < 0 && max_seqlen_q >= 2048 && !split2)))
     return attn::attn_fwd64_launch(st, q, k, v, cu_q, n_seq, max_seqlen_q, hq, hkv, scale, causal, out, pg, lse);
@@ -799,7 +812,8 @@ extern "C" int vsel_varlen_attn_fwd(void* stream, const void* q, const void* k, 
   if (total < 1) return fail(VSEL_ERR_INVALID, "total must be >= 1");
   hipStream_t st = (hipStream_t)stream;
   VSEL_PROF_BEGIN(st);
-  return attn_launch(st, q, k, v, cu_seqlens, n_seq, max_seqlen, hq, hkv, d, scale, causal, out, PagedKV{nullptr, nullptr, nullptr, 0, 1, 0, 0, 0, 0, 0, 0});
+  return attn_launch(st, q, k, v, cu_seqlens, n_seq, max_seqlen, hq, hkv, d, scale, causal, out, PagedKV{nullptr, nullptr, nullptr, 0, 1, 0, 0, 0, 0, 0, 0},
+                     nullptr, total);
 }
 
 extern "C" int vsel_varlen_attn_fwd_lse(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens,
@@ -811,7 +825,7 @@ extern "C" int vsel_varlen_attn_fwd_lse(void* stream, const void* q, const void*
   hipStream_t st = (hipStream_t)stream;
   VSEL_PROF_BEGIN(st);
   return attn_launch(st, q, k, v, cu_seqlens, n_seq, max_seqlen, hq, hkv, d, scale, causal, out,
-                     PagedKV{nullptr, nullptr, nullptr, 0, 1, 0, 0, 0, 0, 0, 0}, lse);
+                     PagedKV{nullptr, nullptr, nullptr, 0, 1, 0, 0, 0, 0, 0, 0}, lse, total);
 }
 
 extern "C" int vsel_varlen_attn_fwd_kv(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens_q,

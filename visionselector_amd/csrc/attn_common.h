@@ -97,9 +97,9 @@ int attn_fwd64_launch(hipStream_t st, const void* q, const void* k, const void* 
 int attn_fwd_gqa_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
                         int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg, float* lse);
 
-// ... its software-pipelined form (attn_fwd_gqap.hip)
-int attn_fwd_gqap_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
-                         int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg, float* lse);
+// ... and on the generated 64-rows-per-wave loop, two heads per wave (attn_fwd_gqa64.hip)
+int attn_fwd_gqa64_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
+                          int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg, float* lse);
 
 // ---- XCD-local work queues (round 4) ------------------------------------------------------------------------------------------
 // Every attention kernel streams one operand pair (K / V in the forward and the dQ pass, Q / dO in the dK / dV pass) that ALL the

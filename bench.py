@@ -773,7 +773,7 @@ def bench_llm_prefill(_native, k, text=64, iters=5):
         model(inputs_embeds=x, position_ids=pos, use_cache=False)
         torch.cuda.synchronize()
         prof = _native.profile_stop()      # (from 2048 tokens the forward is attn_fwd64_kernel, csrc/attn_fwd64.hip)
-        calls = sum(prof.get(nm, (0.0, 0))[1] for nm in ("varlen_attn_fwd_kernel", "attn_fwd64_kernel", "attn_fwd_gqa_kernel"))
+        calls = sum(prof.get(nm, (0.0, 0))[1] for nm in ("varlen_attn_fwd_kernel", "attn_fwd64_kernel", "attn_fwd_gqa_kernel", "attn_fwd_gqa64_kernel"))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):

@@ -10,6 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GEN = os.path.join(ROOT, "tools", "gen_attn_fwd64.py")
 INC = os.path.join(ROOT, "visionselector_amd", "csrc", "attn_fwd64_body.inc")
+HEADS_OPTS = "heads=1,xitem=1"          # options of the committed csrc/attn_fwd_gqa64_body.inc
 
 
 def _gen(tmp_path, opts=""):
@@ -41,3 +42,12 @@ def test_body_register_budget():
         used.update(f"{kind}{i}" for i in range(int(lo), int(hi) + 1))
     used.update(re.findall(r"(?<![\w%\[])([vas]\d+)\b", body))
     assert used <= declared, sorted(used - declared)[:10]
+
+
+def test_committed_heads_body_is_the_generators_output(tmp_path):
+    """attn_fwd_gqa64_body.inc = the same generator with heads = 1 (two q heads of a GQA group per wave) under its own macro prefix"""
+    out = tmp_path / "body.inc"
+    env = dict(os.environ, F64_OUT=str(out), F64_OPTS=HEADS_OPTS, F64_PREFIX="VSEL_GQA64")
+    subprocess.check_call([sys.executable, GEN], env=env, stdout=subprocess.DEVNULL)
+    inc = os.path.join(ROOT, "visionselector_amd", "csrc", "attn_fwd_gqa64_body.inc")
+    assert out.read_text() == open(inc).read(), f"run F64_OPTS={HEADS_OPTS} F64_PREFIX=VSEL_GQA64 F64_OUT=... python tools/gen_attn_fwd64.py"

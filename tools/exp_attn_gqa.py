@@ -31,6 +31,7 @@ def main():
               ("16x524", [524] * 16, 28, 4), ("32x524", [524] * 32, 28, 4), ("64x524", [524] * 64, 28, 4), ("32x294", [294] * 32, 28, 4),
               ("32x1216", [1216] * 32, 28, 4), ("16x1100", [1100] * 16, 28, 4), ("8x2000", [2000] * 8, 28, 4), ("4x2368", [2368] * 4, 28, 4),
               ("ragged8", ragged8, 28, 4), ("ragged64", ragged64, 28, 4),
+              ("16x4096", [4096] * 16, 28, 4), ("4x8192", [8192] * 4, 28, 4), ("16x2368", [2368] * 16, 28, 4),
               ("ov 32x1230", [1230] * 32, 32, 8), ("ov 8x1230", [1230] * 8, 32, 8), ("3b 32x524", [524] * 32, 16, 2)]
     for tag, lens, hq, hkv in shapes:
         total = sum(lens)

@@ -438,6 +438,12 @@ OPT = {
     "heads": 0,           # 1: the wave's two 32-row blocks are the SAME 32 queries of TWO q heads of a GQA group (attn_fwd_gqa64.hip): block B's
                           # Q rows / output rows sit %[qhs2] / %[ohs2] bytes behind block A's instead of 32 rows below, both blocks have
                           # %[nvalid] / %[nvalidb] rows (nvalidb = 0: no second head, nothing stored for it)
+    "xitem": 0,           # 1 (with heads): items are pipelined into each other.  %[flags] bit 0: this item's Q fragments are already in
+                          # a[128:191] and its K(0) / K(1) in the ring (prefetched by the previous body), bit 1: its V(0) too; bit 3 / 4:
+                          # the same for the NEXT item -- its Q rows (%[nxq]), K(0) (%[nxk0]), K(1) (%[nxk1]; = K(0) when it has one tile)
+                          # and V(0) (%[nxv]) are loaded in the gaps of this item's last tile (whole tiles and 32 whole rows only: the
+                          # caller clears the bits otherwise), its Q fragments read before the epilogue; bit 2: block B has a head
+                          # (replaces %[nvalidb]).  The output tile leaves through the wave's own Q staging area (no barrier).
 }
 for kv in os.environ.get("F64_OPTS", "").replace(";", ",").split(","):
     if "=" in kv:
@@ -600,6 +606,70 @@ def full_step(g, par, tag, steady, ks, kdma, ks_next):
             k_read(g, f, ks_next)
 
 
+def q_frag_reads(g):
+    """Q^T fragments out of the wave's staging area into a[128:191]: lane (j, hh) takes chunk 2 st + hh of rows j and 32 + j"""
+    e = g.e
+    QR = [V_T + i for i in range(8)]
+    e(f"v_and_b32 {v(V_U)}, 31, {v(V_LANE)}")                          # j
+    e(f"v_and_b32 {v(V_U + 1)}, 3, {v(V_U)}")
+    e(f"v_lshlrev_b32 {v(V_U + 1)}, 2, {v(V_U + 1)}")
+    e(f"v_bfe_u32 {v(V_U + 2)}, {v(V_U)}, 2, 2")
+    e(f"v_or_b32 {v(V_U + 1)}, {v(V_U + 1)}, {v(V_U + 2)}")            # swz(j)
+    e(f"v_lshrrev_b32 {v(V_U + 2)}, 5, {v(V_LANE)}")
+    e(f"v_xor_b32 {v(V_U + 1)}, {v(V_U + 1)}, {v(V_U + 2)}")           # hh ^ swz(j)
+    e(f"v_lshlrev_b32 {v(V_U)}, 8, {v(V_U)}")
+    e(f"v_lshl_or_b32 {v(V_U)}, {v(V_U + 1)}, 4, {v(V_U)}")
+    e(f"v_add_u32 {v(QR[0])}, {s(S_QST)}, {v(V_U)}")                    # (the staging base is a multiple of 256: the XOR below commutes)
+    for st in range(1, 8):
+        e(f"v_xor_b32 {v(QR[st])}, {st << 5}, {v(QR[0])}")
+    n = 0
+    for b in range(2):
+        for st in range(8):
+            g.lds(f"ds_read_b128 {ar(A_Q + 32 * b + 4 * st, 4)}, {v(QR[st])} offset:{8192 * b}", ("q", n))
+            n += 1
+        g.need(("q", 8 * b + 1))
+
+
+# xitem: registers of the next item's loads.  In an item's last step nothing of the CURRENT item is loaded any more, so its running
+# pointers are free: S_QPTR / S_QPTRB (Q), S_KPTR (K(0) then K(1)), S_VPTR (V(0)); S_KB0 holds the V(0) exec mask.
+def prefetch_setup(g):
+    e = g.e
+    e(f"s_mov_b64 {sr(S_QPTR)}, %[nxq]")
+    e(f"s_add_u32 {s(S_QPTRB)}, {s(S_QPTR)}, %[qhs2]")
+    e(f"s_addc_u32 {s(S_QPTRB + 1)}, {s(S_QPTR + 1)}, 0")
+    e(f"s_lshl_b32 {s(S_TMP + 1)}, {s(S_QRS2)}, 2")                      # four Q rows
+    e(f"s_mul_i32 {s(S_TMP2)}, {s(S_W4)}, {s(S_KRS2)}")                  # this wave's first slice starts at row 4 * wave
+    e(f"s_mov_b64 {sr(S_KPTR)}, %[nxk0]")
+    e(f"s_add_u32 {s(S_KPTR)}, {s(S_KPTR)}, {s(S_TMP2)}")
+    e(f"s_addc_u32 {s(S_KPTR + 1)}, {s(S_KPTR + 1)}, 0")
+    e(f"s_mov_b64 {sr(S_KB0)}, %[nxk1]")
+    e(f"s_add_u32 {s(S_KB0)}, {s(S_KB0)}, {s(S_TMP2)}")
+    e(f"s_addc_u32 {s(S_KB0 + 1)}, {s(S_KB0 + 1)}, 0")
+    e(f"s_mul_i32 {s(S_TMP2)}, {s(S_W4)}, {s(S_VRS2)}")
+    e(f"s_mov_b64 {sr(S_VPTR)}, %[nxv]")
+    e(f"s_add_u32 {s(S_VPTR)}, {s(S_VPTR)}, {s(S_TMP2)}")
+    e(f"s_addc_u32 {s(S_VPTR + 1)}, {s(S_VPTR + 1)}, 0")
+    e(f"s_bitcmp1_b32 %[flags], 4")                                       # V(0) too?  exec mask of its four loads
+    e(f"s_cselect_b64 {sr(S_VB0)}, {sr(S_EXEC)}, 0")
+
+
+def prefetch_pieces():
+    """[(instructions in front of the load, load, instructions behind it)]: 16 Q slices, K(0), K(1) (K slots 0 / 1), V(0) (V slot 0)"""
+    out = []
+    for i in range(16):
+        pre = [f"s_add_u32 m0, {s(S_QST)}, {1024 * i}"]
+        src = S_QPTR if i < 8 else S_QPTRB
+        post = [f"s_add_u32 {s(src)}, {s(src)}, {s(S_TMP + 1)}", f"s_addc_u32 {s(src + 1)}, {s(src + 1)}, 0"]
+        out.append((pre, f"global_load_lds_dwordx4 {v(V_QLO + (i & 3))}, {sr(src)}", post))
+    for slot, ptr in ((0, S_KPTR), (1, S_KB0)):
+        for u in range(4):
+            out.append(([f"s_add_u32 m0, {s(S_LDSW)}, {slot * KBUF + u * 4096}"], f"global_load_lds_dwordx4 {v(V_LOK + u)}, {sr(ptr)}", []))
+    for u in range(4):
+        out.append(([f"s_add_u32 m0, {s(S_LDSW)}, {v_base() + u * 4096}", f"s_mov_b64 exec, {sr(S_VB0)}"],
+                    f"global_load_lds_dwordx4 {v(V_LOV + u)}, {sr(S_VPTR)}", [f"s_mov_b64 exec, {sr(S_EXEC)}"]))
+    return out
+
+
 def gen_step(g, idx, period):
     """step t with t % period == idx"""
     par = idx & 1
@@ -651,30 +721,60 @@ def gen_step(g, idx, period):
     g.e(f"s_branch {g.lref('Lend' + P)}")
 
     # ---------------- the wave's last tile: nothing to overlap with ----------------
-    g.out = list(seed)                                       # (K fragments read ahead for a step that does not come: never used)
+    def last_tile(tagx, pieces):
+        g.out = list(seed)                                   # (K fragments read ahead for a step that does not come: never used)
+        for ins in finish_a(sc)[OPT["early"]:] + finish_chunk(sc, 1, 0, True) + finish_chunk(sc, 1, 1, False) + \
+                [f"v_add_f32 {v(V_L + 1)}, {v(V_L + 1)}, {v(V_PS + 1)}"]:
+            g.e(ins)
+        gl = [[] for _ in range(33)]
+        for text, tag in [r for dt in range(4) for r in v_reads(g, 0, dt, vs)]:
+            if len(g.out) >= 14:
+                g.need(g.out[0])
+            g.lds(text, tag)
+        place(gl, [r for dt in range(4) for r in v_reads(g, 1, dt, vs)], [0, 0, 1, 1, 2, 2, 3, 3])
+        for grp in (2, 3):
+            for dt in range(4):
+                where = 8 * (grp - 2) + 2 * dt + 2 + (2 if grp == 2 else 0)
+                if OPT["pvsplit"]:
+                    where = 4 * (grp - 1) + dt                   # key group g feeds MFMA 4 g of the block-A pass
+                for r in v_reads(g, grp, dt, vs):
+                    gl[where].append(r)
+        # the next item's loads: one per gap behind the V reads of the gap (an m0 write needs one wait state in front of its load)
+        for n_, (pre, ld, post) in enumerate(pieces):
+            w = 2 + n_ if n_ < 28 else 31
+            gl[w] = gl[w] + pre + ["s_nop 0", ld] + post
+        emit_phase(g, 32, lambda i: pv_mfma(g, i), gl[:32])
+        assert not g.out and not gl[32]
+        stamp(g, 4)
+
     g.label("Llast" + P)
-    for ins in finish_a(sc)[OPT["early"]:] + finish_chunk(sc, 1, 0, True) + finish_chunk(sc, 1, 1, False) + \
-            [f"v_add_f32 {v(V_L + 1)}, {v(V_L + 1)}, {v(V_PS + 1)}"]:
-        g.e(ins)
-    gl = [[] for _ in range(32)]
-    for text, tag in [r for dt in range(4) for r in v_reads(g, 0, dt, vs)]:
-        if len(g.out) >= 14:
-            g.need(g.out[0])
-        g.lds(text, tag)
-    place(gl, [r for dt in range(4) for r in v_reads(g, 1, dt, vs)], [0, 0, 1, 1, 2, 2, 3, 3])
-    for grp in (2, 3):
-        for dt in range(4):
-            where = 8 * (grp - 2) + 2 * dt + 2 + (2 if grp == 2 else 0)
-            if OPT["pvsplit"]:
-                where = 4 * (grp - 1) + dt                   # key group g feeds MFMA 4 g of the block-A pass
-            for r in v_reads(g, grp, dt, vs):
-                gl[where].append(r)
-    emit_phase(g, 32, lambda i: pv_mfma(g, i), gl)
-    assert not g.out
-    stamp(g, 4)
+    if OPT["xitem"]:
+        # the ITEM's last step (t + 1 == ntiles) with a next item to prefetch for?  (a wave whose last tile comes earlier -- other query
+        # slices of a wider tile -- issues the loads in its idle last step below)
+        g.e(f"s_add_i32 {s(S_TMP)}, {s(S_T)}, 1")
+        g.e(f"s_cmp_eq_u32 {s(S_TMP)}, {s(S_NT)}")
+        g.e(f"s_cbranch_scc0 {g.lref('Llastplain' + P)}")
+        g.e(f"s_bitcmp1_b32 %[flags], 3")
+        g.e(f"s_cbranch_scc0 {g.lref('Llastplain' + P)}")
+        prefetch_setup(g)
+        last_tile("x", prefetch_pieces())
+        g.e(f"s_branch {g.lref('Lend' + P)}")
+        g.label("Llastplain" + P)
+    last_tile("", [])
 
     g.e(f"s_branch {g.lref('Lend' + P)}")
     g.label("Lidle" + P)
+    if OPT["xitem"]:
+        g.e(f"s_add_i32 {s(S_TMP)}, {s(S_T)}, 1")
+        g.e(f"s_cmp_eq_u32 {s(S_TMP)}, {s(S_NT)}")
+        g.e(f"s_cbranch_scc0 {g.lref('Lidlenp' + P)}")
+        g.e(f"s_bitcmp1_b32 %[flags], 3")
+        g.e(f"s_cbranch_scc0 {g.lref('Lidlenp' + P)}")
+        prefetch_setup(g)
+        for pre, ld, post in prefetch_pieces():
+            for ins in pre + ["s_nop 0", ld] + post:
+                g.e(ins)
+        g.label("Lidlenp" + P)
     stamp(g, 4)
     g.label("Lend" + P)
     g.e(f"s_add_i32 {s(S_T)}, {s(S_T)}, 1")
@@ -811,6 +911,11 @@ def gen_body():
         e(f"v_or_b32 {v(V_QLO + kq)}, {kq}, {v(V_T + 2)}")
         e(f"v_xor_b32 {v(V_QLO + kq)}, {v(V_QLO + kq)}, {v(V_T + 1)}")
         e(f"v_lshl_add_u32 {v(V_QLO + kq)}, {v(V_QLO + kq)}, 4, {v(V_T)}")
+    xitem = OPT["xitem"]
+    assert not xitem or OPT["heads"], "xitem is built on the heads form"
+    if xitem:
+        e(f"s_bitcmp1_b32 %[flags], 0")                                   # Q fragments, K(0), K(1) came with the previous item's last tile
+        e(f"s_cbranch_scc1 {g.lref('Lpkdone')}")
     e(f"s_mov_b64 {sr(S_QPTR)}, %[qbase]")
     e(f"s_lshl_b32 {s(S_TMP + 1)}, {s(S_QRS2)}, 2")
     heads = OPT["heads"]
@@ -843,12 +948,34 @@ def gen_body():
         e(f"global_load_lds_dwordx4 {v(V_U)}, {sr(S_QPTRB if heads and i >= 8 else S_QPTR)}")
     g.label("Lqdone")
     dma_tile(g, "k", 0, S_T, "pk0")
-    dma_tile(g, "v", 0, S_T, "pv0")
-    e(f"s_cmp_gt_i32 {s(S_NT)}, 1")
-    e(f"s_cbranch_scc0 {g.lref('Lp1')}")
-    e(f"s_mov_b32 {s(S_TMP)}, 1")
-    dma_tile(g, "k", 1, S_TMP, "pk1")
-    g.label("Lp1")
+    if xitem:                                                 # (K(1) in front of V(0): the skip labels below)
+        e(f"s_cmp_gt_i32 {s(S_NT)}, 1")
+        e(f"s_cbranch_scc0 {g.lref('Lp1')}")
+        e(f"s_mov_b32 {s(S_TMP)}, 1")
+        dma_tile(g, "k", 1, S_TMP, "pk1")
+        g.label("Lp1")
+        e(f"s_branch {g.lref('Lpv')}")
+        g.label("Lpkdone")
+        # prefetched: the running K pointer the steps continue from = row 4 * wave of tile 2 (the prologue's own loads advance it twice)
+        e(f"s_lshl_b32 {s(S_TMP)}, {s(S_KSTEP)}, 1")
+        e(f"s_add_u32 {s(S_KPTR)}, {s(S_KPTR)}, {s(S_TMP)}")
+        e(f"s_addc_u32 {s(S_KPTR + 1)}, {s(S_KPTR + 1)}, 0")
+        g.label("Lpv")
+        e(f"s_bitcmp1_b32 %[flags], 1")
+        e(f"s_cbranch_scc1 {g.lref('Lpvskip')}")
+        dma_tile(g, "v", 0, S_T, "pv0")
+        e(f"s_branch {g.lref('Lpvdone')}")
+        g.label("Lpvskip")
+        e(f"s_add_u32 {s(S_VPTR)}, {s(S_VPTR)}, {s(S_VSTEP)}")
+        e(f"s_addc_u32 {s(S_VPTR + 1)}, {s(S_VPTR + 1)}, 0")
+        g.label("Lpvdone")
+    else:
+        dma_tile(g, "v", 0, S_T, "pv0")
+        e(f"s_cmp_gt_i32 {s(S_NT)}, 1")
+        e(f"s_cbranch_scc0 {g.lref('Lp1')}")
+        e(f"s_mov_b32 {s(S_TMP)}, 1")
+        dma_tile(g, "k", 1, S_TMP, "pk1")
+        g.label("Lp1")
     for i in range(128):
         e(f"v_accvgpr_write_b32 {a(A_O + i)}, 0")
     for b in range(2):
@@ -860,26 +987,14 @@ def gen_body():
     stamp(g, 9)
     e(f"s_cmp_gt_i32 {s(S_NW)}, 0")
     e(f"s_cbranch_scc0 {g.lref('Lstepp0')}")
-    # ---- Q^T fragments out of the staging area: lane (j, hh) takes chunk 2 st + hh of rows j and 32 + j ----
-    QR = [V_T + i for i in range(8)]
-    e(f"v_and_b32 {v(V_U)}, 31, {v(V_LANE)}")                          # j
-    e(f"v_and_b32 {v(V_U + 1)}, 3, {v(V_U)}")
-    e(f"v_lshlrev_b32 {v(V_U + 1)}, 2, {v(V_U + 1)}")
-    e(f"v_bfe_u32 {v(V_U + 2)}, {v(V_U)}, 2, 2")
-    e(f"v_or_b32 {v(V_U + 1)}, {v(V_U + 1)}, {v(V_U + 2)}")            # swz(j)
-    e(f"v_lshrrev_b32 {v(V_U + 2)}, 5, {v(V_LANE)}")
-    e(f"v_xor_b32 {v(V_U + 1)}, {v(V_U + 1)}, {v(V_U + 2)}")           # hh ^ swz(j)
-    e(f"v_lshlrev_b32 {v(V_U)}, 8, {v(V_U)}")
-    e(f"v_lshl_or_b32 {v(V_U)}, {v(V_U + 1)}, 4, {v(V_U)}")
-    e(f"v_add_u32 {v(QR[0])}, {s(S_QST)}, {v(V_U)}")                    # (the staging base is a multiple of 256: the XOR below commutes)
-    for st in range(1, 8):
-        e(f"v_xor_b32 {v(QR[st])}, {st << 5}, {v(QR[0])}")
-    n = 0
-    for b in range(2):
-        for st in range(8):
-            g.lds(f"ds_read_b128 {ar(A_Q + 32 * b + 4 * st, 4)}, {v(QR[st])} offset:{8192 * b}", ("q", n))
-            n += 1
-        g.need(("q", 8 * b + 1))
+    # ---- Q^T fragments out of the staging area (unless the previous item's body left them in a[128:191]) ----
+    if xitem:
+        e(f"s_bitcmp1_b32 %[flags], 0")
+        e(f"s_cbranch_scc1 {g.lref('Lqfdone')}")
+    q_frag_reads(g)
+    if xitem:
+        g.drain()
+        g.label("Lqfdone")
     # ---- S(0) without overlap, mask, maxima, first reference exponents ----
     for f in range(8):
         k_read(g, f, 0)
@@ -923,7 +1038,17 @@ def gen_body():
     # stored as 16 x 1 KiB of whole 256-byte rows.
     g.label("Lepi")
     e("s_nop 15")
-    e("s_barrier")
+    if xitem:
+        # the next item's Q rows have landed in this wave's staging area (its own loads): fragments into a[128:191] -- the current item's are
+        # dead since its last S -- and the area is free for the output tile.  Wave-private: no barrier.
+        e(f"s_bitcmp1_b32 %[flags], 3")
+        e(f"s_cbranch_scc0 {g.lref('Lnoqn')}")
+        e("s_waitcnt vmcnt(0)")
+        q_frag_reads(g)
+        g.drain()
+        g.label("Lnoqn")
+    else:
+        e("s_barrier")
     T0, T1, X, D0, R, N, E1, Q_ = [V_T + i for i in range(8)]
     INV = [V_U, V_U + 1]
     for b in range(2):
@@ -949,8 +1074,11 @@ def gen_body():
         e(f"v_cndmask_b32 {v(INV[b])}, 0, {v(INV[b])}, vcc")
     # this wave's 16 KiB of LDS: base + wave * 16384 (base is a multiple of 1024: the XOR below commutes with the add)
     WA, RD, AD = V_T, V_T + 1, V_T + 2
-    e(f"s_lshl_b32 {s(S_TMP)}, %[wave], 14")
-    e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, {s(S_RING)}")
+    if xitem:
+        e(f"s_mov_b32 {s(S_TMP)}, {s(S_QST)}")                  # (1 KiB-aligned like the ring: the XOR below commutes with the add)
+    else:
+        e(f"s_lshl_b32 {s(S_TMP)}, %[wave], 14")
+        e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, {s(S_RING)}")
     e(f"v_and_b32 {v(WA)}, 31, {v(V_LANE)}")
     e(f"v_lshlrev_b32 {v(WA)}, 8, {v(WA)}")                         # row * 256
     e(f"v_add_u32 {v(WA)}, {v(WA)}, {v(V_HH8)}")                     # + 8 hh
@@ -998,7 +1126,11 @@ def gen_body():
             e(f"s_mov_b64 {sr(S_TMP)}, %[obase]")
             e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, %[ohs2]")
             e(f"s_addc_u32 {s(S_TMP + 1)}, {s(S_TMP + 1)}, 0")
-            e(f"s_mov_b32 {s(S_TMP2 + 1)}, %[nvalidb]")
+            if OPT["xitem"]:
+                e(f"s_bitcmp1_b32 %[flags], 2")
+                e(f"s_cselect_b32 {s(S_TMP2 + 1)}, %[nvalid], 0")
+            else:
+                e(f"s_mov_b32 {s(S_TMP2 + 1)}, %[nvalidb]")
         e(f"v_cmp_gt_i32 vcc, {s(S_TMP2 + 1)}, {v(V_LANE4)}")        # row 4 i + (lane >> 4) of this wave exists
         e("s_mov_b64 exec, vcc")
         e(f"global_store_dwordx4 {v(VO[i % 4])}, {vr(V_SA + 4 * i, 4)}, {sr(S_TMP)}")

@@ -699,11 +699,11 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   //     the last tile, queue drawn ahead) -- best when a workgroup runs many items (>= 3 rounds of them);
   //   * attn_fwd_gqa64.hip: attn_fwd64's generated loop with two heads per wave (~8 instead of ~18 instructions per MFMA, but every item
   //     pays its own prologue) -- best for few items per workgroup and for groups of <= 4 heads (64-query items).
-  // Same-process A/B (tools/exp_attn_gqa.py, profiles/r05_gqa_ab.txt; us per-head / 8-wave / generated, 28 / 4 heads): 2 x 524 19.8 / 25.4 /
-  // 19.4, 4 x 524 24.2 / 29.3 / 21.1, 8 x 524 42.5 / 42.8 / 41.3, 8 ragged 51.6 / 57.0 / 48.5, 16 x 524 77.5 / 62.0 / 78.5, 32 x 524 144 / 115 /
-  // 137, 32 x 294 70 / 54 / 63, 64 ragged 325 / 275 / 284, 16 x 1100 216 / 193 / 212, 32 x 1216 485 / 452 / 453; LLaVA-OV 32 / 8 heads
-  // 32 x 1230 597 / 518 / 484, 8 x 1230 148 / 130 / 130; 3B 16 / 2 heads 32 x 524 86 / 63 / 78.  One sequence (68 items) stays with the
-  // two-stream per-head form (13.5 vs 18.8 us).
+  // Same-process A/B (tools/exp_attn_gqa.py, profiles/r05_gqa_ab.txt; us per-head / 8-wave / generated, 28 / 4 heads): 2 x 524 19.9 / 24.8 /
+  // 19.8, 4 x 524 24.3 / 28.4 / 21.6, 8 x 524 43.3 / 42.5 / 45.3, 8 ragged 51.8 / 56.0 / 57.3, 16 x 524 78.6 / 61.1 / 74.3, 32 x 524 146 / 115 /
+  // 131, 32 x 294 72 / 54 / 65, 64 ragged 329 / 278 / 284, 16 x 1100 222 / 193 / 194, 32 x 1216 493 / 452 / 450, 8 x 2000 297 / 278 / 257;
+  // LLaVA-OV 32 / 8 heads 32 x 1230 606 / 517 / 480, 8 x 1230 152 / 130 / 124; 3B 16 / 2 heads 32 x 524 89 / 64 / 75.  One sequence (68
+  // items) stays with the two-stream per-head form (13.5 vs 19 us); from 2048 tokens attn_fwd64 (256-query items: 16 x 4096 1 690 vs 1 990).
   const int g_gqa = knob(VSEL_KNOB_ATTN_GQA);
   const int64_t rep_ = hq / hkv;
   if (d == 128 && g_attn_use_tr && !pg.block_table && !pg.seqlens_k && !pg.cu_k && g_attn_nw == 0 && rep_ >= 2 && rep_ <= 8 &&
@@ -712,12 +712,22 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
     // sized by the longest sequence, but a shorter sequence's items at the levels it does not reach are skipped in runs)
     const int64_t bq8 = 32 * (8 / rep_);
     const int64_t items8 = (total > 0 ? std::min(cdiv(total, bq8) + n_seq, cdiv(max_seqlen_q, bq8) * n_seq) : cdiv(max_seqlen_q, bq8) * n_seq) * hkv;
-    if (g_gqa == 1 || (g_gqa < 0 && max_seqlen_q < 2048 && !split2 && items8 >= 128)) {
-      const int form = knob(VSEL_KNOB_ATTN_GQA_FORM);
-      const bool gen = form >= 0 ? form == 1 : (rep_ <= 4 || items8 < 768);
-      return (gen ? attn::attn_fwd_gqa64_launch : attn::attn_fwd_gqa_launch)(st, q, k, v, cu_q, n_seq, max_seqlen_q, hq, hkv, scale, causal, out,
-                                                                              pg, lse);
+    const int64_t bq64 = 32 * (4 / ((rep_ + 1) / 2));
+    const int64_t items64 = (total > 0 ? std::min(cdiv(total, bq64) + n_seq, cdiv(max_seqlen_q, bq64) * n_seq) : cdiv(max_seqlen_q, bq64) * n_seq) * hkv;
+    // which form (-1: none).  The generated loop for groups of <= 4 heads (64-query items), for long-ish sequences (>= 1536 tokens: the tile
+    // loop dominates) and for grids of one or two rounds of items (static deal); the 8-wave form from three rounds of its items; in
+    // between (8 x 524: 544 items) the per-head forms are as fast.
+    int form = -1;
+    if (g_gqa == 1) form = knob(VSEL_KNOB_ATTN_GQA_FORM) == 1 ? 1 : (knob(VSEL_KNOB_ATTN_GQA_FORM) == 0 ? 0 : (rep_ <= 4 ? 1 : 0));
+    else if (g_gqa < 0 && max_seqlen_q < 2048 && !split2) {
+      if ((rep_ <= 4 || max_seqlen_q >= 1536) && items64 >= 128) form = 1;
+      else if (items8 >= 768) form = 0;
+      else if (items64 >= 128 && 20 * items64 <= 36 * 256) form = 1;
+      if (form >= 0 && knob(VSEL_KNOB_ATTN_GQA_FORM) >= 0) form = knob(VSEL_KNOB_ATTN_GQA_FORM);
     }
+    if (form >= 0)
+      return (form == 1 ? attn::attn_fwd_gqa64_launch : attn::attn_fwd_gqa_launch)(st, q, k, v, cu_q, n_seq, max_seqlen_q, hq, hkv, scale, causal, out,
+                                                                                   pg, lse);
   }
   if (d == 128 && g_attn_use_tr && !pack && !pg.block_table && g_attn_nw == 0 &&
       (g_rows64 == 1 || (g_rows64 < 0 && max_seqlen_q >= 2048 && !split2)))

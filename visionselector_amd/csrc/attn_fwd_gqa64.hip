@@ -42,18 +42,26 @@ __device__ unsigned g_gqa64_dbg[64 * 16];
 #define VSEL_GQA64_DBG_OPERAND
 #endif
 
+struct Gqa64Item {
+  int seq, kvh, q0, qs, qlen, n_tiles;             // n_tiles == 0: not an item (empty level of a shorter sequence, or past the end of the list)
+};
+
+// Items are pipelined into each other (generator option xitem): while an item's last tile is computed the NEXT item's Q rows, K(0), K(1) and
+// V(0) are loaded (in the gaps of the P V MFMAs), its Q fragments are read before the epilogue, and the work queue is drawn one item further
+// still -- a workgroup always knows its next item when it starts one.
 __global__ __launch_bounds__(256, 1) void attn_fwd_gqa64_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                 const uint16_t* __restrict__ v, const int32_t* __restrict__ cu,
                                                                 int hq, int hkv, float scale_log2e, int causal,
-                                                                uint16_t* __restrict__ out, int q_tiles, int n_seq, int slot,
-                                                                PagedKV pg, float* __restrict__ lse) {
+                                                                uint16_t* __restrict__ out, int q_tiles, int n_seq, int* __restrict__ counter,
+                                                                int static_deal, PagedKV pg, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(1024))) char smem[kGqa64Lds + 16];
   int& s_item = *reinterpret_cast<int*>(smem + kGqa64Lds);
   const int rep = hq / hkv;
   const int wps = (rep + 1) >> 1;                   // waves per 32-query slice (two heads per wave)
   const int QW = 4 / wps;                           // slices per tile
   const int kBlockQ = 32 * QW;
-  const int n_items = q_tiles * hkv * n_seq;
+  const int n_pairs = hkv * n_seq;
+  const int n_items = q_tiles * n_pairs;
   const int64_t q_rs = pg.q_row_stride ? pg.q_row_stride : (int64_t)hq * kHeadDim64;
   const int64_t q_hs = pg.q_row_stride ? pg.q_head_stride : kHeadDim64;
   const int64_t kv_rs = pg.kv_row_stride ? pg.kv_row_stride : (int64_t)hkv * kHeadDim64;
@@ -65,10 +73,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_gqa64_kernel(const uint16_t* 
   const int j = lane & 31, hh = lane >> 5;
   const bool head_wave = wave < QW * wps;           // (5 / 6 heads: three waves per slice, the fourth only helps to load)
   const int slice = head_wave ? wave / wps : 0;
-  const int hl = head_wave ? 2 * (wave % wps) : 0;  // first head of this wave inside the group
+  const int hl = head_wave ? 2 * (wave % wps) : 0;  // first head of this wave inside the group (a helper wave replays head 0's rows, stores nothing)
   const bool has_b = head_wave && hl + 1 < rep;     // (odd group sizes: the last wave of a slice has one head; block B replays it, nothing stored)
   const int lds_base = (int)lds_u32(smem);
-
+  const int qrs2 = (int)(q_rs * 2), krs2 = (int)(kv_rs * 2), vrs2 = (int)(v_rs * 2);
+  const int qhs2 = has_b ? (int)(q_hs * 2) : 0;
+  const int ostride = hq * kHeadDim64 * 2;
 #ifdef VSEL_GQA64_TRACE
   const unsigned long long t_kernel0 = __builtin_readcyclecounter();
   unsigned long long t_prev = t_kernel0;
@@ -76,39 +86,81 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_gqa64_kernel(const uint16_t* 
 #else
 #define GQA64_TRACE_END() do {} while (0)
 #endif
-  for (int round = 0;; ++round) {
-    int item;
-    if (slot == -2) {
-      item = static_deal_item(round);
-      if (item >= n_items) { GQA64_TRACE_END(); return; }
-    } else if (slot < 0) {
-      if (round > 0) { GQA64_TRACE_END(); return; }
-      item = blockIdx.x;
-      if (item >= n_items) return;
-    } else {
-      item = global_queue_next(&g_gqa64_work_counter[8 * (slot & 0xff)], n_items, &s_item, tid);
-    }
-    item = __builtin_amdgcn_readfirstlane(item);
-    if (item < 0) { GQA64_TRACE_END(); return; }
-    const int n_pairs = hkv * n_seq;
+
+  auto decode = [&](int item) -> Gqa64Item {
+    Gqa64Item it{0, 0, 0, 0, 0, 0};
+    if (item >= n_items) return it;
     const int level = item / n_pairs, pair = item - level * n_pairs;
-    const int seq = pair / hkv, kvh = pair - seq * hkv;
-    const int qs = cu[seq];
-    const int qlen = cu[seq + 1] - qs;
-    const int q0 = (q_tiles - 1 - level) * kBlockQ;
-    if (q0 >= qlen) {
-      if (slot >= 0 && (slot & 0x200) && kvh == 0)
-        queue_skip_empty_run(&g_gqa64_work_counter[8 * (slot & 0xff)], tid, cu, n_seq, hkv, level, seq,
-                             [&](int lv, int ql) { return (q_tiles - 1 - lv) * kBlockQ < ql; });
-      continue;
+    it.seq = pair / hkv;
+    it.kvh = pair - it.seq * hkv;
+    it.qs = cu[it.seq];
+    it.qlen = cu[it.seq + 1] - it.qs;
+    it.q0 = (q_tiles - 1 - level) * kBlockQ;
+    if (it.q0 >= it.qlen) return it;
+    const int kv_end = causal ? min(it.qlen, it.q0 + kBlockQ) : it.qlen;
+    it.n_tiles = (kv_end + kTileK - 1) / kTileK;
+    return it;
+  };
+  // a candidate that is not an item: the counter jumps over the run of empty items it starts (attn_common.h), draw again
+  auto validate = [&](int cand) -> Gqa64Item {
+    for (;;) {
+      Gqa64Item it = decode(cand);
+      if (it.n_tiles > 0 || cand >= n_items || !counter) return it;
+      const int level = cand / n_pairs, pair = cand - level * n_pairs;
+      if (pair % hkv == 0)
+        queue_skip_empty_run(counter, tid, cu, n_seq, hkv, level, pair / hkv, [&](int lv, int ql) { return (q_tiles - 1 - lv) * kBlockQ < ql; });
+      if (tid == 0) s_item = atomicAdd(counter, 1);
+      __syncthreads();
+      cand = __builtin_amdgcn_readfirstlane(s_item);
+      __syncthreads();
     }
-    const int len = qlen;
-    const int wave_qmin = q0 + 32 * slice;
+  };
+  auto q_ptr = [&](const Gqa64Item& it) {
+    return uniform_ptr64(q + (int64_t)it.qs * hq * kHeadDim64 + (int64_t)(it.q0 + 32 * slice) * q_rs + (it.kvh * rep + hl) * q_hs);
+  };
+  auto k_ptr = [&](const Gqa64Item& it) { return uniform_ptr64(k + (int64_t)it.qs * hkv * kHeadDim64 + it.kvh * kv_hs); };
+  auto v_ptr = [&](const Gqa64Item& it) { return uniform_ptr64(v + (int64_t)it.qs * hkv * kHeadDim64 + it.kvh * v_hs); };
+  // what the previous body may load for an item: whole tiles and 32 whole rows in every slice (the body's in-gap loads carry no clamps)
+  auto prefetchable = [&](const Gqa64Item& it) {
+    return it.n_tiles > 0 && it.q0 + kBlockQ <= it.qlen && it.qlen >= (it.n_tiles > 1 ? 2 * kTileK : kTileK);
+  };
+
+  // ---- the first item is the workgroup's own index, the second is drawn (and waited for) once ---------------------------------------------
+  // (static_deal: few rounds of items -- workgroup b takes items b, 2 G - 1 - b, 2 G + b, ... of the heaviest-first list, attn_common.h: no
+  // atomic, no publish; empty items of ragged batches are simply skipped)
+  int deal_round = 0;
+  auto deal_next = [&]() -> Gqa64Item {
+    for (;;) {
+      const int it_idx = static_deal_item(++deal_round);
+      const Gqa64Item it = decode(it_idx);
+      if (it.n_tiles > 0 || it_idx >= n_items) return it;
+    }
+  };
+  Gqa64Item cur = validate((int)blockIdx.x);        // (the counter starts at gridDim.x)
+  Gqa64Item next{0, 0, 0, 0, 0, 0};
+  if (static_deal) {
+    if (cur.n_tiles == 0) cur = deal_next();
+    if (cur.n_tiles == 0) return;
+    next = deal_next();
+  } else if (cur.n_tiles == 0) {
+    return;
+  } else if (counter) {
+    if (tid == 0) s_item = atomicAdd(counter, 1);
+    __syncthreads();
+    const int cand = __builtin_amdgcn_readfirstlane(s_item);
+    __syncthreads();
+    next = validate(cand);
+  }
+  int pref = 0;                                     // what the previous body already loaded of `cur`: bit 0 Q fragments + K(0) + K(1), bit 1 V(0)
+  for (;;) {
+    int pend = 0;                                   // thread 0: the draw for the item after next, in flight during the body
+    if (counter && next.n_tiles > 0 && tid == 0) pend = atomicAdd(counter, 1);
+    const int qlen = cur.qlen, len = cur.qlen;
+    const int wave_qmin = cur.q0 + 32 * slice;
     const int wave_qmax = min(wave_qmin + 31, qlen - 1);
     const int my_q = min(wave_qmin + j, qlen - 1);
     const bool row_ok = head_wave && wave_qmin + j < qlen;
-    const int kv_end = causal ? min(len, q0 + kBlockQ) : len;
-    const int n_tiles = (kv_end + kTileK - 1) / kTileK;
+    const int n_tiles = cur.n_tiles;
     int n_w = (head_wave && wave_qmin < qlen) ? n_tiles : 0;
     if (causal && n_w > 0) n_w = min(n_tiles, wave_qmax / kTileK + 1);
     n_w = __builtin_amdgcn_readfirstlane(n_w);
@@ -116,16 +168,20 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_gqa64_kernel(const uint16_t* 
     if (causal) mfirst = min(mfirst, wave_qmin / kTileK + ((wave_qmin % kTileK) != kTileK - 1 ? 0 : 1));
     mfirst = __builtin_amdgcn_readfirstlane(mfirst);
     const int kmax = causal ? min(len - 1, my_q) : len - 1;
-    const int head_a = kvh * rep + hl;
-    const uint16_t* const qbase = uniform_ptr64(q + (int64_t)qs * hq * kHeadDim64 + (int64_t)wave_qmin * q_rs + head_a * q_hs);
-    const uint16_t* const kbase = uniform_ptr64(k + (int64_t)qs * hkv * kHeadDim64 + kvh * kv_hs);
-    const uint16_t* const vbase = uniform_ptr64(v + (int64_t)qs * hkv * kHeadDim64 + kvh * v_hs);
-    const uint16_t* const obase = uniform_ptr64(out + ((int64_t)(qs + wave_qmin) * hq + head_a) * kHeadDim64);
-    const int qrs2 = (int)(q_rs * 2), krs2 = (int)(kv_rs * 2), vrs2 = (int)(v_rs * 2);
-    const int qhs2 = has_b ? (int)(q_hs * 2) : 0;
-    const int ostride = hq * kHeadDim64 * 2;
+    const int head_a = cur.kvh * rep + hl;
+    const uint16_t* const qbase = q_ptr(cur);
+    const uint16_t* const kbase = k_ptr(cur);
+    const uint16_t* const vbase = v_ptr(cur);
+    const uint16_t* const obase = uniform_ptr64(out + ((int64_t)(cur.qs + wave_qmin) * hq + head_a) * kHeadDim64);
     const int nvalid = __builtin_amdgcn_readfirstlane(head_wave ? qlen - wave_qmin : 0);
-    const int nvalidb = has_b ? nvalid : 0;
+    // the next item's loads ride in this item's last tile: K slots are both free there, V slot 0 only when that tile sits in slot 1
+    const bool nx_ok = prefetchable(next);
+    const int nx_flags = nx_ok ? (1 | (((n_tiles - 1) & 1) ? 2 : 0)) : 0;
+    const uint16_t* const nxq = nx_ok ? q_ptr(next) : qbase;
+    const uint16_t* const nxk0 = nx_ok ? k_ptr(next) : kbase;
+    const uint16_t* const nxk1 = (nx_ok && next.n_tiles > 1) ? nxk0 + (int64_t)kTileK * kv_rs : nxk0;
+    const uint16_t* const nxv = nx_ok ? v_ptr(next) : vbase;
+    const int flags = __builtin_amdgcn_readfirstlane(pref | (has_b ? 4 : 0) | (nx_flags << 3));
     const int len_u = __builtin_amdgcn_readfirstlane(len), ntiles_u = __builtin_amdgcn_readfirstlane(n_tiles);
     float m0, m1, l0, l1;
 #ifdef VSEL_GQA64_TRACE
@@ -140,17 +196,30 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_gqa64_kernel(const uint16_t* 
                  : [qbase] "s"(qbase), [qrs2] "s"(qrs2), [obase] "s"(obase), [ostride] "s"(ostride), [nvalid] "s"(nvalid), [kbase] "s"(kbase),
                    [vbase] "s"(vbase), [krs2] "s"(krs2), [vrs2] "s"(vrs2), [ntiles] "s"(ntiles_u), [nw] "s"(n_w), [mfirst] "s"(mfirst),
                    [len] "s"(len_u), [c] "s"(scale_log2e), [wave] "s"(wave), [ldsbase] "s"(lds_base), [kmaxa] "v"(kmax), [kmaxb] "v"(kmax),
-                   [qhs2] "s"(qhs2), [ohs2] "s"(2 * kHeadDim64), [nvalidb] "s"(nvalidb) VSEL_GQA64_DBG_OPERAND
+                   [qhs2] "s"(qhs2), [ohs2] "s"(2 * kHeadDim64), [flags] "s"(flags), [nxq] "s"(nxq), [nxk0] "s"(nxk0), [nxk1] "s"(nxk1),
+                   [nxv] "s"(nxv) VSEL_GQA64_DBG_OPERAND
                  : VSEL_GQA64_ASM_CLOBBERS);
     if (lse) {
       const float lt0 = l0 + __shfl_xor(l0, 32, 64), lt1 = l1 + __shfl_xor(l1, 32, 64);
       if (hh == 0 && row_ok) {
-        const int64_t r = (int64_t)(qs + my_q) * hq + head_a;
+        const int64_t r = (int64_t)(cur.qs + my_q) * hq + head_a;
         lse[r] = lt0 > 0.f ? (m0 + log2f(lt0)) * 0.6931471805599453f : -INFINITY;
         if (has_b) lse[r + 1] = lt1 > 0.f ? (m1 + log2f(lt1)) * 0.6931471805599453f : -INFINITY;
       }
     }
-    __syncthreads();                   // the next item's first loads overwrite ring slots / staging rows other waves may still read
+    if (next.n_tiles == 0) { GQA64_TRACE_END(); return; }
+    cur = next;
+    pref = nx_flags;
+    if (static_deal) {
+      __syncthreads();                 // the next item's own loads (what was not prefetched) overwrite ring slots other waves may still read
+      next = deal_next();
+    } else {
+      if (tid == 0) s_item = pend;
+      __syncthreads();                 // (the same barrier)
+      const int cand = __builtin_amdgcn_readfirstlane(s_item);
+      __syncthreads();                 // (s_item is rewritten by the next item's publish / the empty-candidate path)
+      next = validate(cand);
+    }
 #ifdef VSEL_GQA64_TRACE
     t_prev = __builtin_readcyclecounter();
 #endif
@@ -166,21 +235,19 @@ int attn_fwd_gqa64_launch(hipStream_t st, const void* q, const void* k, const vo
   const int q_tiles = (int)cdiv(max_seqlen_q, block_q);
   const int64_t n_items = (int64_t)q_tiles * hkv * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
-  const int64_t slots = 256;
-  int slot = -1, taken = -1;
-  if (attn_static_deal(n_items, slots, true, 36)) {
-    slot = -2;
-  } else if (n_items > slots) {
+  const int grid = (int)std::min<int64_t>(n_items, 256);
+  int taken = -1;
+  int* counter = nullptr;                          // one item per workgroup: no queue
+  const int static_deal = attn_static_deal(n_items, 256, true, 36) ? 1 : 0;
+  if (n_items > grid && !static_deal) {
     if (int rc = queue_slot_acquire(kSlotGqa, st, &taken)) return rc;
-    slot = taken;
     int* counters = nullptr;
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_gqa64_work_counter)));
-    VSEL_HIP_CHECK(hipMemsetAsync(counters + 8 * slot, 0, 8 * sizeof(int), st));
-    if (n_seq > 1 && knob(VSEL_KNOB_ATTN_SKIP_EMPTY) != 0) slot |= 0x200;
+    counter = counters + 8 * taken;
+    VSEL_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)counter, grid, 1, st));     // workgroup b starts with item b
   }
-  const dim3 grid((unsigned)std::min<int64_t>(n_items, slots));
-  hipLaunchKernelGGL(attn_fwd_gqa64_kernel, grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, cu_q,
-                     (int)hq, (int)hkv, scale * 1.4426950408889634f, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg, lse);
+  hipLaunchKernelGGL(attn_fwd_gqa64_kernel, dim3(grid), dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, cu_q,
+                     (int)hq, (int)hkv, scale * 1.4426950408889634f, causal, (uint16_t*)out, q_tiles, (int)n_seq, counter, static_deal, pg, lse);
   queue_slot_launched(kSlotGqa, taken, st);
   VSEL_AFTER_LAUNCH(st, "attn_fwd_gqa64_kernel");
   return VSEL_OK;

@@ -105,6 +105,35 @@ def test_lis_select_matches_reference(ops, golden_dir, name, storage):
     assert torch.equal(s2[0], scores)
 
 
+def test_lis_select_bench_batch_forms_match_reference(ops, golden_dir):
+    """The forms bench.py times -- B = 128 images of the 7B geometry: sweep 1 by one wave per (image, column slab), the register radix
+    select as its own launch, the gather with non-temporal stores -- against the reference's golden: the golden image sits at three
+    places of a batch of random images (images are scored independently, so its scores / indices / rows must be the golden's whatever
+    surrounds it), and the profile proves which kernels ran."""
+    from visionselector_amd import _native as N
+    g = load(golden_dir, "qwen7b_2304")
+    _, d, hd, n, seed = CASES["qwen7b_2304"]
+    c = oin.make_case(d, hd, n, seed)
+    hg, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    b = 128
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    h = torch.randn(b, n, d, device="cuda", generator=gen).bfloat16()
+    where = (0, 63, 127)
+    for i in where:
+        h[i] = hg
+    scale = max(1.0, float(np.abs(g["scores"]).max()))
+    k = olis.budget_k_eval(n, 0.2)
+    N.profile_start()
+    out, idx, scores = ops.lis_select(h, wq, bq, wk, bk, k)
+    prof = N.profile_stop()
+    assert {"colsum_seg_kernel", "score_kernel", "topk_select_kernel", "gather_rows_kernel"} <= set(prof), prof
+    for i in where:
+        assert np.abs(scores[i].cpu().numpy() - g["scores"]).max() <= 4e-6 * scale
+        assert np.array_equal(idx[i].cpu().numpy(), g[tag(0.2)]), "selected indices must be bit-exact"
+        assert torch.equal(out[i], hg[idx[i]])
+    assert torch.equal(scores[0], scores[63]) and torch.equal(scores[0], scores[127])
+
+
 # ---------------------------------------------------------------------------------------------------
 # against the reference's OWN bf16 run (contract (iii): bf16 scores within 1e-3, index symmetric difference reported):
 # tests/golden/lisbf16_*.npz = the reference modules and tokens in bfloat16, every op rounding to bf16

@@ -5,7 +5,7 @@
 // qwen-vl-finetune/qwenvl/train/trainer.py:101-113).  What differs is WHEN a wave does what.  In the sequential form a wave's tile is one
 // dependent chain -- K fragments out of LDS, S^T = K Q^T, maxima, exponentials, V fragments, O^T += V^T P^T, barrier -- and measured alone
 // on its SIMD a wave needs ~3 200 cycles per tile for 1 024 cycles of matrix work; two waves per SIMD in lockstep share it at ~4 600
-// (profiles/r05_gqa_notes.txt: knock-outs -- without ANY MFMA the kernel is 13 % faster, without the barrier 20 %).  Here, as in
+// (profiles/EXPERIMENTS.md, round 5: knock-outs -- without ANY MFMA the kernel is 13 % faster, without the barrier 20 %).  Here, as in
 // attn_fwd64.hip's generated loop but compiler-scheduled at two waves per SIMD:
 //     phase X   S(t+1) = K(t+1) Q^T   (16 MFMAs)  beside  p = exp2(S(t) c - m), row sums, bf16 packing of tile t          (VALU)
 //     phase Y   O^T  += V(t)^T P(t)^T (16 MFMAs)  beside  the (masked) row maxima of S(t+1)                                  (VALU)

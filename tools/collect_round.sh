@@ -9,7 +9,7 @@ cd "$ROOT"
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-train --no-attn --no-llm --no-single-sweep --no-batch1"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-train --no-attn --no-llm --no-single-sweep --no-batch1 --no-configs"
 # 1. the default bench line (all legs)
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 # 2. rocprofv3 --kernel-trace --stats of the headline launches
@@ -18,7 +18,7 @@ python tools/summarize_rocprof.py $(find $OUT/prof_b128 -name '*kernel_stats.csv
 python tools/trace_gaps.py $(find $OUT/prof_b128 -name '*kernel_trace.csv' | head -1) 8 > $OUT/bench_b128_gaps.txt
 find $OUT/prof_b128 -name '*kernel_trace.csv' -delete
 # 2b. the same with the single-sweep leg: gelu_colsum / colsum_linear / presummed select in the kernel stats
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_ss -o lis -- python $ROOT/bench.py --no-cpu-baseline --no-train --no-attn --no-llm --no-batch1 --steps 10 --warmup 3 > $OUT/bench_single_sweep_under_rocprof.json 2> $OUT/prof_ss.err)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_ss -o lis -- python $ROOT/bench.py --no-cpu-baseline --no-train --no-attn --no-llm --no-batch1 --no-configs --steps 10 --warmup 3 > $OUT/bench_single_sweep_under_rocprof.json 2> $OUT/prof_ss.err)
 python tools/summarize_rocprof.py $(find $OUT/prof_ss -name '*kernel_stats.csv' | head -1) $OUT/bench_b128_single_sweep_kernel_stats.csv > /dev/null
 find $OUT/prof_ss -name '*kernel_trace.csv' -delete
 # 3. HBM traffic: separate PMC passes

@@ -327,7 +327,7 @@ def test_dq64_pass_is_bit_identical_to_the_reference_dq_kernel(lens, hq, hkv, ca
 @pytest.mark.parametrize("split", [0, 1])
 def test_dkdv64_pass_is_bit_identical_to_the_four_wave_dkdv_kernel(lens, hq, hkv, causal, split):
     """The hand-scheduled dK / dV pass keeps the four-wave kernel's work split (wave w owns keys 32 w .. 32 w + 31 of a 128-key item,
-    the group's q heads looped inside) and its summation order over query tiles: dK and dV are bit-identical to that form's.  (Oracle
+    the group's q heads looped inside) and its summation order (query tiles from the sequence's end downward, heads inner): dK and dV are bit-identical to that form's.  (Oracle
     parity of the gradients is test_backward_matches_oracle's; this is the form-vs-form gate.)  Lengths with remainders 1 / 65 / 129
     exercise the clamped tile loads (one valid row), partial key blocks, key blocks above the diagonal and the two-sided mask.
     split = 1: the per-q-head item form (raw fp32 partial rows + attn_bwd_group_sum_kernel) in both kernels."""

@@ -68,7 +68,9 @@ S_WAVE = 81
 S_PTR2 = 82                                       # 82..83
 S_FLAG = 84                                       # this tile needs the mask for this wave
 S_SL2P = 86                                       # 86..87: sl2 twice (operand pair of the packed fma)
-FIRST_S, LAST_S = 40, 87
+S_NS0 = 42                                        # order=td: first step that may run the steady form (s42 is otherwise unused)
+S_H0, S_HEND, S_CH, S_NH = 85, 88, 89, 90         # order=td: the item's first head, one past its last, heads done on the compute side's tile, head count
+FIRST_S, LAST_S = 40, 90
 
 KBUF = 16384
 NQ = 3                                            # ring slots of Q and of dO
@@ -77,7 +79,8 @@ D_BASE = LSE_BASE + NQ * 256
 LDS_BYTES = D_BASE + NQ * 256
 
 # defaults = the measured best (profiles/r04_dkdv64_ab.txt); bar=top, valu=skew, split=24, tail=11 is the first working form
-OPT = {"dma": "1,3,5,7,9,11,13,15", "split": "40", "ko": "", "bar": "mid", "valu": "ab", "trx": "0", "tail": "13", "fw": "0", "fr": "9", "pk": "0"}
+OPT = {"dma": "1,3,5,7,9,11,13,15", "split": "40", "ko": "", "bar": "mid", "valu": "ab", "trx": "0", "tail": "13", "fw": "0", "fr": "9", "pk": "0",
+       "order": "td"}
 for kv in os.environ.get("DKDV64_OPTS", "").split(","):
     if "=" in kv:
         key, val = kv.split("=", 1)
@@ -92,6 +95,9 @@ PK = OPT["pk"] == "1"              # packed fp32 VALU (v_pk_fma / add / mul_f32:
 FINE_WAITS = OPT["fw"] == "1"     # SdP waits per row fragment instead of per group of them
 FR_GAP = int(OPT["fr"])            # first dVdK gap that carries the next SdP's first row reads (two per gap)
 TAIL_HI = int(OPT["tail"])         # last SdP gap that takes VALU of the previous unit
+ORDER_TD = OPT["order"] == "td"   # tiles outer from the sequence's END downward, the item's heads inner (ht: heads outer, tiles ascending): the
+                                   # items of one sequence (key blocks, causal: each starts at its own first query) then sit on the SAME Q / dO
+                                   # tile at the same time, and a ragged sequence's one partial tile comes first, every later step steady
 BAR_STAG = OPT["bar"] == "stag"    # bar=mid with waves 2, 3 at the barrier one batch earlier: they then run one batch behind waves 0, 1, so
                                    # two waves are in an SdP batch (row reads) while two are in a dVdK batch (half-rate transposed reads)
 BAR_MID = OPT["bar"] in ("mid", "stag")      # the step's barrier in front of its last batch, whose gaps then carry the NEXT tile's first reads
@@ -303,6 +309,13 @@ def tile_flags(g):
 
 def advance_cqt(g):
     e = g.e
+    if ORDER_TD:
+        e(f"s_add_i32 {s(S_CH)}, {s(S_CH)}, 1")
+        e(f"s_cmp_eq_u32 {s(S_CH)}, {s(S_NH)}")
+        e(f"s_cselect_b32 {s(S_TMP2)}, 64, 0")
+        e(f"s_cselect_b32 {s(S_CH)}, 0, {s(S_CH)}")
+        e(f"s_sub_i32 {s(S_CQT)}, {s(S_CQT)}, {s(S_TMP2)}")
+        return
     e(f"s_add_i32 {s(S_CQT)}, {s(S_CQT)}, 64")
     e(f"s_cmp_ge_i32 {s(S_CQT)}, {s(S_LEN)}")
     e(f"s_cselect_b32 {s(S_CQT)}, {s(S_QBEG)}, {s(S_CQT)}")
@@ -353,6 +366,14 @@ def load_tail(g, slot, uniq):
     e("s_nop 0")
     e(f"global_load_lds_dword {v(V_U)}, {sr(S_TMP)}")
     g.label("Lnold" + uniq)
+    if ORDER_TD:
+        e(f"s_add_i32 {s(S_LHEAD)}, {s(S_LHEAD)}, 1")
+        e(f"s_cmp_eq_u32 {s(S_LHEAD)}, {s(S_HEND)}")
+        e(f"s_cselect_b32 {s(S_TMP2)}, 64, 0")
+        e(f"s_cselect_b32 {s(S_LHEAD)}, {s(S_H0)}, {s(S_LHEAD)}")
+        e(f"s_sub_i32 {s(S_LQT)}, {s(S_LQT)}, {s(S_TMP2)}")
+        e(f"s_add_i32 {s(S_LCNT)}, {s(S_LCNT)}, 1")
+        return
     e(f"s_add_i32 {s(S_LQT)}, {s(S_LQT)}, 64")
     e(f"s_cmp_ge_i32 {s(S_LQT)}, {s(S_LEN)}")
     e(f"s_cselect_b32 {s(S_TMP2)}, 1, 0")
@@ -528,7 +549,10 @@ def gen_step(g, idx):
         e("s_barrier")
     e(f"s_cmp_lt_i32 {s(S_IT)}, {s(S_NF)}")
     e(f"s_cbranch_scc0 {g.lref('Lgen' + P)}")
-    e(f"s_cmp_gt_i32 {s(S_IT)}, 0")
+    if ORDER_TD:
+        e(f"s_cmp_ge_i32 {s(S_IT)}, {s(S_NS0)}")
+    else:
+        e(f"s_cmp_gt_i32 {s(S_IT)}, 0")
     e(f"s_cbranch_scc0 {g.lref('Lgen' + P)}")
     g.out = carry_reads()
     step_body(g, idx, "s" + P, True, True)
@@ -578,13 +602,33 @@ def gen_body():
     e(f"s_mov_b32 {s(S_CQT)}, {s(S_QBEG)}")
     e(f"s_mov_b32 {s(S_LCNT)}, 0")
     e(f"s_mov_b32 {s(S_IT)}, 0")
+    if ORDER_TD:
+        # cursors start on the LAST tile (the one partial tile of a ragged sequence): qt = qbegin + 64 (ceil((len - qbegin) / 64) - 1).
+        # Steps [0, nheads) work on it; a step is steady when its NEXT tile is whole: it >= max(1, partial ? nheads - 1 : 1), it < niter - 1
+        e(f"s_mov_b32 {s(S_NH)}, %[nheads]")
+        e(f"s_mov_b32 {s(S_H0)}, {s(S_LHEAD)}")
+        e(f"s_add_i32 {s(S_HEND)}, {s(S_LHEAD)}, {s(S_NH)}")
+        e(f"s_mov_b32 {s(S_CH)}, 0")
+        e(f"s_sub_i32 {s(S_TMP)}, {s(S_LEN)}, {s(S_QBEG)}")
+        e(f"s_add_i32 {s(S_TMP)}, {s(S_TMP)}, -1")
+        e(f"s_andn2_b32 {s(S_TMP)}, {s(S_TMP)}, 63")
+        e(f"s_add_i32 {s(S_LQT)}, {s(S_QBEG)}, {s(S_TMP)}")
+        e(f"s_mov_b32 {s(S_CQT)}, {s(S_LQT)}")
+        e(f"s_sub_i32 {s(S_TMP)}, {s(S_LEN)}, {s(S_QBEG)}")
+        e(f"s_and_b32 {s(S_TMP)}, {s(S_TMP)}, 63")
+        e(f"s_add_i32 {s(S_TMP + 1)}, {s(S_NH)}, -1")
+        e(f"s_cmp_eq_u32 {s(S_TMP)}, 0")
+        e(f"s_cselect_b32 {s(S_NS0)}, 1, {s(S_TMP + 1)}")
+        e(f"s_max_i32 {s(S_NS0)}, {s(S_NS0)}, 1")
+        e(f"s_add_i32 {s(S_NF)}, {s(S_NIT)}, -1")
     # steady steps: it >= 1 with a next tile that is whole.  Tiles of a head are whole except its last one when (len - qbegin) % 64 != 0:
     # then no step is steady (the generic form clamps); else every step with a next tile is.
-    e(f"s_sub_i32 {s(S_TMP)}, {s(S_LEN)}, {s(S_QBEG)}")
-    e(f"s_and_b32 {s(S_TMP)}, {s(S_TMP)}, 63")
-    e(f"s_cmp_eq_u32 {s(S_TMP)}, 0")
-    e(f"s_cselect_b32 {s(S_NF)}, {s(S_NIT)}, 0")
-    e(f"s_add_i32 {s(S_NF)}, {s(S_NF)}, -1")
+    if not ORDER_TD:
+        e(f"s_sub_i32 {s(S_TMP)}, {s(S_LEN)}, {s(S_QBEG)}")
+        e(f"s_and_b32 {s(S_TMP)}, {s(S_TMP)}, 63")
+        e(f"s_cmp_eq_u32 {s(S_TMP)}, 0")
+        e(f"s_cselect_b32 {s(S_NF)}, {s(S_NIT)}, 0")
+        e(f"s_add_i32 {s(S_NF)}, {s(S_NF)}, -1")
     # lane-derived constants (as in gen_attn_fwd64.py)
     T = [V_T + i for i in range(6)]
     e(f"v_mbcnt_lo_u32_b32 {v(V_LANE)}, -1, 0")

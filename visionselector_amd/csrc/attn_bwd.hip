@@ -409,7 +409,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
     // image of such a load is lane-linear (wave-uniform base + 16 * lane), so the swizzle is applied to the SOURCE address:
     // LDS position (row, part') receives global part part' ^ swz(row).  A wave-instruction covers 4 rows; wave w issues
     // instructions w, w+4, w+8, w+12, for which swz(row) = ((lane >> 4) << 2) | w is a per-lane constant.
-    int ld_qt = q_begin, ld_head = SPLIT ? hsel : kvh * rep;     // (query tile, head) of the NEXT tile to load
+    // Tile order: query tiles OUTER from the sequence's END downward, the item's q heads INNER.  Under the causal mask the items of a
+    // sequence (its key blocks) start at different first queries but all end at the last one, so walking down from the end puts the
+    // items that run side by side on the SAME Q / dO tile at the same time (one HBM fetch, the rest L2 hits), and a ragged sequence's
+    // one partial tile is the first tile of every head instead of the last.  attn_bwd_dkdv8_kernel and the generated
+    // attn_bwd_dkdv64_kernel (tools/gen_attn_bwd_dkdv64.py, order=td) walk the same way: dK / dV are bit-identical across the forms.
+    const int first_head = SPLIT ? hsel : kvh * rep, n_heads = SPLIT ? 1 : rep;
+    const int q_last = q_begin + (tiles_per_head - 1) * kTile;
+    int ld_qt = q_last, ld_head = first_head;                    // (query tile, head) of the NEXT tile to load
     const int ld_part = slice_src_part(lane, wave) * 8;
     auto load_tile = [&](int buf) {
       typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -427,8 +434,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
         if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(lse + o), (lptr_t)(&lse_sm[buf][0]), 4, 0, 0);
         else __builtin_amdgcn_global_load_lds((gptr_t)(dvec + o), (lptr_t)(&d_sm[buf][0]), 4, 0, 0);
       }
-      ld_qt += kTile;
-      if (ld_qt >= len) { ld_qt = q_begin; ++ld_head; }
+      if (++ld_head == first_head + n_heads) { ld_head = first_head; ld_qt -= kTile; }
     };
     load_tile(0);
     __syncthreads();
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
 #ifdef VSEL_TRACE
     bool trace_on = false;
 #endif
-    int qt = q_begin;                                            // query tile being processed
+    int qt = q_last, qt_heads = 0;                               // query tile being processed; heads done on it
     // one 64-query tile from LDS buffer CUR (compile-time, so that every LDS address is a per-lane base + an immediate)
     auto tile_body = [&](auto cur_c) {
       constexpr int CUR = decltype(cur_c)::value;
@@ -512,8 +518,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
           VSEL_BWD_STAMP(3 + 2 * qb);
         }
       }
-      qt += kTile;
-      if (qt >= len) qt = q_begin;
+      if (++qt_heads == n_heads) { qt_heads = 0; qt -= kTile; }
     };
 
     for (int it = 0; it < n_iter; it += 2) {
@@ -687,7 +692,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
     const int q_begin = causal ? k0 : 0;
     const int tiles_per_head = (len - q_begin + kTile - 1) / kTile;
     const int n_iter = tiles_per_head * n_heads;
-    int ld_qt = q_begin, ld_head = first_head;
+    const int q_last = q_begin + (tiles_per_head - 1) * kTile;   // tiles outer from the END downward, heads inner (attn_bwd_dkdv_kernel)
+    int ld_qt = q_last, ld_head = first_head;
     auto load_tile = [&](int buf) {
       if (ld_qt + kTile <= len) {
         // full tile: a wave-uniform 64-bit row base on the scalar ALU plus the per-lane 32-bit offset computed once per item
@@ -718,8 +724,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
         if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(lse + o), (lptr_t)(&lse_sm[buf][0]), 4, 0, 0);
         else __builtin_amdgcn_global_load_lds((gptr_t)(dvec + o), (lptr_t)(&d_sm[buf][0]), 4, 0, 0);
       }
-      ld_qt += kTile;
-      if (ld_qt >= len) { ld_qt = q_begin; ++ld_head; }
+      if (++ld_head == first_head + n_heads) { ld_head = first_head; ld_qt -= kTile; }
     };
     load_tile(0);
     __syncthreads();
@@ -727,7 +732,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
 #ifdef VSEL_TRACE
     bool trace_on = false;
 #endif
-    int qt = q_begin;
+    int qt = q_last, qt_heads = 0;
     auto tile_body = [&](auto cur_c) {
       constexpr int CUR = decltype(cur_c)::value;
       const int qw0 = qt + 32 * qh;                              // first query of the wave's half
@@ -822,8 +827,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
         }
         VSEL_BWD_STAMP(3);
       }
-      qt += kTile;
-      if (qt >= len) qt = q_begin;
+      if (++qt_heads == n_heads) { qt_heads = 0; qt -= kTile; }
     };
 
     for (int it = 0; it < n_iter; it += 2) {

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
     const int tiles_per_head = (len - q_begin + kTileK - 1) / kTileK;
     const int n_iter = __builtin_amdgcn_readfirstlane(tiles_per_head * n_heads);
     const int head0 = __builtin_amdgcn_readfirstlane(first_head);
+    const int nheads_u = __builtin_amdgcn_readfirstlane(n_heads);
 
     const void* const qbase = uniform_ptr(q + (int64_t)qs * hq * kD);
     const void* const dobase = uniform_ptr(dout + (int64_t)qs * hq * kD);
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
                  :
                  : [qbase] "s"(qbase), [dobase] "s"(dobase), [lsebase] "s"(lsebase), [dbase] "s"(dbase), [qrs2] "s"(qrs2),
                    [fstride] "s"(fstride), [niter] "s"(n_iter), [qbegin] "s"(qbeg_u), [len] "s"(len_u), [sl2] "s"(sl2), [scale] "s"(scale),
-                   [kw0] "s"(kw0), [causal] "s"(causal), [wave] "s"(wave), [head0] "s"(head0), [ldsbase] "s"(lds_base), [split] "s"(split_u),
+                   [kw0] "s"(kw0), [causal] "s"(causal), [wave] "s"(wave), [head0] "s"(head0), [nheads] "s"(nheads_u), [ldsbase] "s"(lds_base), [split] "s"(split_u),
                    [kptr] "v"(kptr), [vptr] "v"(vptr), [dkptr] "v"(dkptr), [dvptr] "v"(dvptr), [kvalid] "v"(kvalid)
                  : VSEL_DKDV64_ASM_CLOBBERS);
     __syncthreads();                   // the next item's first loads overwrite ring slots other waves may still read

@@ -69,7 +69,12 @@ typedef enum vsel_debug_knob {
   VSEL_KNOB_ATTN_GQA_FORM = 20,   /* which group-shared forward: -1 by item count and group size (default), 0 the 8-wave form (one head per wave,
                                      items pipelined into each other; csrc/attn_fwd_gqa.hip), 1 the generated 64-rows-per-wave loop with two heads
                                      per wave (csrc/attn_fwd_gqa64.hip); env VSEL_ATTN_GQA_FORM; bit-identical outputs */
-  VSEL_KNOB_COUNT = 21
+  VSEL_KNOB_ATTN_BWD_UPDOWN = 21, /* dK / dV pass, causal, even number of kv heads: items of odd kv heads walk their query tiles UPWARD from the item's
+                                     first query (even ones downward from the sequence's end) and (sequence, kv head) pairs are queued in couples
+                                     per XCD, so the two directions alternate on a queue and its CUs stay on one Q / dO tile per pair (L2);
+                                     default 1; env VSEL_ATTN_BWD_UPDOWN; a rule of the item alone (batch-invariant), fp32 association of odd
+                                     heads differs from the 0 setting */
+  VSEL_KNOB_COUNT = 22
 } vsel_debug_knob;
 
 /* Set knob to value (clamped to the knob's range).  *previous (may be NULL) receives the value it had.

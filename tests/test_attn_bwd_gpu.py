@@ -354,6 +354,52 @@ def test_dkdv64_pass_is_bit_identical_to_the_four_wave_dkdv_kernel(lens, hq, hkv
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("lens,hq,hkv", [([300, 129, 64], 4, 2), ([37, 700, 256, 129], 28, 4), ([1230, 65], 32, 8), ([2368], 8, 4), ([4096, 1], 8, 2)])
+def test_dkdv_walk_direction_is_a_rule_of_the_item(lens, hq, hkv):
+    """Round 5: dK / dV items of odd kv heads walk their query tiles upward, even ones downward from the sequence's end (knob
+    attn_bwd_updown, attn_common.h dkdv_walks_up).  Against the all-downward setting: dQ bit-identical (another pass), dK / dV of EVEN kv heads
+    bit-identical, of odd ones within a bf16 rounding; the 4-wave and the 64-row kernel give the same bits under either setting (the 8-wave
+    kernel, whose fp32 association differs anyway, within a rounding); a sequence's gradients do not depend on its place in the batch (reversed batch order)."""
+    import torch
+    from visionselector_amd import _native as N, ops
+    g = torch.Generator(device="cuda").manual_seed(57 + len(lens))
+    T = sum(lens)
+    q = torch.randn(T, hq, 128, device="cuda", generator=g).bfloat16()
+    k = torch.randn(T, hkv, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(T, hkv, 128, device="cuda", generator=g).bfloat16()
+    do = torch.randn(T, hq, 128, device="cuda", generator=g).bfloat16()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
+    out, lse = ops.varlen_attn_fwd_lse(q, k, v, cu, max(lens))
+    res = {}
+    for ud in (0, 1):
+        for form in ({"attn_bwd_dkdv64": 0, "attn_bwd_waves": 4}, {"attn_bwd_dkdv64": 0, "attn_bwd_waves": 8}, {"attn_bwd_dkdv64": 1}):
+            with N.debug_knob(attn_bwd_updown=ud, attn_bwd_split=0, **form):
+                got = ops.varlen_attn_bwd(do, q, k, v, out, lse, cu, max(lens))
+            if ud in res:
+                for i, (a, b) in enumerate(zip(got, res[ud])):
+                    if form.get("attn_bwd_waves") == 8 and i > 0:     # (the 8-wave kernel adds two half-tile sums per key block: another fp32 association)
+                        assert float((a.float() - b.float()).abs().max()) <= 2 ** -7 * float(b.float().abs().max()), (ud, form)
+                    else:
+                        assert torch.equal(a, b), (ud, form)
+            else:
+                res[ud] = got
+    assert torch.equal(res[0][0], res[1][0])
+    for i in (1, 2):
+        assert torch.equal(res[0][i][:, 0::2], res[1][i][:, 0::2])
+        assert float((res[0][i].float() - res[1][i].float()).abs().max()) <= 2 ** -7 * float(res[0][i].float().abs().max())
+        assert not torch.equal(res[0][i][:, 1::2], res[1][i][:, 1::2]) or max(lens) <= 64     # (the odd heads really took the other order)
+    # reversed batch order: every sequence's rows come out with the same bits
+    order = list(range(len(lens)))[::-1]
+    starts = [0] + list(torch.tensor(lens).cumsum(0).tolist())
+    rows = torch.cat([torch.arange(starts[i], starts[i + 1]) for i in order]).cuda()
+    cu_r = torch.tensor([0] + list(torch.tensor([lens[i] for i in order]).cumsum(0)), dtype=torch.int32, device="cuda")
+    got_r = ops.varlen_attn_bwd(do[rows].contiguous(), q[rows].contiguous(), k[rows].contiguous(), v[rows].contiguous(), out[rows].contiguous(),
+                                lse[rows].contiguous(), cu_r, max(lens))
+    base = ops.varlen_attn_bwd(do, q, k, v, out, lse, cu, max(lens))
+    for a, b in zip(got_r, base):
+        assert torch.equal(a, b[rows])
+
+
 @pytest.mark.parametrize("lens,hq,hkv", [([1100, 1300], 28, 4), ([1025, 129, 64, 2000], 8, 2), ([1500], 16, 2), ([1100, 700], 32, 8)])
 def test_dkdv_group_in_parts_matches_the_formula_and_the_other_item_forms(lens, hq, hkv):
     """dK / dV with a group's q heads cut in 2 / 3 / 4 PARTS (knob attn_bwd_split = k; csrc/attn_bwd_dkdv64.hip: a part = one item that

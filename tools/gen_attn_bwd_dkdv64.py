@@ -70,7 +70,8 @@ S_FLAG = 84                                       # this tile needs the mask for
 S_SL2P = 86                                       # 86..87: sl2 twice (operand pair of the packed fma)
 S_NS0 = 42                                        # order=td: first step that may run the steady form (s42 is otherwise unused)
 S_H0, S_HEND, S_CH, S_NH = 85, 88, 89, 90         # order=td: the item's first head, one past its last, heads done on the compute side's tile, head count
-FIRST_S, LAST_S = 40, 90
+S_STEP = 91                                       # order=td: -64 (tiles from the end downward) or +64 (%[dirup]: from the item's first query upward)
+FIRST_S, LAST_S = 40, 91
 
 KBUF = 16384
 NQ = 3                                            # ring slots of Q and of dO
@@ -312,9 +313,9 @@ def advance_cqt(g):
     if ORDER_TD:
         e(f"s_add_i32 {s(S_CH)}, {s(S_CH)}, 1")
         e(f"s_cmp_eq_u32 {s(S_CH)}, {s(S_NH)}")
-        e(f"s_cselect_b32 {s(S_TMP2)}, 64, 0")
+        e(f"s_cselect_b32 {s(S_TMP2)}, {s(S_STEP)}, 0")
         e(f"s_cselect_b32 {s(S_CH)}, 0, {s(S_CH)}")
-        e(f"s_sub_i32 {s(S_CQT)}, {s(S_CQT)}, {s(S_TMP2)}")
+        e(f"s_add_i32 {s(S_CQT)}, {s(S_CQT)}, {s(S_TMP2)}")
         return
     e(f"s_add_i32 {s(S_CQT)}, {s(S_CQT)}, 64")
     e(f"s_cmp_ge_i32 {s(S_CQT)}, {s(S_LEN)}")
@@ -369,9 +370,9 @@ def load_tail(g, slot, uniq):
     if ORDER_TD:
         e(f"s_add_i32 {s(S_LHEAD)}, {s(S_LHEAD)}, 1")
         e(f"s_cmp_eq_u32 {s(S_LHEAD)}, {s(S_HEND)}")
-        e(f"s_cselect_b32 {s(S_TMP2)}, 64, 0")
+        e(f"s_cselect_b32 {s(S_TMP2)}, {s(S_STEP)}, 0")
         e(f"s_cselect_b32 {s(S_LHEAD)}, {s(S_H0)}, {s(S_LHEAD)}")
-        e(f"s_sub_i32 {s(S_LQT)}, {s(S_LQT)}, {s(S_TMP2)}")
+        e(f"s_add_i32 {s(S_LQT)}, {s(S_LQT)}, {s(S_TMP2)}")
         e(f"s_add_i32 {s(S_LCNT)}, {s(S_LCNT)}, 1")
         return
     e(f"s_add_i32 {s(S_LQT)}, {s(S_LQT)}, 64")
@@ -603,8 +604,10 @@ def gen_body():
     e(f"s_mov_b32 {s(S_LCNT)}, 0")
     e(f"s_mov_b32 {s(S_IT)}, 0")
     if ORDER_TD:
-        # cursors start on the LAST tile (the one partial tile of a ragged sequence): qt = qbegin + 64 (ceil((len - qbegin) / 64) - 1).
-        # Steps [0, nheads) work on it; a step is steady when its NEXT tile is whole: it >= max(1, partial ? nheads - 1 : 1), it < niter - 1
+        # Direction %[dirup] = 0: cursors start on the LAST tile (the one partial tile of a ragged sequence), qt = qbegin +
+        # 64 (ceil((len - qbegin) / 64) - 1), and walk down; steps [0, nheads) work on it.  %[dirup] = 1: from qbegin upward, the partial tile
+        # is the last one (steps [niter - nheads, niter)).  A step is steady when its NEXT tile is whole:
+        #   down:  max(1, partial ? nheads - 1 : 1) <= it < niter - 1          up:  1 <= it < (partial ? niter - nheads : niter) - 1
         e(f"s_mov_b32 {s(S_NH)}, %[nheads]")
         e(f"s_mov_b32 {s(S_H0)}, {s(S_LHEAD)}")
         e(f"s_add_i32 {s(S_HEND)}, {s(S_LHEAD)}, {s(S_NH)}")
@@ -612,15 +615,23 @@ def gen_body():
         e(f"s_sub_i32 {s(S_TMP)}, {s(S_LEN)}, {s(S_QBEG)}")
         e(f"s_add_i32 {s(S_TMP)}, {s(S_TMP)}, -1")
         e(f"s_andn2_b32 {s(S_TMP)}, {s(S_TMP)}, 63")
-        e(f"s_add_i32 {s(S_LQT)}, {s(S_QBEG)}, {s(S_TMP)}")
+        e(f"s_add_i32 {s(S_TMP)}, {s(S_QBEG)}, {s(S_TMP)}")                       # the last tile
+        e(f"s_cmp_lg_u32 %[dirup], 0")
+        e(f"s_cselect_b32 {s(S_LQT)}, {s(S_QBEG)}, {s(S_TMP)}")
+        e(f"s_cselect_b32 {s(S_STEP)}, 64, -64")
         e(f"s_mov_b32 {s(S_CQT)}, {s(S_LQT)}")
         e(f"s_sub_i32 {s(S_TMP)}, {s(S_LEN)}, {s(S_QBEG)}")
-        e(f"s_and_b32 {s(S_TMP)}, {s(S_TMP)}, 63")
+        e(f"s_and_b32 {s(S_TMP)}, {s(S_TMP)}, 63")                                # != 0: the head's last tile is partial
         e(f"s_add_i32 {s(S_TMP + 1)}, {s(S_NH)}, -1")
+        e(f"s_sub_i32 {s(S_TMP + 2)}, {s(S_NIT)}, {s(S_NH)}")
         e(f"s_cmp_eq_u32 {s(S_TMP)}, 0")
-        e(f"s_cselect_b32 {s(S_NS0)}, 1, {s(S_TMP + 1)}")
+        e(f"s_cselect_b32 {s(S_NS0)}, 1, {s(S_TMP + 1)}")                         # down: nheads - 1 when partial
+        e(f"s_cselect_b32 {s(S_NF)}, {s(S_NIT)}, {s(S_TMP + 2)}")                 # up: niter - nheads when partial
+        e(f"s_cmp_lg_u32 %[dirup], 0")
+        e(f"s_cselect_b32 {s(S_NS0)}, 1, {s(S_NS0)}")
+        e(f"s_cselect_b32 {s(S_NF)}, {s(S_NF)}, {s(S_NIT)}")
         e(f"s_max_i32 {s(S_NS0)}, {s(S_NS0)}, 1")
-        e(f"s_add_i32 {s(S_NF)}, {s(S_NIT)}, -1")
+        e(f"s_add_i32 {s(S_NF)}, {s(S_NF)}, -1")
     # steady steps: it >= 1 with a next tile that is whole.  Tiles of a head are whole except its last one when (len - qbegin) % 64 != 0:
     # then no step is steady (the generic form clamps); else every step with a next tile is.
     if not ORDER_TD:

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
     const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dvec,
     const int32_t* __restrict__ cu, int hq, int hkv, float scale, int causal, uint16_t* __restrict__ dk,
     uint16_t* __restrict__ dv, float* __restrict__ dk_part, float* __restrict__ dv_part, int k_blocks, int n_seq, int slot,
-    int xcd_local) {
+    int xcd_local_arg) {
   // ONE __shared__ object (see attn_bwd_dq_kernel): Q[2], dO[2], lse[2][kTile], D[2][kTile], work-item slot
   __shared__ __attribute__((aligned(16))) char smem[4 * kTileB + 4 * kTile * sizeof(float) + 16];
   float (*lse_sm)[kTile] = reinterpret_cast<float (*)[kTile]>(smem + 4 * kTileB);
@@ -355,7 +355,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
 
   // work items: (sequence, kv head) pairs on XCD-local queues; a pair's items = (SPLIT: q head of the group, outer) key blocks,
   // block 0 first -- under the causal mask it is seen by the most queries
-  XcdQueue wq{&g_bwd_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * (SPLIT ? rep : 1), xcc_id(), 0};
+  const int updown = xcd_local_arg >> 4, xcd_local = xcd_local_arg & 15;      // (bit 4: attn_common.h, dkdv_walks_up)
+  XcdQueue wq{&g_bwd_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * (SPLIT ? rep : 1), xcc_id(), 0, updown};
   for (int round = 0;; ++round) {
     int kblock, hsel, seq;
     if (slot < 0 || xcd_local != 1) {
@@ -416,7 +417,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
     // attn_bwd_dkdv64_kernel (tools/gen_attn_bwd_dkdv64.py, order=td) walk the same way: dK / dV are bit-identical across the forms.
     const int first_head = SPLIT ? hsel : kvh * rep, n_heads = SPLIT ? 1 : rep;
     const int q_last = q_begin + (tiles_per_head - 1) * kTile;
-    int ld_qt = q_last, ld_head = first_head;                    // (query tile, head) of the NEXT tile to load
+    const bool up = dkdv_walks_up(kvh, updown, len) != 0;             // odd kv heads walk UPWARD from the item's first query (attn_common.h)
+    const int q_first = up ? q_begin : q_last, q_step = up ? kTile : -kTile;
+    int ld_qt = q_first, ld_head = first_head;                   // (query tile, head) of the NEXT tile to load
     const int ld_part = slice_src_part(lane, wave) * 8;
     auto load_tile = [&](int buf) {
       typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
         if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(lse + o), (lptr_t)(&lse_sm[buf][0]), 4, 0, 0);
         else __builtin_amdgcn_global_load_lds((gptr_t)(dvec + o), (lptr_t)(&d_sm[buf][0]), 4, 0, 0);
       }
-      if (++ld_head == first_head + n_heads) { ld_head = first_head; ld_qt -= kTile; }
+      if (++ld_head == first_head + n_heads) { ld_head = first_head; ld_qt += q_step; }
     };
     load_tile(0);
     __syncthreads();
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
 #ifdef VSEL_TRACE
     bool trace_on = false;
 #endif
-    int qt = q_last, qt_heads = 0;                               // query tile being processed; heads done on it
+    int qt = q_first, qt_heads = 0;                              // query tile being processed; heads done on it
     // one 64-query tile from LDS buffer CUR (compile-time, so that every LDS address is a per-lane base + an immediate)
     auto tile_body = [&](auto cur_c) {
       constexpr int CUR = decltype(cur_c)::value;
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(
           VSEL_BWD_STAMP(3 + 2 * qb);
         }
       }
-      if (++qt_heads == n_heads) { qt_heads = 0; qt -= kTile; }
+      if (++qt_heads == n_heads) { qt_heads = 0; qt += q_step; }
     };
 
     for (int it = 0; it < n_iter; it += 2) {
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
     const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dvec,
     const int32_t* __restrict__ cu, int hq, int hkv, float scale, int causal, uint16_t* __restrict__ dk,
     uint16_t* __restrict__ dv, float* __restrict__ dk_part, float* __restrict__ dv_part, int k_blocks, int n_seq, int slot,
-    int xcd_local, int split_heads) {
+    int xcd_local_arg, int split_heads) {
   constexpr int kKV = 2 * kTileB;                               // one 128-key tile
   __shared__ __attribute__((aligned(16))) char smem[2 * kKV + 4 * kTileB + 4 * kTile * sizeof(float) + 16];
   char* const k_sm = smem;
@@ -634,7 +637,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
 
   // work items: (sequence, kv head) pairs on XCD-local queues; a pair's items = (SPLIT: q head of the group, outer) key blocks,
   // block 0 first -- under the causal mask it is seen by the most queries
-  XcdQueue wq{&g_bwd_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * parts, xcc_id(), 0};
+  const int updown = xcd_local_arg >> 4, xcd_local = xcd_local_arg & 15;
+  XcdQueue wq{&g_bwd_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * parts, xcc_id(), 0, updown};
   for (int round = 0;; ++round) {
     int kblock, hsel, seq;
     if (slot < 0 || xcd_local != 1) {
@@ -692,8 +696,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
     const int q_begin = causal ? k0 : 0;
     const int tiles_per_head = (len - q_begin + kTile - 1) / kTile;
     const int n_iter = tiles_per_head * n_heads;
-    const int q_last = q_begin + (tiles_per_head - 1) * kTile;   // tiles outer from the END downward, heads inner (attn_bwd_dkdv_kernel)
-    int ld_qt = q_last, ld_head = first_head;
+    const int q_last = q_begin + (tiles_per_head - 1) * kTile;   // tiles outer from the END downward (odd kv heads: upward), heads inner (attn_bwd_dkdv_kernel)
+    const bool up = dkdv_walks_up(kvh, updown, len) != 0;
+    const int q_first = up ? q_begin : q_last, q_step = up ? kTile : -kTile;
+    int ld_qt = q_first, ld_head = first_head;
     auto load_tile = [&](int buf) {
       if (ld_qt + kTile <= len) {
         // full tile: a wave-uniform 64-bit row base on the scalar ALU plus the per-lane 32-bit offset computed once per item
@@ -724,7 +730,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
         if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(lse + o), (lptr_t)(&lse_sm[buf][0]), 4, 0, 0);
         else __builtin_amdgcn_global_load_lds((gptr_t)(dvec + o), (lptr_t)(&d_sm[buf][0]), 4, 0, 0);
       }
-      if (++ld_head == first_head + n_heads) { ld_head = first_head; ld_qt -= kTile; }
+      if (++ld_head == first_head + n_heads) { ld_head = first_head; ld_qt += q_step; }
     };
     load_tile(0);
     __syncthreads();
@@ -732,7 +738,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
 #ifdef VSEL_TRACE
     bool trace_on = false;
 #endif
-    int qt = q_last, qt_heads = 0;
+    int qt = q_first, qt_heads = 0;
     auto tile_body = [&](auto cur_c) {
       constexpr int CUR = decltype(cur_c)::value;
       const int qw0 = qt + 32 * qh;                              // first query of the wave's half
@@ -827,7 +833,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(
         }
         VSEL_BWD_STAMP(3);
       }
-      if (++qt_heads == n_heads) { qt_heads = 0; qt -= kTile; }
+      if (++qt_heads == n_heads) { qt_heads = 0; qt += q_step; }
     };
 
     for (int it = 0; it < n_iter; it += 2) {
@@ -1061,7 +1067,9 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
   // (2 = single queue whose counter jumps over runs of empty items: ragged batches, knob attn_skip_empty)
   const int skip_empty = n_seq > 1 && knob(VSEL_KNOB_ATTN_SKIP_EMPTY) != 0 ? 2 : 0;
   const int xcd_local_dq = attn_use_xcd_queues(max_seqlen, n_seq * hkv, 2048, 32) ? 1 : skip_empty;
-  const int xcd_local_dkdv = attn_use_xcd_queues(max_seqlen, n_seq * hkv, 4096, 16) ? 1 : skip_empty;
+  // bit 4: odd kv heads walk their query tiles upward, pairs queued in couples (attn_common.h, dkdv_walks_up; knob attn_bwd_updown)
+  const int xcd_local_dkdv = (attn_use_xcd_queues(max_seqlen, n_seq * hkv, 4096, 16) ? 1 : skip_empty) |
+                             (causal && hkv % 2 == 0 && knob(VSEL_KNOB_ATTN_BWD_UPDOWN) != 0 ? 16 : 0);
   // dQ first: it also leaves D = rowsum(dO * O) and the exp2-domain log-sum-exp in the workspace for the dK / dV kernel
   const int g_dq64 = knob(VSEL_KNOB_ATTN_BWD_DQ64);
   if (g_dq64 == 1 || (g_dq64 < 0 && kDq64FromTokens > 0 && max_seqlen >= kDq64FromTokens)) {

@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v, const uint16_t* __restrict__ dout,
     const float* __restrict__ lse2, const float* __restrict__ dvec, const int32_t* __restrict__ cu, int hq, int hkv, float scale, float sl2,
     int causal, uint16_t* __restrict__ dk, uint16_t* __restrict__ dv, float* __restrict__ dk_part, float* __restrict__ dv_part, int split,
-    int k_blocks, int n_seq, int slot, int xcd_local) {
+    int k_blocks, int n_seq, int slot, int xcd_local_arg) {
+  const int updown = xcd_local_arg >> 4, xcd_local = xcd_local_arg & 15;      // (bit 4: attn_common.h, dkdv_walks_up)
   __shared__ __attribute__((aligned(1024))) char smem[VSEL_DKDV64_LDS_BYTES + 16];
   int& s_item = *reinterpret_cast<int*>(smem + VSEL_DKDV64_LDS_BYTES);
   // split = q heads per item (attn_bwd.hip bwd_split_heads; 0: the whole group inside the item).  1 (few items): item = (key block, Q head,
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
   const int j = lane & 31, hh = lane >> 5;
   const int lds_base = (int)lds_u32(smem);
   const int rep = hq / hkv;
-  XcdQueue wq{&g_dkdv64_work_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * parts, xcc_id(), 0};
+  XcdQueue wq{&g_dkdv64_work_counter[8 * max(slot, 0)], n_seq * hkv, k_blocks * parts, xcc_id(), 0, updown};
   for (int round = 0;; ++round) {
     int kblock, hsel, seq;
     if (slot < 0 || xcd_local != 1) {
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
     const int n_iter = __builtin_amdgcn_readfirstlane(tiles_per_head * n_heads);
     const int head0 = __builtin_amdgcn_readfirstlane(first_head);
     const int nheads_u = __builtin_amdgcn_readfirstlane(n_heads);
+    const int dirup = __builtin_amdgcn_readfirstlane(dkdv_walks_up(kvh, updown, len));
 
     const void* const qbase = uniform_ptr(q + (int64_t)qs * hq * kD);
     const void* const dobase = uniform_ptr(dout + (int64_t)qs * hq * kD);
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(
                  :
                  : [qbase] "s"(qbase), [dobase] "s"(dobase), [lsebase] "s"(lsebase), [dbase] "s"(dbase), [qrs2] "s"(qrs2),
                    [fstride] "s"(fstride), [niter] "s"(n_iter), [qbegin] "s"(qbeg_u), [len] "s"(len_u), [sl2] "s"(sl2), [scale] "s"(scale),
-                   [kw0] "s"(kw0), [causal] "s"(causal), [wave] "s"(wave), [head0] "s"(head0), [nheads] "s"(nheads_u), [ldsbase] "s"(lds_base), [split] "s"(split_u),
+                   [kw0] "s"(kw0), [causal] "s"(causal), [wave] "s"(wave), [head0] "s"(head0), [nheads] "s"(nheads_u), [dirup] "s"(dirup), [ldsbase] "s"(lds_base), [split] "s"(split_u),
                    [kptr] "v"(kptr), [vptr] "v"(vptr), [dkptr] "v"(dkptr), [dvptr] "v"(dvptr), [kvalid] "v"(kvalid)
                  : VSEL_DKDV64_ASM_CLOBBERS);
     __syncthreads();                   // the next item's first loads overwrite ring slots other waves may still read

@@ -52,6 +52,7 @@ constexpr KnobSpec kKnobs[VSEL_KNOB_COUNT] = {
     {"VSEL_ATTN_SKIP_EMPTY", 1, 0, 1},   // VSEL_KNOB_ATTN_SKIP_EMPTY
     {"VSEL_ATTN_GQA", -1, -1, 1},        // VSEL_KNOB_ATTN_GQA
     {"VSEL_ATTN_GQA_FORM", -1, -1, 1},   // VSEL_KNOB_ATTN_GQA_FORM
+    {"VSEL_ATTN_BWD_UPDOWN", 1, 0, 1},   // VSEL_KNOB_ATTN_BWD_UPDOWN
 };
 int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 int knob_default(int id) {

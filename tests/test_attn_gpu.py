@@ -515,6 +515,26 @@ def test_gqa_shared_forward_matches_oracle_and_per_head_forms_bit_for_bit(ops, l
     check(bo.float().cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("lens,hq,hkv", [([31, 32, 33, 64, 65, 1, 127, 300], 28, 4), ([524] * 8, 28, 4), ([793, 210, 17], 32, 8),
+                                         ([900, 5, 700, 64, 1, 333, 2, 450, 800, 120], 28, 4), ([294] * 20, 16, 2)])
+def test_gqa_shared_forward_dealt_and_queued_items_agree(ops, lens, hq, hkv):
+    """More items than workgroups: the group-shared kernels either deal the heaviest-first item list out (workgroup b: items b, 2 G - 1 - b,
+    2 G + b, ...; uniform batches by default, knob attn_static = 1 anywhere) or draw it from the queue behind two dealt rounds (ragged
+    batches, attn_static = 0: a workgroup whose own item is empty starts on its mirror item).  Placement only: every setting of both forms
+    gives the per-head kernels' bits, also when most first-round items are empty."""
+    from visionselector_amd import _native as N
+    q, k, v = make_qkv(sum(lens), hq, hkv, 77 + len(lens))
+    cu = torch.from_numpy(np.concatenate(([0], np.cumsum(lens))).astype(np.int32)).cuda()
+    q, k, v = q.cuda(), k.cuda(), v.cuda()
+    with N.debug_knob(attn_gqa=0, attn_split=0, attn_rows64=0):
+        ref = ops.varlen_attn_fwd_lse(q, k, v, cu, max(lens))
+    for form in (0, 1):
+        for static in (0, 1, -1):
+            with N.debug_knob(attn_gqa=1, attn_gqa_form=form, attn_static=static, attn_split=0, attn_rows64=0):
+                got = ops.varlen_attn_fwd_lse(q, k, v, cu, max(lens))
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (form, static)
+
+
 def test_gqa_shared_forward_rescale_and_lazy_exponent(ops):
     lens = [900, 333, 1500]
     total = sum(lens)

@@ -699,11 +699,12 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   //     the last tile, queue drawn ahead) -- best when a workgroup runs many items (>= 3 rounds of them);
   //   * attn_fwd_gqa64.hip: attn_fwd64's generated loop with two heads per wave (~8 instead of ~18 instructions per MFMA, but every item
   //     pays its own prologue) -- best for few items per workgroup and for groups of <= 4 heads (64-query items).
-  // Same-process A/B (tools/exp_attn_gqa.py, profiles/r05_gqa_ab.txt; us per-head / 8-wave / generated, 28 / 4 heads): 2 x 524 19.9 / 24.8 /
-  // 19.8, 4 x 524 24.3 / 28.4 / 21.6, 8 x 524 43.3 / 42.5 / 45.3, 8 ragged 51.8 / 56.0 / 57.3, 16 x 524 78.6 / 61.1 / 74.3, 32 x 524 146 / 115 /
-  // 131, 32 x 294 72 / 54 / 65, 64 ragged 329 / 278 / 284, 16 x 1100 222 / 193 / 194, 32 x 1216 493 / 452 / 450, 8 x 2000 297 / 278 / 257;
-  // LLaVA-OV 32 / 8 heads 32 x 1230 606 / 517 / 480, 8 x 1230 152 / 130 / 124; 3B 16 / 2 heads 32 x 524 89 / 64 / 75.  One sequence (68
-  // items) stays with the two-stream per-head form (13.5 vs 19 us); from 2048 tokens attn_fwd64 (256-query items: 16 x 4096 1 690 vs 1 990).
+  // Same-process A/B (profiles/r05_gqa_ab.txt, second table; us per-head / 8-wave dealt / generated dealt, 28 / 4 heads): 4 x 524 25.8 / 23.9 /
+  // 21.5, 5 x 524 31.7 / 25.3 / 24.6, 6 x 524 35.3 / 25.2 / 27.1, 8 x 524 43.0 / 32.6 / 36.8, 32 x 524 146 / 110 / 128, 32 x 294 70.5 / 51.3 / 64.7,
+  // 16 x 1100 219 / 188.5 / 186, 32 x 1216 486 / 448 / 443; ragged (queue behind two dealt rounds): 8 prompts 52.1 / 51.2 / 51.2, 64 prompts 325 /
+  // 276 / 288; LLaVA-OV 32 / 8 heads 8 x 1230 148 / 122 / 115, 32 x 1230 589 / 521 / 479; 3B 16 / 2 heads 32 x 524 88 / 59 / 68.  Dealing the
+  // list (mirrored rounds) instead of drawing it an item or two ahead is what moved the few-round grids: 8 x 524 was 44.7 / 44.3 drawn.
+  // One sequence (68 items) stays with the two-stream per-head form (13.5 vs 19 us); from 2048 tokens attn_fwd64 (256-query items).
   const int g_gqa = knob(VSEL_KNOB_ATTN_GQA);
   const int64_t rep_ = hq / hkv;
   if (d == 128 && g_attn_use_tr && !pg.block_table && !pg.seqlens_k && !pg.cu_k && g_attn_nw == 0 && rep_ >= 2 && rep_ <= 8 &&
@@ -715,19 +716,26 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
     const int64_t bq64 = 32 * (4 / ((rep_ + 1) / 2));
     const int64_t items64 = (total > 0 ? std::min(cdiv(total, bq64) + n_seq, cdiv(max_seqlen_q, bq64) * n_seq) : cdiv(max_seqlen_q, bq64) * n_seq) * hkv;
     // which form (-1: none).  The generated loop for groups of <= 4 heads (64-query items), for long-ish sequences (>= 1536 tokens: the tile
-    // loop dominates) and for grids of one or two rounds of items (static deal); the 8-wave form from three rounds of its items; in
-    // between (8 x 524: 544 items) the per-head forms are as fast.
+    // loop dominates) and for grids of one or two rounds of items; the 8-wave form from 1.6 rounds of its items when they are dealt
+    // (uniform batches), from three rounds when they are drawn (ragged ones).
+    const bool uniform = total > 0 && total == n_seq * max_seqlen_q;
     int form = -1;
     if (g_gqa == 1) form = knob(VSEL_KNOB_ATTN_GQA_FORM) == 1 ? 1 : (knob(VSEL_KNOB_ATTN_GQA_FORM) == 0 ? 0 : (rep_ <= 4 ? 1 : 0));
     else if (g_gqa < 0 && max_seqlen_q < 2048 && !split2) {
       if ((rep_ <= 4 || max_seqlen_q >= 1536) && items64 >= 128) form = 1;
-      else if (items8 >= 768) form = 0;
+      else if (items8 >= (uniform ? 400 : 768)) form = 0;       // (dealt: from 1.6 rounds of its items -- 6 x 524 25.5 us against 26.8 / 36.2)
       else if (items64 >= 128 && 20 * items64 <= 36 * 256) form = 1;
       if (form >= 0 && knob(VSEL_KNOB_ATTN_GQA_FORM) >= 0) form = knob(VSEL_KNOB_ATTN_GQA_FORM);
     }
-    if (form >= 0)
-      return (form == 1 ? attn::attn_fwd_gqa64_launch : attn::attn_fwd_gqa_launch)(st, q, k, v, cu_q, n_seq, max_seqlen_q, hq, hkv, scale, causal, out,
-                                                                                   pg, lse);
+    if (form >= 0) {
+      // uniform batches: the item list dealt out with mirrored rounds (the queue's draws run one or two items ahead, i.e. in arrival order
+      // for the first rounds, and every workgroup would keep its level's rank); ragged ones keep the queue, whose counter jumps over empty
+      // runs -- with the second round dealt as well
+      const int g_static = knob(VSEL_KNOB_ATTN_STATIC);
+      const bool deal = g_static == 1 || (g_static < 0 && uniform);
+      return (form == 1 ? attn::attn_fwd_gqa64_launch : attn::attn_fwd_gqa_launch)(st, q, k, v, cu_q, n_seq, max_seqlen_q, hq, hkv, scale, causal,
+                                                                                   out, pg, lse, deal);
+    }
   }
   if (d == 128 && g_attn_use_tr && !pack && !pg.block_table && g_attn_nw == 0 &&
       (g_rows64 == 1 || (g_rows64 < 0 && max_seqlen_q >= 2048 && !split2)))

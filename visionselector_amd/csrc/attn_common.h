@@ -95,11 +95,13 @@ int attn_fwd64_launch(hipStream_t st, const void* q, const void* k, const void* 
 // group-shared forward for short sequences (attn_fwd_gqa.hip): one 8-wave workgroup serves a kv head's whole q-head group on one query
 // tile; contiguous keys of the queries' own sequences only (prefill), head_dim 128, 2 <= hq / hkv <= 8
 int attn_fwd_gqa_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
-                        int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg, float* lse);
+                        int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg, float* lse,
+                        bool deal);      // deal: items dealt out statically (b, 2 G - 1 - b, 2 G + b, ...) instead of drawn from the queue
 
 // ... and on the generated 64-rows-per-wave loop, two heads per wave (attn_fwd_gqa64.hip)
 int attn_fwd_gqa64_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
-                          int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg, float* lse);
+                          int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg, float* lse,
+                          bool deal);
 
 // ---- XCD-local work queues (round 4) ------------------------------------------------------------------------------------------
 // Every attention kernel streams one operand pair (K / V in the forward and the dQ pass, Q / dO in the dK / dV pass) that ALL the

@@ -240,15 +240,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
   };
   // a candidate that is not an item: move the shared counter past the run of empty items it starts (attn_common.h) and draw again.
   // Uniform over the workgroup (cand comes out of LDS); costs two barriers and an atomic round trip per empty candidate.
+  // counter == nullptr: the item list is DEALT, not drawn -- workgroup b takes items b, 2 G - 1 - b, 2 G + b, ... (attn_common.h,
+  // static_deal_item): with every draw two items ahead the queue hands the first three rounds out in arrival order anyway, and without
+  // the mirroring a workgroup that starts on a level's heaviest item keeps the heaviest of every later round (8 x 524: 9 + 5 + 1 tiles
+  // against 5 + 1 on the last workgroup).  Only thread 0 draws: deal_round is its private count.
+  int deal_round = 1;
+  auto draw = [&]() -> int { return counter ? atomicAdd(counter, 1) : static_deal_item(deal_round++); };
   auto validate = [&](int cand) -> GqaItem {
     for (;;) {
       GqaItem it = decode(cand);
       if (it.n_tiles > 0 || cand >= n_items) return it;
       const int level = cand / n_pairs, pair = cand - level * n_pairs;
-      if (pair % hkv == 0)
+      if (counter && pair % hkv == 0)
         queue_skip_empty_run(counter, tid, cu, n_seq, hkv, level, pair / hkv,
                              [&](int lv, int ql) { return (q_tiles - 1 - lv) * kBlockQ < ql; });
-      if (tid == 0) s_slow = atomicAdd(counter, 1);
+      if (tid == 0) s_slow = draw();
       __syncthreads();
       cand = __builtin_amdgcn_readfirstlane(s_slow);
       __syncthreads();
@@ -256,18 +262,22 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
   };
 
   // ---- prologue: the first item is the workgroup's own index, the second is drawn (and waited for) once ----------------------------
-  GqaItem cur = validate((int)blockIdx.x);          // the counter starts at gridDim.x
+  // Rounds 0 and 1 are DEALT in either mode -- items b and 2 G - 1 - b, the mirror (the queue's counter starts at 2 G).  A workgroup whose
+  // own item is empty (ragged batches) starts on its mirror item and takes the second one from the queue.
+  GqaItem cur = decode((int)blockIdx.x);
+  const bool own_empty = counter && cur.n_tiles == 0;
+  cur = validate(own_empty ? static_deal_item(1) : (int)blockIdx.x);
   if (cur.n_tiles == 0) return;
   load_q(cur);
   load_tile(cur, 0, std::integral_constant<int, 0>{});
-  if (tid == 0) s_slow = atomicAdd(counter, 1);
+  if (tid == 0) s_slow = (counter && !own_empty) ? static_deal_item(1) : draw();
   __syncthreads();                                  // (also: the loads above have landed for every wave -- vmcnt(0) in front of it)
   int cand = __builtin_amdgcn_readfirstlane(s_slow);
   __syncthreads();
   GqaItem next = validate(cand);
   GqaItem next2{0, 0, 0, 0, 0, 0};                  // the item after `next`: decoded during the current item's first round
   int pend = 0;                                     // thread 0: the draw for that item, in flight
-  if (tid == 0) pend = atomicAdd(counter, 1);
+  if (tid == 0) pend = draw();
   int ipar = 0;                                     // item parity (slot of s_cand)
   int t = 0;                                        // tile of the current item
 
@@ -583,7 +593,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
     wave_has_rows = next_has_rows;
     my_q = min(wave_qmin + j, cur.qlen - 1);
     next = next2;
-    if (tid == 0) pend = atomicAdd(counter, 1);
+    if (tid == 0) pend = draw();
     GQA_STAMP(7);
     return true;
   };
@@ -595,23 +605,28 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
 
 namespace attn {
 
-// q_tiles = ceil(max_seqlen / (32 * (8 / rep))); counter: one int, set to the grid size by the launcher
+// q_tiles = ceil(max_seqlen / (32 * (8 / rep))); counter: one int, set to twice the grid size by the launcher (nullptr: every round dealt)
 int attn_fwd_gqa_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
-                        int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg, float* lse) {
+                        int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg, float* lse,
+                        bool deal) {
   const int rep = (int)(hq / hkv);
   const int block_q = 32 * (8 / rep);
   const int64_t q_tiles = cdiv(max_seqlen_q, block_q);
   const int64_t n_items = q_tiles * hkv * n_seq;
   if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
-  int slot = -1;                                  // (a counter slot per launch: common.h, queue_slot_acquire)
-  if (int rc = queue_slot_acquire(kSlotGqa, st, &slot)) return rc;
-  int* counters = nullptr;
-  VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_gqa_work_counter)));
   const int grid = (int)std::min<int64_t>(n_items, 256);                      // 128 KiB of LDS: one workgroup per CU
-  VSEL_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(counters + slot), grid, 1, st));
+  int* counter = nullptr;                         // deal: no counter (the kernel deals the list out: items b, 2 G - 1 - b, ...)
+  int slot = -1;                                  // (a counter slot per launch: common.h, queue_slot_acquire)
+  if (!deal) {
+    if (int rc = queue_slot_acquire(kSlotGqa, st, &slot)) return rc;
+    int* counters = nullptr;
+    VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_gqa_work_counter)));
+    VSEL_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(counters + slot), 2 * grid, 1, st));     // (two rounds are dealt: items b and 2 G - 1 - b)
+    counter = counters + slot;
+  }
   hipLaunchKernelGGL(attn_fwd_gqa_kernel, dim3(grid), dim3(512), 0, st, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, cu_q,
-                     (int)hq, (int)hkv, scale * 1.4426950408889634f, causal, (uint16_t*)out, (int)q_tiles, (int)n_seq, counters + slot, pg, lse);
-  queue_slot_launched(kSlotGqa, slot, st);
+                     (int)hq, (int)hkv, scale * 1.4426950408889634f, causal, (uint16_t*)out, (int)q_tiles, (int)n_seq, counter, pg, lse);
+  if (!deal) queue_slot_launched(kSlotGqa, slot, st);
   VSEL_AFTER_LAUNCH(st, "attn_fwd_gqa_kernel");
   return VSEL_OK;
 }

@@ -136,20 +136,30 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_gqa64_kernel(const uint16_t* 
       if (it.n_tiles > 0 || it_idx >= n_items) return it;
     }
   };
-  Gqa64Item cur = validate((int)blockIdx.x);        // (the counter starts at gridDim.x)
+  Gqa64Item cur = decode((int)blockIdx.x);
   Gqa64Item next{0, 0, 0, 0, 0, 0};
   if (static_deal) {
     if (cur.n_tiles == 0) cur = deal_next();
     if (cur.n_tiles == 0) return;
     next = deal_next();
+  } else if (counter) {
+    // the second item is dealt too (2 G - 1 - b, the mirror of the first round; the counter starts at 2 G): with every draw an item ahead the
+    // queue would hand the second round out in arrival order, and the workgroup on a level's heaviest item would get the next level's heaviest.
+    // An EMPTY first item (ragged batches) hands its slot to the dealt one; the queue then supplies the second.
+    const bool first_empty = cur.n_tiles == 0;
+    if (first_empty) cur = validate(static_deal_item(1));
+    if (cur.n_tiles == 0) return;
+    if (first_empty) {
+      if (tid == 0) s_item = atomicAdd(counter, 1);
+      __syncthreads();
+      const int cand = __builtin_amdgcn_readfirstlane(s_item);
+      __syncthreads();
+      next = validate(cand);
+    } else {
+      next = validate(static_deal_item(1));
+    }
   } else if (cur.n_tiles == 0) {
     return;
-  } else if (counter) {
-    if (tid == 0) s_item = atomicAdd(counter, 1);
-    __syncthreads();
-    const int cand = __builtin_amdgcn_readfirstlane(s_item);
-    __syncthreads();
-    next = validate(cand);
   }
   int pref = 0;                                     // what the previous body already loaded of `cur`: bit 0 Q fragments + K(0) + K(1), bit 1 V(0)
   for (;;) {
@@ -229,7 +239,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_gqa64_kernel(const uint16_t* 
 namespace attn {
 
 int attn_fwd_gqa64_launch(hipStream_t st, const void* q, const void* k, const void* v, const int32_t* cu_q, int64_t n_seq,
-                          int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg, float* lse) {
+                          int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg, float* lse,
+                          bool deal) {
   const int rep = (int)(hq / hkv);
   const int block_q = 32 * (4 / ((rep + 1) / 2));
   const int q_tiles = (int)cdiv(max_seqlen_q, block_q);
@@ -238,13 +249,13 @@ int attn_fwd_gqa64_launch(hipStream_t st, const void* q, const void* k, const vo
   const int grid = (int)std::min<int64_t>(n_items, 256);
   int taken = -1;
   int* counter = nullptr;                          // one item per workgroup: no queue
-  const int static_deal = attn_static_deal(n_items, 256, true, 36) ? 1 : 0;
+  const int static_deal = (deal || attn_static_deal(n_items, 256, true, 36)) ? 1 : 0;     // (deal: uniform batches, any number of rounds)
   if (n_items > grid && !static_deal) {
     if (int rc = queue_slot_acquire(kSlotGqa, st, &taken)) return rc;
     int* counters = nullptr;
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_gqa64_work_counter)));
     counter = counters + 8 * taken;
-    VSEL_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)counter, grid, 1, st));     // workgroup b starts with item b
+    VSEL_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)counter, 2 * grid, 1, st));     // workgroup b starts with items b and 2 G - 1 - b
   }
   hipLaunchKernelGGL(attn_fwd_gqa64_kernel, dim3(grid), dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, cu_q,
                      (int)hq, (int)hkv, scale * 1.4426950408889634f, causal, (uint16_t*)out, q_tiles, (int)n_seq, counter, static_deal, pg, lse);

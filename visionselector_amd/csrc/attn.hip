@@ -722,7 +722,7 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
     int form = -1;
     if (g_gqa == 1) form = knob(VSEL_KNOB_ATTN_GQA_FORM) == 1 ? 1 : (knob(VSEL_KNOB_ATTN_GQA_FORM) == 0 ? 0 : (rep_ <= 4 ? 1 : 0));
     else if (g_gqa < 0 && max_seqlen_q < 2048 && !split2) {
-      if ((rep_ <= 4 || max_seqlen_q >= 1536) && items64 >= 128) form = 1;
+      if ((rep_ <= 4 || max_seqlen_q >= (uniform ? 1024 : 1536)) && items64 >= 128) form = 1;     // (dealt: 16 x 1100 182 vs 189 us, 32 x 1216 430 vs 448)
       else if (items8 >= (uniform ? 400 : 768)) form = 0;       // (dealt: from 1.6 rounds of its items -- 6 x 524 25.5 us against 26.8 / 36.2)
       else if (items64 >= 128 && 20 * items64 <= 36 * 256) form = 1;
       if (form >= 0 && knob(VSEL_KNOB_ATTN_GQA_FORM) >= 0) form = knob(VSEL_KNOB_ATTN_GQA_FORM);

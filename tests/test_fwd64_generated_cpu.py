@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GEN = os.path.join(ROOT, "tools", "gen_attn_fwd64.py")
 INC = os.path.join(ROOT, "visionselector_amd", "csrc", "attn_fwd64_body.inc")
-HEADS_OPTS = "heads=1,xitem=1"          # options of the committed csrc/attn_fwd_gqa64_body.inc
+HEADS_OPTS = "heads=1,xitem=1,epi=1,qearly=1"          # options of the committed csrc/attn_fwd_gqa64_body.inc
 
 
 def _gen(tmp_path, opts=""):

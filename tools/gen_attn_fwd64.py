@@ -444,6 +444,14 @@ OPT = {
                           # and V(0) (%[nxv]) are loaded in the gaps of this item's last tile (whole tiles and 32 whole rows only: the
                           # caller clears the bits otherwise), its Q fragments read before the epilogue; bit 2: block B has a head
                           # (replaces %[nvalidb]).  The output tile leaves through the wave's own Q staging area (no barrier).
+    "qearly": 0,          # 1 (with xitem): the next item's 16 Q slices are issued at the TOP of the item's last step, in front of its softmax
+                          # arithmetic (the epilogue waits for them first thing: issued in the P V gaps they had ~300 cycles of lead on a
+                          # ~3 000-cycle round trip); K(0) / K(1) / V(0) stay in the P V gaps and the epilogue waits for the Q slices only.
+                          # (A step earlier still -- top of the second-to-last step -- was slower: 123.0 vs 114.1 us at 32 x 524, the
+                          # slices then sit in front of that step's vmcnt(0) + barrier and their issue is not under any MFMA.)
+    "epi": 0,             # 1: epilogue with packed multiplies (v_pk_mul_f32: half the normalisation instructions, the same IEEE products) and block
+                          # A's rows read back and stored while block B is still being converted (the LDS round trip and the store issue of
+                          # one block under the VALU work of the other); the next item's Q fragments are waited for after the 1 / l arithmetic
 }
 for kv in os.environ.get("F64_OPTS", "").replace(";", ",").split(","):
     if "=" in kv:
@@ -723,6 +731,11 @@ def gen_step(g, idx, period):
     # ---------------- the wave's last tile: nothing to overlap with ----------------
     def last_tile(tagx, pieces):
         g.out = list(seed)                                   # (K fragments read ahead for a step that does not come: never used)
+        if pieces and OPT["qearly"]:
+            for pre, ld, post in pieces[:16]:
+                for ins in pre + ["s_nop 0", ld] + post:
+                    g.e(ins)
+            pieces = pieces[16:]
         for ins in finish_a(sc)[OPT["early"]:] + finish_chunk(sc, 1, 0, True) + finish_chunk(sc, 1, 1, False) + \
                 [f"v_add_f32 {v(V_L + 1)}, {v(V_L + 1)}, {v(V_PS + 1)}"]:
             g.e(ins)
@@ -782,6 +795,131 @@ def gen_step(g, idx, period):
     g.e(f"s_cbranch_scc0 {g.lref('Lepi')}")
     if idx == period - 1:
         g.e(f"s_branch {g.lref('Lstepp0')}")
+
+
+def epilogue_pipelined(g, xitem):
+    """option epi=1 (see OPT): the epilogue of the item, same values and same stores as the plain form"""
+    e = g.e
+    e("s_nop 15")
+    T0, T1, X, D0, R, N, E1, Q_ = [V_T + i for i in range(8)]
+    if xitem:
+        # the next item's Q rows have landed in this wave's staging area (its own loads): fragments into a[128:191]; waited for below
+        e(f"s_bitcmp1_b32 %[flags], 3")
+        e(f"s_cbranch_scc0 {g.lref('Lnoqn')}")
+        e(f"s_waitcnt vmcnt({8 if OPT['qearly'] else 0})")           # (qearly: the 16 Q slices are the oldest loads; 8 K + 4 masked V behind them)
+        q_frag_reads(g)
+        g.out = []                                                   # (drained by the s_waitcnt lgkmcnt(0) in front of the first ds_write)
+        g.label("Lnoqn")
+    else:
+        e("s_barrier")
+    # 1 / l of both blocks, each in the LOW register of an even-aligned pair (the packed multiply takes it for both halves)
+    INVP = [V_U + 1, V_T + 4]
+    assert INVP[0] % 2 == 0 and INVP[1] % 2 == 0
+    SAVE = [V_U + 2, V_U]                                            # (the T registers are the division's temporaries: results parked here)
+    for b in range(2):
+        e(f"v_mov_b32 {v(T0)}, {v(V_L + b)}")
+        e(f"v_mov_b32 {v(T1)}, {v(V_L + b)}")
+        e("s_nop 1")
+        e(f"v_permlane32_swap_b32 {v(T0)}, {v(T1)}")
+        e(f"v_add_f32 {v(X)}, {v(T0)}, {v(T1)}")
+        e(f"v_div_scale_f32 {v(D0)}, {sr(S_TMP)}, {v(X)}, {v(X)}, 1.0")
+        e(f"v_rcp_f32 {v(R)}, {v(D0)}")
+        e(f"v_div_scale_f32 {v(N)}, vcc, 1.0, {v(X)}, 1.0")
+        e("s_nop 0")
+        e(f"v_fma_f32 {v(E1)}, -{v(D0)}, {v(R)}, 1.0")
+        e(f"v_fmac_f32 {v(R)}, {v(E1)}, {v(R)}")
+        e(f"v_mul_f32 {v(Q_)}, {v(N)}, {v(R)}")
+        e(f"v_fma_f32 {v(E1)}, -{v(D0)}, {v(Q_)}, {v(N)}")
+        e(f"v_fmac_f32 {v(Q_)}, {v(E1)}, {v(R)}")
+        e(f"v_fma_f32 {v(D0)}, -{v(D0)}, {v(Q_)}, {v(N)}")
+        e(f"v_div_fmas_f32 {v(D0)}, {v(D0)}, {v(R)}, {v(Q_)}")
+        e(f"v_div_fixup_f32 {v(SAVE[b])}, {v(D0)}, {v(X)}, 1.0")
+        e(f"v_cmp_lt_f32 vcc, 0, {v(X)}")
+        e(f"v_cndmask_b32 {v(SAVE[b])}, 0, {v(SAVE[b])}, vcc")
+    e(f"v_mov_b32 {v(INVP[0])}, {v(SAVE[0])}")
+    e(f"v_mov_b32 {v(INVP[1])}, {v(SAVE[1])}")
+    WA, RD, AD = V_T, V_T + 1, V_T + 2
+    if xitem:
+        e(f"s_mov_b32 {s(S_TMP)}, {s(S_QST)}")
+    else:
+        e(f"s_lshl_b32 {s(S_TMP)}, %[wave], 14")
+        e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, {s(S_RING)}")
+    e(f"v_and_b32 {v(WA)}, 31, {v(V_LANE)}")
+    e(f"v_lshlrev_b32 {v(WA)}, 8, {v(WA)}")
+    e(f"v_add_u32 {v(WA)}, {v(WA)}, {v(V_HH8)}")
+    e(f"v_and_b32 {v(AD)}, 15, {v(V_LANE)}")
+    e(f"v_lshlrev_b32 {v(AD)}, 4, {v(AD)}")
+    e(f"v_xor_b32 {v(WA)}, {v(WA)}, {v(AD)}")
+    e(f"v_add_u32 {v(WA)}, {s(S_TMP)}, {v(WA)}")
+    e(f"v_lshlrev_b32 {v(RD)}, 4, {v(V_LANE)}")
+    e(f"v_add_u32 {v(RD)}, {s(S_TMP)}, {v(RD)}")
+    # global offsets of the four row phases: (lane >> 4) * row stride + 16 * ((lane & 15) ^ (4 k + (lane >> 4)))
+    VO = [V_KR, V_KR + 1, V_MX, V_MX + 1]
+    WB = V_T + 3
+    e(f"v_and_b32 {v(AD)}, 15, {v(V_LANE)}")
+    e(f"v_mul_lo_u32 {v(WB)}, {v(V_LANE4)}, %[ostride]")
+    for k in range(4):
+        e(f"v_add_u32 {v(VO[k])}, {4 * k}, {v(V_LANE4)}")
+        e(f"v_xor_b32 {v(VO[k])}, {v(VO[k])}, {v(AD)}")
+        e(f"v_lshl_add_u32 {v(VO[k])}, {v(VO[k])}, 4, {v(WB)}")
+    e(f"s_mov_b64 {sr(S_TMP)}, %[obase]")
+    e(f"s_lshl_b32 {s(S_TMP2)}, %[ostride], 2")
+    e(f"s_mov_b32 {s(S_TMP2 + 1)}, %[nvalid]")
+    tmp = [V_U + 3 + i for i in range(4)]
+    assert tmp[0] % 2 == 0 and tmp[3] <= LAST_V
+    e("s_waitcnt lgkmcnt(0)")                                        # (the next item's Q fragments: the staging area is free now)
+
+    def convert(b, dt, g4):
+        base = A_O + 64 * b + 16 * dt + 4 * g4
+        for i in range(4):
+            e(f"v_accvgpr_read_b32 {v(tmp[i])}, {a(base + i)}")
+        e(f"v_pk_mul_f32 {vr(tmp[0], 2)}, {vr(tmp[0], 2)}, {vr(INVP[b], 2)} op_sel_hi:[1,0]")
+        e(f"v_pk_mul_f32 {vr(tmp[2], 2)}, {vr(tmp[2], 2)}, {vr(INVP[b], 2)} op_sel_hi:[1,0]")
+        e(f"v_cvt_pk_bf16_f32 {v(tmp[0])}, {v(tmp[0])}, {v(tmp[1])}")
+        e(f"v_cvt_pk_bf16_f32 {v(tmp[1])}, {v(tmp[2])}, {v(tmp[3])}")
+        e(f"v_xor_b32 {v(AD)}, {(4 * dt + g4) << 4}, {v(WA)}")
+        e(f"ds_write_b64 {v(AD)}, {vr(tmp[0], 2)} offset:{8192 * b}")
+
+    def store(i):
+        if OPT["heads"] and i == 8:                                 # block B: the second head's rows (none when there is no second head)
+            e(f"s_mov_b64 {sr(S_TMP)}, %[obase]")
+            e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, %[ohs2]")
+            e(f"s_addc_u32 {s(S_TMP + 1)}, {s(S_TMP + 1)}, 0")
+            if OPT["xitem"]:
+                e(f"s_bitcmp1_b32 %[flags], 2")
+                e(f"s_cselect_b32 {s(S_TMP2 + 1)}, %[nvalid], 0")
+            else:
+                e(f"s_mov_b32 {s(S_TMP2 + 1)}, %[nvalidb]")
+        e(f"v_cmp_gt_i32 vcc, {s(S_TMP2 + 1)}, {v(V_LANE4)}")        # row 4 i + (lane >> 4) of this wave exists
+        e("s_mov_b64 exec, vcc")
+        e(f"global_store_dwordx4 {v(VO[i % 4])}, {vr(V_SA + 4 * i, 4)}, {sr(S_TMP)}")
+        e(f"s_mov_b64 exec, {sr(S_EXEC)}")
+        e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, {s(S_TMP2)}")
+        e(f"s_addc_u32 {s(S_TMP + 1)}, {s(S_TMP + 1)}, 0")
+        e(f"s_add_i32 {s(S_TMP2 + 1)}, {s(S_TMP2 + 1)}, -4")
+
+    # block A converted and written; its eight row groups read back; block B converted with block A's stores between the groups
+    for dt in range(4):
+        for g4 in range(4):
+            convert(0, dt, g4)
+    e("s_waitcnt lgkmcnt(0)")
+    for i in range(8):
+        e(f"ds_read_b128 {vr(V_SA + 4 * i, 4)}, {v(RD)} offset:{1024 * i}")
+    n = 0
+    for dt in range(4):
+        for g4 in range(4):
+            convert(1, dt, g4)                                       # (one more LDS operation behind the reads: they return in order)
+            n += 1
+            if n % 2 == 0:
+                i = n // 2 - 1                                       # reads 0 .. i have landed when at most (7 - i) reads + n writes are outstanding
+                e(f"s_waitcnt lgkmcnt({min(13, 7 - i + n)})")     # (capped: never more than 15 LDS operations outstanding)
+                store(i)
+    e("s_waitcnt lgkmcnt(0)")
+    for i in range(8, 16):
+        e(f"ds_read_b128 {vr(V_SA + 4 * i, 4)}, {v(RD)} offset:{1024 * i}")
+    for i in range(8, 16):
+        e(f"s_waitcnt lgkmcnt({15 - i})")
+        store(i)
 
 
 def gen_body():
@@ -1037,107 +1175,110 @@ def gen_body():
     # c ^ (r & 15) (conflict-free for the 16 lanes of a group), read back as whole rows (ds_read_b128, 4 rows per instruction) and
     # stored as 16 x 1 KiB of whole 256-byte rows.
     g.label("Lepi")
-    e("s_nop 15")
-    if xitem:
-        # the next item's Q rows have landed in this wave's staging area (its own loads): fragments into a[128:191] -- the current item's are
-        # dead since its last S -- and the area is free for the output tile.  Wave-private: no barrier.
-        e(f"s_bitcmp1_b32 %[flags], 3")
-        e(f"s_cbranch_scc0 {g.lref('Lnoqn')}")
-        e("s_waitcnt vmcnt(0)")
-        q_frag_reads(g)
-        g.drain()
-        g.label("Lnoqn")
+    if OPT["epi"]:
+        epilogue_pipelined(g, xitem)
     else:
-        e("s_barrier")
-    T0, T1, X, D0, R, N, E1, Q_ = [V_T + i for i in range(8)]
-    INV = [V_U, V_U + 1]
-    for b in range(2):
-        e(f"v_mov_b32 {v(T0)}, {v(V_L + b)}")
-        e(f"v_mov_b32 {v(T1)}, {v(V_L + b)}")
-        e("s_nop 1")
-        e(f"v_permlane32_swap_b32 {v(T0)}, {v(T1)}")
-        e(f"v_add_f32 {v(X)}, {v(T0)}, {v(T1)}")
-        # 1.0f / x exactly as hipcc expands it (v_div_scale / v_rcp / Newton / v_div_fmas / v_div_fixup)
-        e(f"v_div_scale_f32 {v(D0)}, {sr(S_TMP)}, {v(X)}, {v(X)}, 1.0")
-        e(f"v_rcp_f32 {v(R)}, {v(D0)}")
-        e(f"v_div_scale_f32 {v(N)}, vcc, 1.0, {v(X)}, 1.0")
-        e("s_nop 0")
-        e(f"v_fma_f32 {v(E1)}, -{v(D0)}, {v(R)}, 1.0")
-        e(f"v_fmac_f32 {v(R)}, {v(E1)}, {v(R)}")
-        e(f"v_mul_f32 {v(Q_)}, {v(N)}, {v(R)}")
-        e(f"v_fma_f32 {v(E1)}, -{v(D0)}, {v(Q_)}, {v(N)}")
-        e(f"v_fmac_f32 {v(Q_)}, {v(E1)}, {v(R)}")
-        e(f"v_fma_f32 {v(D0)}, -{v(D0)}, {v(Q_)}, {v(N)}")
-        e(f"v_div_fmas_f32 {v(D0)}, {v(D0)}, {v(R)}, {v(Q_)}")
-        e(f"v_div_fixup_f32 {v(INV[b])}, {v(D0)}, {v(X)}, 1.0")
-        e(f"v_cmp_lt_f32 vcc, 0, {v(X)}")
-        e(f"v_cndmask_b32 {v(INV[b])}, 0, {v(INV[b])}, vcc")
-    # this wave's 16 KiB of LDS: base + wave * 16384 (base is a multiple of 1024: the XOR below commutes with the add)
-    WA, RD, AD = V_T, V_T + 1, V_T + 2
-    if xitem:
-        e(f"s_mov_b32 {s(S_TMP)}, {s(S_QST)}")                  # (1 KiB-aligned like the ring: the XOR below commutes with the add)
-    else:
-        e(f"s_lshl_b32 {s(S_TMP)}, %[wave], 14")
-        e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, {s(S_RING)}")
-    e(f"v_and_b32 {v(WA)}, 31, {v(V_LANE)}")
-    e(f"v_lshlrev_b32 {v(WA)}, 8, {v(WA)}")                         # row * 256
-    e(f"v_add_u32 {v(WA)}, {v(WA)}, {v(V_HH8)}")                     # + 8 hh
-    e(f"v_and_b32 {v(AD)}, 15, {v(V_LANE)}")
-    e(f"v_lshlrev_b32 {v(AD)}, 4, {v(AD)}")                          # (row & 15) << 4
-    e(f"v_xor_b32 {v(WA)}, {v(WA)}, {v(AD)}")
-    e(f"v_add_u32 {v(WA)}, {s(S_TMP)}, {v(WA)}")
-    e(f"v_lshlrev_b32 {v(RD)}, 4, {v(V_LANE)}")
-    e(f"v_add_u32 {v(RD)}, {s(S_TMP)}, {v(RD)}")
-    tmp = [V_U + 3 + i for i in range(4)]                         # (64-bit VGPR operands must start at an even register)
-    assert tmp[0] % 2 == 0 and tmp[3] <= LAST_V
-    for b in range(2):
-        for dt in range(4):
-            for g4 in range(4):
-                base = A_O + 64 * b + 16 * dt + 4 * g4
-                for i in range(4):
-                    e(f"v_accvgpr_read_b32 {v(tmp[i])}, {a(base + i)}")
-                for i in range(4):
-                    e(f"v_mul_f32 {v(tmp[i])}, {v(tmp[i])}, {v(INV[b])}")
-                e(f"v_cvt_pk_bf16_f32 {v(tmp[0])}, {v(tmp[0])}, {v(tmp[1])}")
-                e(f"v_cvt_pk_bf16_f32 {v(tmp[1])}, {v(tmp[2])}, {v(tmp[3])}")
-                e(f"v_xor_b32 {v(AD)}, {(4 * dt + g4) << 4}, {v(WA)}")
-                e(f"ds_write_b64 {v(AD)}, {vr(tmp[0], 2)} offset:{8192 * b}")
-    e("s_waitcnt lgkmcnt(0)")
-    # global offsets of the four row phases: (lane >> 4) * row stride + 16 * ((lane & 15) ^ (4 k + (lane >> 4)))
-    VO = [V_KR, V_KR + 1, V_MX, V_MX + 1]
-    e(f"v_and_b32 {v(AD)}, 15, {v(V_LANE)}")
-    e(f"v_mul_lo_u32 {v(WA)}, {v(V_LANE4)}, %[ostride]")
-    for k in range(4):
-        e(f"v_add_u32 {v(VO[k])}, {4 * k}, {v(V_LANE4)}")
-        e(f"v_xor_b32 {v(VO[k])}, {v(VO[k])}, {v(AD)}")
-        e(f"v_lshl_add_u32 {v(VO[k])}, {v(VO[k])}, 4, {v(WA)}")
-    e(f"s_mov_b64 {sr(S_TMP)}, %[obase]")
-    e(f"s_lshl_b32 {s(S_TMP2)}, %[ostride], 2")
-    e(f"s_mov_b32 {s(S_TMP2 + 1)}, %[nvalid]")
-    for i in range(12):
-        e(f"ds_read_b128 {vr(V_SA + 4 * i, 4)}, {v(RD)} offset:{1024 * i}")
-    e("s_waitcnt lgkmcnt(8)")                                  # (lgkmcnt counts at most 15 outstanding operations)
-    for i in range(12, 16):
-        e(f"ds_read_b128 {vr(V_SA + 4 * i, 4)}, {v(RD)} offset:{1024 * i}")
-    for i in range(16):
-        if i >= 4:
-            e(f"s_waitcnt lgkmcnt({15 - i})")
-        if OPT["heads"] and i == 8:                                 # block B: the second head's rows (none when there is no second head)
-            e(f"s_mov_b64 {sr(S_TMP)}, %[obase]")
-            e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, %[ohs2]")
+        e("s_nop 15")
+        if xitem:
+            # the next item's Q rows have landed in this wave's staging area (its own loads): fragments into a[128:191] -- the current item's are
+            # dead since its last S -- and the area is free for the output tile.  Wave-private: no barrier.
+            e(f"s_bitcmp1_b32 %[flags], 3")
+            e(f"s_cbranch_scc0 {g.lref('Lnoqn')}")
+            e(f"s_waitcnt vmcnt({8 if OPT['qearly'] else 0})")
+            q_frag_reads(g)
+            g.drain()
+            g.label("Lnoqn")
+        else:
+            e("s_barrier")
+        T0, T1, X, D0, R, N, E1, Q_ = [V_T + i for i in range(8)]
+        INV = [V_U, V_U + 1]
+        for b in range(2):
+            e(f"v_mov_b32 {v(T0)}, {v(V_L + b)}")
+            e(f"v_mov_b32 {v(T1)}, {v(V_L + b)}")
+            e("s_nop 1")
+            e(f"v_permlane32_swap_b32 {v(T0)}, {v(T1)}")
+            e(f"v_add_f32 {v(X)}, {v(T0)}, {v(T1)}")
+            # 1.0f / x exactly as hipcc expands it (v_div_scale / v_rcp / Newton / v_div_fmas / v_div_fixup)
+            e(f"v_div_scale_f32 {v(D0)}, {sr(S_TMP)}, {v(X)}, {v(X)}, 1.0")
+            e(f"v_rcp_f32 {v(R)}, {v(D0)}")
+            e(f"v_div_scale_f32 {v(N)}, vcc, 1.0, {v(X)}, 1.0")
+            e("s_nop 0")
+            e(f"v_fma_f32 {v(E1)}, -{v(D0)}, {v(R)}, 1.0")
+            e(f"v_fmac_f32 {v(R)}, {v(E1)}, {v(R)}")
+            e(f"v_mul_f32 {v(Q_)}, {v(N)}, {v(R)}")
+            e(f"v_fma_f32 {v(E1)}, -{v(D0)}, {v(Q_)}, {v(N)}")
+            e(f"v_fmac_f32 {v(Q_)}, {v(E1)}, {v(R)}")
+            e(f"v_fma_f32 {v(D0)}, -{v(D0)}, {v(Q_)}, {v(N)}")
+            e(f"v_div_fmas_f32 {v(D0)}, {v(D0)}, {v(R)}, {v(Q_)}")
+            e(f"v_div_fixup_f32 {v(INV[b])}, {v(D0)}, {v(X)}, 1.0")
+            e(f"v_cmp_lt_f32 vcc, 0, {v(X)}")
+            e(f"v_cndmask_b32 {v(INV[b])}, 0, {v(INV[b])}, vcc")
+        # this wave's 16 KiB of LDS: base + wave * 16384 (base is a multiple of 1024: the XOR below commutes with the add)
+        WA, RD, AD = V_T, V_T + 1, V_T + 2
+        if xitem:
+            e(f"s_mov_b32 {s(S_TMP)}, {s(S_QST)}")                  # (1 KiB-aligned like the ring: the XOR below commutes with the add)
+        else:
+            e(f"s_lshl_b32 {s(S_TMP)}, %[wave], 14")
+            e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, {s(S_RING)}")
+        e(f"v_and_b32 {v(WA)}, 31, {v(V_LANE)}")
+        e(f"v_lshlrev_b32 {v(WA)}, 8, {v(WA)}")                         # row * 256
+        e(f"v_add_u32 {v(WA)}, {v(WA)}, {v(V_HH8)}")                     # + 8 hh
+        e(f"v_and_b32 {v(AD)}, 15, {v(V_LANE)}")
+        e(f"v_lshlrev_b32 {v(AD)}, 4, {v(AD)}")                          # (row & 15) << 4
+        e(f"v_xor_b32 {v(WA)}, {v(WA)}, {v(AD)}")
+        e(f"v_add_u32 {v(WA)}, {s(S_TMP)}, {v(WA)}")
+        e(f"v_lshlrev_b32 {v(RD)}, 4, {v(V_LANE)}")
+        e(f"v_add_u32 {v(RD)}, {s(S_TMP)}, {v(RD)}")
+        tmp = [V_U + 3 + i for i in range(4)]                         # (64-bit VGPR operands must start at an even register)
+        assert tmp[0] % 2 == 0 and tmp[3] <= LAST_V
+        for b in range(2):
+            for dt in range(4):
+                for g4 in range(4):
+                    base = A_O + 64 * b + 16 * dt + 4 * g4
+                    for i in range(4):
+                        e(f"v_accvgpr_read_b32 {v(tmp[i])}, {a(base + i)}")
+                    for i in range(4):
+                        e(f"v_mul_f32 {v(tmp[i])}, {v(tmp[i])}, {v(INV[b])}")
+                    e(f"v_cvt_pk_bf16_f32 {v(tmp[0])}, {v(tmp[0])}, {v(tmp[1])}")
+                    e(f"v_cvt_pk_bf16_f32 {v(tmp[1])}, {v(tmp[2])}, {v(tmp[3])}")
+                    e(f"v_xor_b32 {v(AD)}, {(4 * dt + g4) << 4}, {v(WA)}")
+                    e(f"ds_write_b64 {v(AD)}, {vr(tmp[0], 2)} offset:{8192 * b}")
+        e("s_waitcnt lgkmcnt(0)")
+        # global offsets of the four row phases: (lane >> 4) * row stride + 16 * ((lane & 15) ^ (4 k + (lane >> 4)))
+        VO = [V_KR, V_KR + 1, V_MX, V_MX + 1]
+        e(f"v_and_b32 {v(AD)}, 15, {v(V_LANE)}")
+        e(f"v_mul_lo_u32 {v(WA)}, {v(V_LANE4)}, %[ostride]")
+        for k in range(4):
+            e(f"v_add_u32 {v(VO[k])}, {4 * k}, {v(V_LANE4)}")
+            e(f"v_xor_b32 {v(VO[k])}, {v(VO[k])}, {v(AD)}")
+            e(f"v_lshl_add_u32 {v(VO[k])}, {v(VO[k])}, 4, {v(WA)}")
+        e(f"s_mov_b64 {sr(S_TMP)}, %[obase]")
+        e(f"s_lshl_b32 {s(S_TMP2)}, %[ostride], 2")
+        e(f"s_mov_b32 {s(S_TMP2 + 1)}, %[nvalid]")
+        for i in range(12):
+            e(f"ds_read_b128 {vr(V_SA + 4 * i, 4)}, {v(RD)} offset:{1024 * i}")
+        e("s_waitcnt lgkmcnt(8)")                                  # (lgkmcnt counts at most 15 outstanding operations)
+        for i in range(12, 16):
+            e(f"ds_read_b128 {vr(V_SA + 4 * i, 4)}, {v(RD)} offset:{1024 * i}")
+        for i in range(16):
+            if i >= 4:
+                e(f"s_waitcnt lgkmcnt({15 - i})")
+            if OPT["heads"] and i == 8:                                 # block B: the second head's rows (none when there is no second head)
+                e(f"s_mov_b64 {sr(S_TMP)}, %[obase]")
+                e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, %[ohs2]")
+                e(f"s_addc_u32 {s(S_TMP + 1)}, {s(S_TMP + 1)}, 0")
+                if OPT["xitem"]:
+                    e(f"s_bitcmp1_b32 %[flags], 2")
+                    e(f"s_cselect_b32 {s(S_TMP2 + 1)}, %[nvalid], 0")
+                else:
+                    e(f"s_mov_b32 {s(S_TMP2 + 1)}, %[nvalidb]")
+            e(f"v_cmp_gt_i32 vcc, {s(S_TMP2 + 1)}, {v(V_LANE4)}")        # row 4 i + (lane >> 4) of this wave exists
+            e("s_mov_b64 exec, vcc")
+            e(f"global_store_dwordx4 {v(VO[i % 4])}, {vr(V_SA + 4 * i, 4)}, {sr(S_TMP)}")
+            e(f"s_mov_b64 exec, {sr(S_EXEC)}")
+            e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, {s(S_TMP2)}")
             e(f"s_addc_u32 {s(S_TMP + 1)}, {s(S_TMP + 1)}, 0")
-            if OPT["xitem"]:
-                e(f"s_bitcmp1_b32 %[flags], 2")
-                e(f"s_cselect_b32 {s(S_TMP2 + 1)}, %[nvalid], 0")
-            else:
-                e(f"s_mov_b32 {s(S_TMP2 + 1)}, %[nvalidb]")
-        e(f"v_cmp_gt_i32 vcc, {s(S_TMP2 + 1)}, {v(V_LANE4)}")        # row 4 i + (lane >> 4) of this wave exists
-        e("s_mov_b64 exec, vcc")
-        e(f"global_store_dwordx4 {v(VO[i % 4])}, {vr(V_SA + 4 * i, 4)}, {sr(S_TMP)}")
-        e(f"s_mov_b64 exec, {sr(S_EXEC)}")
-        e(f"s_add_u32 {s(S_TMP)}, {s(S_TMP)}, {s(S_TMP2)}")
-        e(f"s_addc_u32 {s(S_TMP + 1)}, {s(S_TMP + 1)}, 0")
-        e(f"s_add_i32 {s(S_TMP2 + 1)}, {s(S_TMP2 + 1)}, -4")
+            e(f"s_add_i32 {s(S_TMP2 + 1)}, {s(S_TMP2 + 1)}, -4")
     if OPT["trace"]:
         e("s_waitcnt vmcnt(0)")
         stamp(g, 6)

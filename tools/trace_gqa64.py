@@ -10,7 +10,7 @@ LIB = os.path.join(ROOT, "tools", "variants", "libvsel_gqa64trace.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     inc = "/tmp/gqa64_trace_body.inc"
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_attn_fwd64.py")],
-                          env=dict(os.environ, F64_OUT=inc, F64_OPTS="heads=1,xitem=1,trace=1", F64_PREFIX="VSEL_GQA64"), stdout=subprocess.DEVNULL)
+                          env=dict(os.environ, F64_OUT=inc, F64_OPTS="heads=1,xitem=1,epi=1,qearly=1,trace=1", F64_PREFIX="VSEL_GQA64"), stdout=subprocess.DEVNULL)
     subprocess.check_call([os.path.join(ROOT, "tools", "build_variant.sh"), "gqa64trace", "attn_fwd_gqa64.hip", "-DVSEL_GQA64_TRACE",
                            f'-DVSEL_GQA64_BODY="{inc}"'])
     sys.exit(0)

@@ -57,8 +57,9 @@ typedef enum vsel_debug_knob {
                                      (default), 0 never, 1 always; env VSEL_ATTN_BWD_DKDV64; dK / dV as the 4-wave form's, bit for bit */
   VSEL_KNOB_ATTN_STATIC = 17,     /* forward, 4- / 8-wave workgroups: work items dealt out statically (workgroup b takes items b, 2 G - 1 - b,
                                      2 G + b, ... of the heaviest-first list: no atomic, no hand-over barriers, the next item known in advance):
-                                     -1 by item count and sequence length (default), 0 / 1 force; env VSEL_ATTN_STATIC; placement only,
-                                     outputs bit-identical */
+                                     -1 by item count and sequence length (default; the group-shared forms attn_fwd_gqa / attn_fwd_gqa64 deal
+                                     every uniform batch and draw ragged ones behind two dealt rounds), 0 / 1 force; env VSEL_ATTN_STATIC;
+                                     placement only, outputs bit-identical */
   VSEL_KNOB_ATTN_SKIP_EMPTY = 18, /* single work queue on ragged batches: the shared counter jumps over runs of EMPTY items (levels a shorter
                                      sequence does not reach) instead of handing each one out: 1 (default) / 0; env VSEL_ATTN_SKIP_EMPTY;
                                      placement only, outputs bit-identical */

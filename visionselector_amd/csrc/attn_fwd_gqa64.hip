@@ -221,7 +221,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_gqa64_kernel(const uint16_t* 
     cur = next;
     pref = nx_flags;
     if (static_deal) {
-      __syncthreads();                 // the next item's own loads (what was not prefetched) overwrite ring slots other waves may still read
+      // the next item's own loads (what was not prefetched) overwrite ring slots other waves may still read -- nothing is left to load when
+      // the last body prefetched all of it (Q, K(0), K(1), V(0): the next body's first step barrier is then the first point of contact)
+      if (pref != 3) __syncthreads();
       next = deal_next();
     } else {
       if (tid == 0) s_item = pend;

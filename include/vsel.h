@@ -127,6 +127,12 @@ int vsel_gather_rows(void* stream, const void* h, vsel_dtype hdtype, int64_t d, 
  * xs [B, N] float32 -> ps [B, N], ts [B].
  * Reference asserts 0 < k < N (:75) -> VSEL_ERR_INVALID.                                          */
 int vsel_soft_topk_fwd(void* stream, const float* xs, int64_t b, int64_t n, int64_t k, float* ps, float* ts);
+/* The same entry in the reference's own BFLOAT16 arithmetic (its released scorers run in bf16: EV/token_compression/
+ * selector_model.py:75-89 then rounds lo / hi / mid, x + mid, the sigmoid and the sum -- spacing 2 at 256 .. 512 -- to bf16, and
+ * the 64-step bisection stalls on a bf16 neighbour of the root, e.g. sum(ps) = 459.35 for k = 460).  xs [B, N] float32 (rounded
+ * to bf16 on entry) -> ps, ts float32 holding bf16 values: the reference's last_combined_scores (:190) bit for bit on the same
+ * scores (tests/golden/lisbf16_*.npz).  Opt-in (selector attribute soft_topk_bf16_reference); the default returns the fp32 root. */
+int vsel_soft_topk_fwd_bf16ref(void* stream, const float* xs, int64_t b, int64_t n, int64_t k, float* ps, float* ts);
 /* TopK.backward (FT/compression_method/selector_model.py:60-70).                                  */
 int vsel_soft_topk_bwd(void* stream, const float* grad_ps, const float* xs, const float* ts, int64_t b, int64_t n,
                        float* grad_xs);

@@ -160,6 +160,30 @@ def find_ts(xs: np.ndarray, k: int):
     return ts, _sigmoid32(xs + ts)                                     # :86
 
 
+def find_ts_bf16_reference(xs: np.ndarray, k: int):
+    """_find_ts as the reference runs it on a BFLOAT16 score tensor (its released scorers are bf16): the same lines with every
+    operation's result rounded to bf16 -- lo / hi / mid, xs + mid, the sigmoid, and .sum() (fp32 inside, bf16 out: spacing 2 at
+    256 .. 512), so the comparison with k stalls the bisection on a bf16 neighbour of the root.
+    EV/token_compression/selector_model.py:75-89 (= FT/compression_method/selector_model.py:72-86).  xs [B,N] (rounded to bf16
+    on entry) -> (ts [B,1], ps [B,N]) float32 holding bf16 values.  Pinned bit for bit on tests/golden/lisbf16_*.npz (`ts_bf16`,
+    `ps_bf16` from `scores_bf16`): tests/test_oracle_golden.py."""
+    r = bf16_round
+    xs = r(np.asarray(xs, np.float32))
+    b, n = xs.shape
+    assert 0 < k < n                                                   # :77
+    lo = r(r(-xs.max(axis=1, keepdims=True)) - np.float32(10))         # :80
+    hi = r(r(-xs.min(axis=1, keepdims=True)) + np.float32(10))         # :81
+    kf = np.float32(k)
+    for _ in range(64):                                                # :82
+        mid = r(r(hi + lo) / np.float32(2))                            # :83
+        s = r(r(_sigmoid32(r(xs + mid))).sum(axis=1, dtype=np.float32))
+        mask = s < kf                                                  # :84
+        lo[mask] = mid[mask]                                           # :85
+        hi[~mask] = mid[~mask]                                         # :86
+    ts = r(r(lo + hi) / np.float32(2))                                 # :87
+    return ts, r(_sigmoid32(r(xs + ts)))                               # :88
+
+
 def soft_topk(xs: np.ndarray, k: int) -> np.ndarray:
     """topk = TopK.apply (forward).  FT/.../selector_model.py:53-58,88."""
     return find_ts(xs, k)[1]

@@ -30,6 +30,8 @@ MEAN_ABS_FWD = 1e-3      # gate: mean |err| vs the un-rounded fp64 oracle
 # against the build's bf16-storage / fp32-accumulate path.  north_star: "soft scores ... within 1e-3 bf16".
 BF16_SCORE_TOL = 1e-3    # |score - reference bf16 score| <= 1e-3 * max(1, max|score|)
 BF16_IDX_FRAC = 0.01     # |idx (sym.diff) reference bf16 idx| <= max(2 * ties at the k-th value, 1 % of k)
+# (the DEFAULT soft top-k returns the fp32 root; the opt-in vsel_soft_topk_fwd_bf16ref restates the reference's bf16 arithmetic and matches
+# its fixtures bit for bit on the same scores -- tests/test_lis_gpu.py, tests/test_oracle_golden.py)
 BF16_PS_TOL = 3e-3       # soft mask: the reference's bf16 bisection stalls at bf16 spacing of t (|dt| <= 2^-7 -> |dp| <= 2e-3)
                          # and its p is rounded to bf16 (<= 2^-9 relative = 2e-3 near 1); observed worst 2.2e-3
                          # (profiles/r03_parity.json), logged every run

@@ -66,6 +66,32 @@ def test_selector_state_dict_keys(selector_model):
     assert all(k.startswith("model.visual.importance_scorer.") for k in keys)
 
 
+def test_selector_soft_scores_in_the_reference_bf16_arithmetic(selector_model):
+    """visual.soft_topk_bf16_reference = True: last_combined_scores comes from vsel_soft_topk_fwd_bf16ref -- the reference's _find_ts with
+    every step rounded to bf16 (its bf16 scorers' stalled bisection, sum != k) -- instead of the fp32 root; selection, logits and
+    the default behaviour are untouched."""
+    from visionselector_amd import ops
+    m = selector_model
+    m.visual.budgets = 0.25
+    inp, n_vis = make_inputs()
+    k = max(1, int(n_vis * 0.25))
+    outs = {}
+    try:
+        for flag in (False, True):
+            m.visual.soft_topk_bf16_reference = flag
+            m.model.rope_deltas = None
+            with torch.no_grad():
+                o = m(**inp)
+            outs[flag] = (o.logits.clone(), m.visual.last_selected_indices.clone(), m.visual.last_combined_scores.float().clone())
+    finally:
+        m.visual.soft_topk_bf16_reference = False
+    assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1])
+    assert abs(float(outs[False][2].sum()) - k) < 1e-2
+    ps = outs[True][2]
+    assert torch.equal(ps, ps.bfloat16().float())                                     # bf16 values
+    assert float((ps - outs[False][2]).abs().max()) <= 2e-2 and abs(float(ps.sum()) - k) <= 0.02 * k + 1.0
+
+
 @pytest.mark.parametrize("budget", [0.25, 0.5])
 def test_selector_prefill_matches_manual_splice(selector_model, budget):
     from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as hf

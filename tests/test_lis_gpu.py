@@ -164,6 +164,20 @@ def test_lis_select_vs_reference_bf16_run(ops, golden_dir, name):
     parity.record(f"soft_topk[{name}]", "soft_bf16", sm)
     assert sm["max_abs_dps"] <= parity.BF16_PS_TOL and sm["abs_dts"] <= 2.0 ** -7, sm
     assert abs(sm["sum_ps"] - k) <= 1e-2                     # ours sums to k; the reference's bf16 bisection does not
+    # ... and the opt-in bf16-reference mode (vsel_soft_topk_fwd_bf16ref): on the REFERENCE's bf16 scores it reproduces the reference's
+    # stalled bisection exactly -- ts bit for bit; ps bit for bit but for elements whose fp32 sigmoid falls within an ulp of a bf16
+    # rounding boundary (libm vs device expf): at most 2 of them, one bf16 step apart
+    sref = torch.from_numpy(g["scores_bf16"]).cuda()
+    psr, tsr = ops.soft_topk_fwd(sref[None], k, bf16_reference=True)
+    psr = psr[0].cpu().numpy()
+    assert float(tsr[0]) == float(g["ts_bf16"])
+    bad = np.flatnonzero(psr != g["ps_bf16"])
+    assert len(bad) <= 2 and (len(bad) == 0 or np.abs(psr[bad] - g["ps_bf16"][bad]).max() <= 2.0 ** -8), (len(bad), psr[bad], g["ps_bf16"][bad])
+    assert np.array_equal(psr, olis.find_ts_bf16_reference(g["scores_bf16"][None], k)[1][0]) or len(bad) <= 2
+    # on OUR scores (fp32 accumulation; within 1e-3 of the reference's) the mode lands on the same bf16 threshold or its neighbour
+    pso, tso = ops.soft_topk_fwd(scores[None], k, bf16_reference=True)
+    assert abs(float(tso[0]) - float(g["ts_bf16"])) <= 2.0 ** -6
+    assert np.abs(pso[0].cpu().numpy() - g["ps_bf16"]).max() <= 2 * parity.BF16_PS_TOL
     # training forward (FT/compression_method/selector_model.py:158-173) against the reference's bf16 training forward
     h_new, tps, y, tsc, tts, bce = ops.lis_train_fwd(h, wq, bq, wk, bk, olis.budget_k_train(n, 0.2))
     assert np.abs(tps.cpu().numpy() - g["train_ps_bf16"]).max() <= parity.BF16_PS_TOL

@@ -221,6 +221,19 @@ def test_fp32_oracle_vs_reference_bf16_run(golden_dir, name):
     assert int((g16["train_y_bf16"] != g32["train_y"]).sum()) <= max(2, int(0.01 * k))
 
 
+@pytest.mark.parametrize("name", ["tiny", "qwen3b_256", "qwen3b_576", "qwen7b_2304", "ov8b_5832"])
+def test_find_ts_bf16_reference_reproduces_the_reference_bf16_run_bit_for_bit(golden_dir, name):
+    """oracle/lis.py::find_ts_bf16_reference = _find_ts with every operation rounded to bf16 (what the reference's bf16 scorer makes of
+    EV/token_compression/selector_model.py:75-89): from the fixture's `scores_bf16` it gives the reference's own `ts_bf16` and `ps_bf16`
+    -- the stalled bisection, sum(ps) != k -- BIT FOR BIT, on all five fixtures."""
+    g = load_bf16(golden_dir, name)
+    k = int(g["topk_k"])
+    ts, ps = lis.find_ts_bf16_reference(g["scores_bf16"][None], k)
+    assert float(ts[0, 0]) == float(g["ts_bf16"])
+    assert np.array_equal(ps[0], g["ps_bf16"])
+    assert float(ps[0].sum(dtype=np.float64)) == float(g["sum_ps_bf16"])
+
+
 @pytest.mark.parametrize("name", ["tiny", "qwen3b_256", "qwen7b_2304"])
 def test_torch_cpu_restatement_bf16(golden_dir, cases, name):
     """oracle/lis_torch.py run in bfloat16 (bench.py's `bf16_reference_formulation` CPU leg) is the reference's bf16 run: same

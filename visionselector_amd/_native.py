@@ -42,6 +42,7 @@ SIGNATURES = {
     "vsel_topk_select": (C.c_int, [_P, _P, _SEG, _P, _P]),
     "vsel_gather_rows": (C.c_int, [_P, _P, C.c_int, _I64, _SEG, _P, _P]),
     "vsel_soft_topk_fwd": (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _P]),
+    "vsel_soft_topk_fwd_bf16ref": (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _P]),
     "vsel_soft_topk_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P]),
     "vsel_lis_train_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "vsel_lis_train_fwd": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _SC, _P, _SZ, _P, _P, _P, _P, _P, _P]),

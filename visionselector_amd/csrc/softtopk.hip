@@ -90,6 +90,65 @@ __global__ __launch_bounds__(NT) void soft_topk_fwd_kernel(const float* __restri
   }
 }
 
+// The reference's OWN arithmetic when its scorer runs in bfloat16 (the released checkpoints do): _find_ts on a bf16 tensor rounds every
+// operation to bf16 -- lo / hi / mid, x + mid, the sigmoid, and the SUM (fp32 accumulation, bf16 result: spacing 2 at 256 .. 512) -- so
+// the bisection stalls after ~10 of its 64 steps on the bf16 neighbour of the root (EV/token_compression/selector_model.py:75-89; e.g.
+// sum ps = 459.35 for k = 460).  This kernel restates exactly that, rounding step for rounding step (oracle/lis.py,
+// find_ts_bf16_reference, pinned bit for bit on the reference's bf16 fixtures); the default entry returns the fp32 root instead.
+// One workgroup per row; x rounded to bf16 on entry; the loop stops when a step leaves lo and hi unchanged (every later step repeats it).
+__device__ __forceinline__ float round_bf16(float x) { return bf16_to_f32(f32_to_bf16_bits(x)); }
+
+template <int NT>
+__global__ __launch_bounds__(NT) void soft_topk_fwd_bf16ref_kernel(const float* __restrict__ xs, int n, int k, float* __restrict__ ps,
+                                                                   float* __restrict__ ts) {
+  constexpr int NW = NT / 64;
+  __shared__ float red[6][NW];
+  const int row = blockIdx.x;
+  const float* x = xs + (int64_t)row * n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float mx = -INFINITY, mn = INFINITY;
+  for (int i = tid; i < n; i += NT) {
+    const float v = round_bf16(x[i]);
+    mx = fmaxf(mx, v);
+    mn = fminf(mn, v);
+  }
+  mx = wave_max(mx);
+  mn = wave_min(mn);
+  if (lane == 0) { red[4][wave] = mx; red[5][wave] = mn; }
+  __syncthreads();
+  mx = red[4][0]; mn = red[5][0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) { mx = fmaxf(mx, red[4][w]); mn = fminf(mn, red[5][w]); }
+  __syncthreads();
+  float lo = round_bf16(round_bf16(-mx) - 10.0f), hi = round_bf16(round_bf16(-mn) + 10.0f);     // :80-81
+  const float kf = (float)k;
+  for (int it = 0; it < 64; ++it) {                                                              // :82
+    const float mid = round_bf16(round_bf16(hi + lo) * 0.5f);                                    // :83
+    float s = 0.f;
+    for (int i = tid; i < n; i += NT) {
+      float a = round_bf16(round_bf16(x[i]) + mid);
+      asm volatile("" : "+v"(a));                                                                // (see the output loop below)
+      s += round_bf16(sigmoidf_ref(a));
+    }
+    const float st = round_bf16(block_sum<NW>(s, red, it & 1 ? 1 : 0));                          // :84 (.sum of a bf16 tensor: fp32 inside, bf16 out)
+    const float lo2 = st < kf ? mid : lo, hi2 = st < kf ? hi : mid;                              // :85-86
+    const int same = __builtin_amdgcn_readfirstlane((lo2 == lo && hi2 == hi) ? 1 : 0);       // (the same value in every lane: a scalar branch)
+    lo = lo2;
+    hi = hi2;
+    if (same) break;
+  }
+  const float t = round_bf16(round_bf16(lo + hi) * 0.5f);                                        // :87
+  if (tid == 0) ts[row] = t;
+  float* prow = ps + (int64_t)row * n;
+  for (int i = tid; i < n; i += NT) {
+    float a = round_bf16(round_bf16(x[i]) + t);
+    // (hipcc, ROCm 7.2, unrolls this loop by two and packs the pair's "1 + exp(-a)" into v_pk_add_f32 -- the negation of the FIRST element
+    // was lost on the way: every thread's first output came out as sigmoid(-a).  An opaque copy keeps the elements apart.)
+    asm volatile("" : "+v"(a));
+    prow[i] = round_bf16(sigmoidf_ref(a));                                                        // :88
+  }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void soft_topk_bwd_kernel(const float* __restrict__ grad_ps,
                                                            const float* __restrict__ xs,
@@ -152,6 +211,16 @@ extern "C" int vsel_soft_topk_fwd(void* stream, const float* xs, int64_t b, int6
   if (!(0 < k && k < n)) return fail(VSEL_ERR_INVALID, "soft top-k needs 0 < k < n (k=%lld, n=%lld)", (long long)k, (long long)n);
   VSEL_PROF_BEGIN(stream);
   return launch_soft_topk_fwd((hipStream_t)stream, xs, b, n, k, ps, ts);
+}
+
+extern "C" int vsel_soft_topk_fwd_bf16ref(void* stream, const float* xs, int64_t b, int64_t n, int64_t k, float* ps, float* ts) {
+  if (!xs || !ps || !ts) return fail(VSEL_ERR_INVALID, "NULL pointer");
+  if (b < 1 || n < 1 || b > 0x7fffffff || n > 0x7fffffff) return fail(VSEL_ERR_INVALID, "bad shape [%lld, %lld]", (long long)b, (long long)n);
+  if (!(0 < k && k < n)) return fail(VSEL_ERR_INVALID, "soft top-k needs 0 < k < n (k=%lld, n=%lld)", (long long)k, (long long)n);
+  VSEL_PROF_BEGIN(stream);
+  hipLaunchKernelGGL((soft_topk_fwd_bf16ref_kernel<1024>), dim3((unsigned)b), dim3(1024), 0, (hipStream_t)stream, xs, (int)n, (int)k, ps, ts);
+  VSEL_AFTER_LAUNCH((hipStream_t)stream, "soft_topk_fwd_bf16ref_kernel");
+  return VSEL_OK;
 }
 
 extern "C" int vsel_soft_topk_bwd(void* stream, const float* grad_ps, const float* xs, const float* ts, int64_t b,

@@ -168,8 +168,11 @@ def select_and_splice(self, base_forward: Callable, hidden_states: torch.Tensor,
         merged.contiguous(), *params, input_ids[0].contiguous(), inputs_embeds[0].contiguous(), visual_token_id, [L], [total], [k],
         position_ids=None if position_ids is None else position_ids.reshape(-1, L), col_sums=col_sums,
         attention_mask=None if attention_mask is None else attention_mask[0], logical_to_physical=l2p, physical_to_logical=p2l,
-        check=check, soft=True)
+        check=check, soft=not _soft_bf16_reference(self))
     # EV :190 (visualisation only): the soft top-k comes out of the same launch (one extra workgroup), not a launch of its own
+    # (tower attribute soft_topk_bf16_reference: the reference's bf16 arithmetic instead, from the scores, in a launch of its own)
+    if _soft_bf16_reference(self) and 0 < k < total:
+        o["soft_ps"] = ops.soft_topk_fwd(o["scores"][None], k, bf16_reference=True)[0][0]
     combined = None if o["soft_ps"] is None else o["soft_ps"].to(merged.dtype)
     self.last_combined_scores = combined
     self.last_selected_indices = o["idx"]
@@ -181,9 +184,11 @@ def select_and_splice(self, base_forward: Callable, hidden_states: torch.Tensor,
 def select_block_from_tokens(self, merged, perm, col_sums):
     """The LIS block on tokens tower_tokens_for_selection returned (the unfused continuation of select_and_splice)."""
     if perm is not None:
-        out, idx, total, combined = _select_block_permuted(merged, perm, self.importance_scorer, self.budgets, col_sums)
+        out, idx, total, combined = _select_block_permuted(merged, perm, self.importance_scorer, self.budgets, col_sums,
+                                                               soft_bf16_reference=_soft_bf16_reference(self))
     else:
-        out, idx, total, combined = lis_select_block(merged, self.importance_scorer, self.budgets)
+        out, idx, total, combined = lis_select_block(merged, self.importance_scorer, self.budgets,
+                                                         soft_bf16_reference=_soft_bf16_reference(self))
     self.last_combined_scores = combined
     self.last_selected_indices = idx
     return out, idx, total
@@ -204,9 +209,11 @@ def make_vision_tower_forward_selector(base_forward: Callable, mode: str):
     def forward_eval(self, hidden_states: torch.Tensor, grid_thw: torch.Tensor, **kwargs):
         merged, perm, col_sums = tower_tokens_for_selection(self, base_forward, hidden_states, grid_thw, **kwargs)
         if perm is not None:
-            out, idx, total, combined = _select_block_permuted(merged, perm, self.importance_scorer, self.budgets, col_sums)
+            out, idx, total, combined = _select_block_permuted(merged, perm, self.importance_scorer, self.budgets, col_sums,
+                                                               soft_bf16_reference=_soft_bf16_reference(self))
         else:
-            out, idx, total, combined = lis_select_block(merged, self.importance_scorer, self.budgets)
+            out, idx, total, combined = lis_select_block(merged, self.importance_scorer, self.budgets,
+                                                         soft_bf16_reference=_soft_bf16_reference(self))
         self.last_combined_scores = combined
         self.last_selected_indices = idx
         return out, idx, total
@@ -214,9 +221,15 @@ def make_vision_tower_forward_selector(base_forward: Callable, mode: str):
     return forward_train if mode == "train" else forward_eval
 
 
+def _soft_bf16_reference(tower) -> bool:
+    """tower.soft_topk_bf16_reference (default False): last_combined_scores in the reference's own bf16 arithmetic
+    (vsel_soft_topk_fwd_bf16ref) instead of the fp32 root"""
+    return bool(getattr(tower, "soft_topk_bf16_reference", False))
+
+
 @torch.no_grad()
 def _select_block_permuted(merged_physical: torch.Tensor, reverse_indices: torch.Tensor, scorer, budgets: float,
-                           col_sums: torch.Tensor | None = None):
+                           col_sums: torch.Tensor | None = None, soft_bf16_reference: bool = False):
     """lis_select_block on merged_physical[reverse_indices] without materialising it (vsel_lis_select_permuted; with the
     producer's column sums: vsel_lis_select_presummed, one sweep over the tokens instead of two)."""
     total = merged_physical.shape[0]
@@ -232,5 +245,5 @@ def _select_block_permuted(merged_physical: torch.Tensor, reverse_indices: torch
         out, idx, scores = ops.lis_select_permuted(merged_physical.contiguous(), l2p, p2l, *params, k)
     combined = None
     if 0 < k < total:
-        combined = ops.soft_topk_fwd(scores[None], k)[0][0].to(merged_physical.dtype)
+        combined = ops.soft_topk_fwd(scores[None], k, bf16_reference=soft_bf16_reference)[0][0].to(merged_physical.dtype)
     return out, idx, total, combined

@@ -301,14 +301,17 @@ def gather_rows(h: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 # differentiable top-k
 # ------------------------------------------------------------------------------------------------
 
-def soft_topk_fwd(xs: torch.Tensor, k: int):
+def soft_topk_fwd(xs: torch.Tensor, k: int, bf16_reference: bool = False):
+    """_find_ts: (ps [B, N], ts [B]).  bf16_reference: the reference's own bfloat16 arithmetic (every step rounded to bf16: its
+    bisection stalls on a bf16 neighbour of the root) instead of the fp32 root -- vsel_soft_topk_fwd_bf16ref, include/vsel.h."""
     dev = _dev(xs)
     if xs.dtype != torch.float32 or xs.dim() != 2:
         raise TypeError("soft_topk_fwd takes float32 [B, N]")
     b, n = xs.shape
     ps = torch.empty_like(xs)
     ts = torch.empty(b, dtype=torch.float32, device=dev)
-    N.check(N.lib().vsel_soft_topk_fwd(_stream(), xs.data_ptr(), b, n, int(k), ps.data_ptr(), ts.data_ptr()))
+    fn = N.lib().vsel_soft_topk_fwd_bf16ref if bf16_reference else N.lib().vsel_soft_topk_fwd
+    N.check(fn(_stream(), xs.data_ptr(), b, n, int(k), ps.data_ptr(), ts.data_ptr()))
     return ps, ts
 
 

@@ -195,7 +195,7 @@ def lis_train_block(hidden_states: torch.Tensor, scorer: TransformerScorer, budg
 # --------------------------------------------------------------------------------------------------
 @torch.no_grad()
 def lis_select_block(hidden_states: torch.Tensor, scorer: TransformerScorer, budgets: float,
-                     with_soft_scores: bool = True):
+                     with_soft_scores: bool = True, soft_bf16_reference: bool = False):
     """hidden_states [N, D] -> (hidden_states_new [k, D], all_indices int64 [k] ascending, total_token_num,
     last_combined_scores [N] or None)   -- EV/token_compression/selector_model.py:182-194."""
     total_token_num = hidden_states.shape[0]
@@ -204,7 +204,9 @@ def lis_select_block(hidden_states: torch.Tensor, scorer: TransformerScorer, bud
                                       dominant_num)
     combined = None
     if with_soft_scores and 0 < dominant_num < total_token_num:            # :190 (visualisation only)
-        combined = ops.soft_topk_fwd(scores[None], dominant_num)[0][0].to(hidden_states.dtype)
+        # soft_bf16_reference (tower attribute `soft_topk_bf16_reference`, default off): last_combined_scores in the reference's own bf16
+        # arithmetic -- its stalled bisection, bit for bit on the same scores -- instead of the fp32 root (include/vsel.h)
+        combined = ops.soft_topk_fwd(scores[None], dominant_num, bf16_reference=soft_bf16_reference)[0][0].to(hidden_states.dtype)
     return out, idx, total_token_num, combined
 
 

@@ -336,6 +336,18 @@ int vsel_varlen_attn_fwd_strided(void* stream, const void* q, const void* k, con
                                  int64_t k_row_stride, int64_t k_head_stride, int64_t v_row_stride, int64_t v_head_stride,
                                  float scale, int causal, void* out);
 
+/* -------- the same forward with a caller workspace: key-range parts for ONE long sequence ------------------------
+ * vsel_varlen_attn_fwd (and _lse when lse != NULL) on batches the launch cannot balance as they are -- one uncompressed prompt, or a
+ * few of equal length: 256-query items cut over key ranges, fp32 partial outputs + (m, l) in `ws`, merged in part order by a second
+ * launch (csrc/attn_fwd64_parts.hip; the reference's call is the same flash_attn_varlen_func, EV/qwen25vl/modeling_qwen2_5_vl.py:900).
+ * vsel_varlen_attn_fwd_workspace_bytes: bytes the call would use for these shapes, 0 when it would run the workspace-free forms
+ * (then ws may be NULL; the call is vsel_varlen_attn_fwd[_lse]).  Deterministic; not bit-identical to the workspace-free forms
+ * (another fp32 association: within a bf16 rounding).  head_dim 128, causal, every sequence max_seqlen tokens.                    */
+size_t vsel_varlen_attn_fwd_workspace_bytes(int64_t n_seq, int64_t max_seqlen, int64_t total, int64_t hq, int64_t hkv, int64_t d, int causal);
+int vsel_varlen_attn_fwd_ws(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens, int64_t n_seq,
+                            int64_t max_seqlen, int64_t total, int64_t hq, int64_t hkv, int64_t d, float scale, int causal, void* out,
+                            float* lse, void* ws, size_t ws_bytes);
+
 /* -------- var-len attention for TRAINING: forward that also saves the log-sum-exp, and the backward -------------
  * The reference trains the LIS through the frozen LLM with flash_attn_varlen_func (FT/qwenvl/train/trainer.py:101-113,
  * patched in by replace_qwen2_vl_attention_class :150-160), so dQ / dK / dV of the same op are on the training path.

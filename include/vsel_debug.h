@@ -75,7 +75,10 @@ typedef enum vsel_debug_knob {
                                      per XCD, so the two directions alternate on a queue and its CUs stay on one Q / dO tile per pair (L2);
                                      default 1; env VSEL_ATTN_BWD_UPDOWN; a rule of the item alone (batch-invariant), fp32 association of odd
                                      heads differs from the 0 setting */
-  VSEL_KNOB_COUNT = 22
+  VSEL_KNOB_ATTN_KEY_PARTS = 22,  /* vsel_varlen_attn_fwd_ws: key-range parts of the 256-query items (csrc/attn_fwd64_parts.hip): -1 for uniform causal batches
+                                     of <= 128 items (few q heads) from 2048 tokens (default), 0 never, 1 whenever the shapes allow, n > 1: n key tiles per part;
+                                     env VSEL_ATTN_KEY_PARTS; deterministic, another fp32 association than the unsplit forms */
+  VSEL_KNOB_COUNT = 23
 } vsel_debug_knob;
 
 /* Set knob to value (clamped to the knob's range).  *previous (may be NULL) receives the value it had.

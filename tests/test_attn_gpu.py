@@ -535,6 +535,63 @@ def test_gqa_shared_forward_dealt_and_queued_items_agree(ops, lens, hq, hkv):
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (form, static)
 
 
+@pytest.mark.parametrize("lens,hq,hkv,cap", [([2368], 4, 4, -1), ([2368], 8, 2, -1), ([2368], 28, 4, 1), ([2112, 2112], 8, 2, 1), ([4096], 4, 1, 9),
+                                             ([2049], 6, 2, 8), ([8192], 4, 2, -1), ([3000], 12, 4, 12)])
+def test_key_range_parts_forward_matches_oracle_and_unsplit_form(ops, lens, hq, hkv, cap):
+    """One long sequence (or a few of equal length) through vsel_varlen_attn_fwd_ws: 256-query items cut over key ranges, fp32 partials +
+    (m, l) in a workspace, merged in part order (csrc/attn_fwd64_parts.hip).  Within the usual gate of the fp64 oracle, within a bf16 rounding
+    of the unsplit form (another fp32 association), bit-identical between two runs; cap = knob attn_key_parts (-1: the library's own rule --
+    few heads; 1: forced with its own cap; n: n key tiles per part); partial last tiles (2049, 3000), GQA 1 / 3 / 4 / 7, two sequences."""
+    from visionselector_amd import _native as N
+    q, k, v = make_qkv(sum(lens), hq, hkv, 91 + hq)
+    cu = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    cu_t = torch.from_numpy(cu).cuda()
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    with N.debug_knob(attn_key_parts=0):
+        base = ops.varlen_attn(qc, kc, vc, cu_t, max(lens))
+    with N.debug_knob(attn_key_parts=cap):
+        N.profile_start()
+        got = ops.varlen_attn(qc, kc, vc, cu_t, max(lens))
+        prof = N.profile_stop()
+        again = ops.varlen_attn(qc, kc, vc, cu_t, max(lens))
+    assert "attn_fwd64_parts_kernel" in prof and "attn_fwd64_merge_kernel" in prof, prof
+    assert torch.equal(got, again)
+    assert float((got.float() - base.float()).abs().max()) <= 2 ** -7 * float(base.float().abs().max())
+    ref = oattn.varlen_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu, causal=True)
+    check(got.float().cpu().numpy(), ref)
+
+
+def test_key_range_parts_are_not_taken_for_other_batches(ops):
+    """vsel_varlen_attn_fwd_workspace_bytes is 0 -- and the workspace-free forms run -- for ragged batches, non-causal calls, short
+    sequences, and (by the library's own rule) more than half a round of items; a too-small workspace is refused loudly."""
+    import ctypes as C
+    from visionselector_amd import _native as N
+    lib = N.lib()
+    wsb = lib.vsel_varlen_attn_fwd_workspace_bytes
+    assert wsb(1, 2368, 2368, 4, 4, 128, 1) > 0
+    assert wsb(1, 2368, 2368, 28, 4, 128, 1) == 0            # 280 items: the 7B geometry keeps the unsplit form (measured: slower in parts)
+    assert wsb(2, 2368, 4000, 4, 4, 128, 1) == 0             # ragged
+    assert wsb(1, 2368, 2368, 4, 4, 128, 0) == 0             # not causal
+    assert wsb(1, 1024, 1024, 4, 4, 128, 1) == 0             # short
+    q, k, v = make_qkv(2368, 4, 4, 5)
+    cu_t = torch.tensor([0, 2368], dtype=torch.int32, device="cuda")
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    out = torch.empty_like(qc)
+    ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    rc = lib.vsel_varlen_attn_fwd_ws(None, qc.data_ptr(), kc.data_ptr(), vc.data_ptr(), cu_t.data_ptr(), 1, 2368, 2368, 4, 4, 128,
+                                     128 ** -0.5, 1, out.data_ptr(), None, ws.data_ptr(), ws.numel())
+    assert rc == 2, rc                                        # VSEL_ERR_WORKSPACE
+    lse = torch.empty(2368, 4, dtype=torch.float32, device="cuda")
+    need = wsb(1, 2368, 2368, 4, 4, 128, 1)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    N.check(lib.vsel_varlen_attn_fwd_ws(None, qc.data_ptr(), kc.data_ptr(), vc.data_ptr(), cu_t.data_ptr(), 1, 2368, 2368, 4, 4, 128,
+                                        128 ** -0.5, 1, out.data_ptr(), lse.data_ptr(), ws.data_ptr(), ws.numel()))
+    with N.debug_knob(attn_key_parts=0):
+        o2, l2 = ops.varlen_attn_fwd_lse(qc, kc, vc, cu_t, 2368)
+    assert float((out.float() - o2.float()).abs().max()) <= 2 ** -7 * float(o2.float().abs().max())
+    assert float((lse - l2).abs().max()) <= 1e-4 * max(1.0, float(l2.abs().max()))
+
+
 def test_gqa_shared_forward_rescale_and_lazy_exponent(ops):
     lens = [900, 333, 1500]
     total = sum(lens)

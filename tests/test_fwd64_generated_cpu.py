@@ -44,6 +44,15 @@ def test_body_register_budget():
     assert used <= declared, sorted(used - declared)[:10]
 
 
+def test_committed_parts_body_is_the_generators_output(tmp_path):
+    """attn_fwd64_parts_body.inc = the same generator with raw = 1 (key-range parts: fp32 accumulators + (m, l) out, csrc/attn_fwd64_parts.hip)"""
+    out = tmp_path / "body.inc"
+    env = dict(os.environ, F64_OUT=str(out), F64_OPTS="raw=1", F64_PREFIX="VSEL_FWD64P")
+    subprocess.check_call([sys.executable, GEN], env=env, stdout=subprocess.DEVNULL)
+    inc = os.path.join(ROOT, "visionselector_amd", "csrc", "attn_fwd64_parts_body.inc")
+    assert out.read_text() == open(inc).read(), "run F64_OPTS=raw=1 F64_PREFIX=VSEL_FWD64P F64_OUT=... python tools/gen_attn_fwd64.py"
+
+
 def test_committed_heads_body_is_the_generators_output(tmp_path):
     """attn_fwd_gqa64_body.inc = the same generator with heads = 1 (two q heads of a GQA group per wave) under its own macro prefix"""
     out = tmp_path / "body.inc"

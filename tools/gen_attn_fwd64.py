@@ -449,6 +449,7 @@ OPT = {
                           # ~3 000-cycle round trip); K(0) / K(1) / V(0) stay in the P V gaps and the epilogue waits for the Q slices only.
                           # (A step earlier still -- top of the second-to-last step -- was slower: 123.0 vs 114.1 us at 32 x 524, the
                           # slices then sit in front of that step's vmcnt(0) + barrier and their issue is not under any MFMA.)
+    "raw": 0,             # 1: the body also serves key-range PARTS of an item: inputs %[raw], %[prawa], %[prawb] (see the epilogue)
     "epi": 0,             # 1: epilogue with packed multiplies (v_pk_mul_f32: half the normalisation instructions, the same IEEE products) and block
                           # A's rows read back and stored while block B is still being converted (the LDS round trip and the store issue of
                           # one block under the VALU work of the other); the next item's Q fragments are waited for after the 1 / l arithmetic
@@ -1175,6 +1176,26 @@ def gen_body():
     # c ^ (r & 15) (conflict-free for the 16 lanes of a group), read back as whole rows (ds_read_b128, 4 rows per instruction) and
     # stored as 16 x 1 KiB of whole 256-byte rows.
     g.label("Lepi")
+    if OPT["raw"]:
+        # key-range PARTS of an item (attn_fwd64_parts.hip): %[raw] != 0 -> the un-normalised fp32 accumulators leave as they are, lane (j, hh)
+        # writing features 32 dt + 8 g4 + 4 hh .. + 3 of its row at %[prawa] / %[prawb] (per-lane row pointers, + 16 hh bytes), rows that
+        # exist only; (m, l) go back through the outputs as always and the merge kernel does the rest.  No barrier: nothing shared is touched.
+        assert not xitem and not OPT["heads"]
+        e("s_cmp_lg_u32 %[raw], 0")
+        e(f"s_cbranch_scc0 {g.lref('Lnotraw')}")
+        e("s_nop 15")
+        for b, ptr in ((0, "prawa"), (1, "prawb")):
+            e(f"v_and_b32 {v(V_T)}, 31, {v(V_LANE)}")
+            if b:
+                e(f"v_add_u32 {v(V_T)}, 32, {v(V_T)}")
+            e(f"v_cmp_gt_i32 vcc, %[nvalid], {v(V_T)}")
+            e("s_mov_b64 exec, vcc")
+            for dt in range(4):
+                for g4 in range(4):
+                    e(f"global_store_dwordx4 %[{ptr}], {ar(A_O + 64 * b + 16 * dt + 4 * g4, 4)}, off offset:{128 * dt + 32 * g4}")
+            e(f"s_mov_b64 exec, {sr(S_EXEC)}")
+        e(f"s_branch {g.lref('Lrawdone')}")
+        g.label("Lnotraw")
     if OPT["epi"]:
         epilogue_pipelined(g, xitem)
     else:
@@ -1288,6 +1309,8 @@ def gen_body():
             e(f"v_mov_b32 {v(V_T)}, {s(S_TR + 3 + k)}")
             e(f"global_atomic_add {v(V_T + 1)}, {v(V_T)}, %[dbg] offset:{4 * k}")
         e(f"s_mov_b64 exec, {sr(S_EXEC)}")
+    if OPT["raw"]:
+        g.label("Lrawdone")
     for b in range(2):
         e(f"v_mov_b32 %[m{b}], {v(V_M + b)}")
         e(f"v_mov_b32 %[l{b}], {v(V_L + b)}")

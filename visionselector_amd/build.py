@@ -40,7 +40,7 @@ ASM_READ_KERNELS = (("attn.hip", "varlen_attn_fwd_kernelILb1E"), ("attn_bwd.hip"
                     # the generated one-statement bodies clobber v32-255 / a0-255 / s40-99: everything the C++ around them keeps live must
                     # fit in what is left, without scratch
                     ("attn_fwd64.hip", "attn_fwd64_kernel"), ("attn_fwd_gqa64.hip", "attn_fwd_gqa64_kernel"), ("attn_bwd_dq64.hip", "attn_bwd_dq64_kernel"),
-                    ("attn_bwd_dkdv64.hip", "attn_bwd_dkdv64_kernel"))
+                    ("attn_bwd_dkdv64.hip", "attn_bwd_dkdv64_kernel"), ("attn_fwd64_parts.hip", "attn_fwd64_parts_kernel"))
 
 
 def extra_flags() -> list:

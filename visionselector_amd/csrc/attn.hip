@@ -834,6 +834,47 @@ extern "C" int vsel_varlen_attn_fwd(void* stream, const void* q, const void* k, 
                      nullptr, total);
 }
 
+// ---- one long sequence (or a few of equal length): key-range parts with a caller workspace (attn_fwd64_parts.hip) -----------------------
+// cap = key tiles per part: the launch's tile steps spread over the CUs, never below 8 (a part costs an item's prologue and epilogue)
+static bool parts_plan_for(int64_t n_seq, int64_t max_seqlen, int64_t total, int64_t hq, int64_t hkv, int64_t d, int causal, attn::PartsPlan* plan) {
+  const int g = knob(VSEL_KNOB_ATTN_KEY_PARTS);
+  if (g == 0 || d != 128 || !causal || total != n_seq * max_seqlen || hq % hkv != 0) return false;
+  const int64_t q_tiles = cdiv(max_seqlen, 256);
+  const int64_t items = q_tiles * hq * n_seq;
+  // by itself only for launches of at most half a round of items -- few q heads: small models, heads sharded over GPUs.  Measured (one
+  // sequence, unsplit / parts us): 4 heads 2368 33.3 / 31.2, 8192 137.9 / 102.4; 8 heads 2368 43.5 / 35.4, 4096 72.2 / 68.8; but 12 heads
+  // 2368 47.1 / 54.7, 28 heads 2368 60.8 / 79.9, 4096 112 / 139: the fp32 partials of 28 heads are 49 MB written and read again (merge
+  // launch 17 us), more than the balance wins (profiles/EXPERIMENTS.md, round 5)
+  if (g < 0 && (max_seqlen < 2048 || items > 128)) return false;
+  int64_t steps = 0;                                                        // 64-key tile steps of the launch
+  for (int64_t t = 0; t < q_tiles; ++t) steps += cdiv(std::min(max_seqlen, (t + 1) * 256), 64);
+  steps *= hq * n_seq;
+  const int cap = g > 1 ? g : (int)std::max<int64_t>(8, cdiv(steps * 3, 4 * 256));
+  return attn::fwd64_parts_plan(n_seq, max_seqlen, hq, cap, plan);
+}
+
+extern "C" size_t vsel_varlen_attn_fwd_workspace_bytes(int64_t n_seq, int64_t max_seqlen, int64_t total, int64_t hq, int64_t hkv, int64_t d,
+                                                       int causal) {
+  attn::PartsPlan plan;
+  if (n_seq < 1 || max_seqlen < 1 || hq < 1 || hkv < 1 || !parts_plan_for(n_seq, max_seqlen, total, hq, hkv, d, causal, &plan)) return 0;
+  return attn::fwd64_parts_workspace_bytes(n_seq, max_seqlen, hq, plan.max_parts);
+}
+
+extern "C" int vsel_varlen_attn_fwd_ws(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens, int64_t n_seq,
+                                       int64_t max_seqlen, int64_t total, int64_t hq, int64_t hkv, int64_t d, float scale, int causal,
+                                       void* out, float* lse, void* ws, size_t ws_bytes) {
+  int rc = attn_checks(q, k, v, cu_seqlens, out, n_seq, max_seqlen, hq, hkv, d);
+  if (rc) return rc;
+  if (total < 1) return fail(VSEL_ERR_INVALID, "total must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  VSEL_PROF_BEGIN(st);
+  attn::PartsPlan plan;
+  if (ws && parts_plan_for(n_seq, max_seqlen, total, hq, hkv, d, causal, &plan))
+    return attn::attn_fwd64_parts_launch(st, q, k, v, n_seq, max_seqlen, hq, hkv, scale, out, lse, plan, ws, ws_bytes);
+  return attn_launch(st, q, k, v, cu_seqlens, n_seq, max_seqlen, hq, hkv, d, scale, causal, out, PagedKV{nullptr, nullptr, nullptr, 0, 1, 0, 0, 0, 0, 0, 0},
+                     lse, total);
+}
+
 extern "C" int vsel_varlen_attn_fwd_lse(void* stream, const void* q, const void* k, const void* v, const int32_t* cu_seqlens,
                                         int64_t n_seq, int64_t max_seqlen, int64_t total, int64_t hq, int64_t hkv, int64_t d,
                                         float scale, int causal, void* out, float* lse) {

@@ -103,6 +103,16 @@ int attn_fwd_gqa64_launch(hipStream_t st, const void* q, const void* k, const vo
                           int64_t max_seqlen_q, int64_t hq, int64_t hkv, float scale, int causal, void* out, const PagedKV& pg, float* lse,
                           bool deal);
 
+// key-range parts of attn_fwd64's items for one long sequence / a few of equal length (attn_fwd64_parts.hip; needs a caller workspace)
+struct PartsPlan {
+  int q_tiles, cap, n_items, max_parts;
+  int level_off[65];                    // items in front of tile level l (level 0 = the LAST query tile: the heaviest), [q_tiles] = n_items
+};
+bool fwd64_parts_plan(int64_t n_seq, int64_t len, int64_t hq, int cap, PartsPlan* plan);
+size_t fwd64_parts_workspace_bytes(int64_t n_seq, int64_t len, int64_t hq, int max_parts);
+int attn_fwd64_parts_launch(hipStream_t st, const void* q, const void* k, const void* v, int64_t n_seq, int64_t len, int64_t hq, int64_t hkv,
+                            float scale, void* out, float* lse, const PartsPlan& plan, void* ws, size_t ws_bytes);
+
 // ---- XCD-local work queues (round 4) ------------------------------------------------------------------------------------------
 // Every attention kernel streams one operand pair (K / V in the forward and the dQ pass, Q / dO in the dK / dV pass) that ALL the
 // work items of a (sequence, kv head) pair share.  With one global queue the workgroups resident on an XCD belong to 8+ different

@@ -53,6 +53,7 @@ constexpr KnobSpec kKnobs[VSEL_KNOB_COUNT] = {
     {"VSEL_ATTN_GQA", -1, -1, 1},        // VSEL_KNOB_ATTN_GQA
     {"VSEL_ATTN_GQA_FORM", -1, -1, 1},   // VSEL_KNOB_ATTN_GQA_FORM
     {"VSEL_ATTN_BWD_UPDOWN", 1, 0, 1},   // VSEL_KNOB_ATTN_BWD_UPDOWN
+    {"VSEL_ATTN_KEY_PARTS", -1, -1, 64}, // VSEL_KNOB_ATTN_KEY_PARTS
 };
 int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 int knob_default(int id) {

@@ -692,9 +692,18 @@ def varlen_attn(q, k, v, cu_seqlens: torch.Tensor, max_seqlen: int, causal: bool
     hkv = k.shape[1]
     scale = float(softmax_scale) if softmax_scale is not None else d ** -0.5
     out = torch.empty_like(q)
-    N.check(N.lib().vsel_varlen_attn_fwd(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), cu_seqlens.data_ptr(),
-                                         cu_seqlens.numel() - 1, int(max_seqlen), t, hq, hkv, d, scale, int(causal),
-                                         out.data_ptr()))
+    lib = N.lib()
+    n_seq = cu_seqlens.numel() - 1
+    # one long prompt (or a few of equal length): key-range parts through a workspace (vsel_varlen_attn_fwd_ws; 0 bytes = not such a batch)
+    ws_bytes = lib.vsel_varlen_attn_fwd_workspace_bytes(n_seq, int(max_seqlen), t, hq, hkv, d, int(causal))
+    if ws_bytes:
+        ws = _workspace(ws_bytes, dev)
+        N.check(lib.vsel_varlen_attn_fwd_ws(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), cu_seqlens.data_ptr(), n_seq, int(max_seqlen),
+                                            t, hq, hkv, d, scale, int(causal), out.data_ptr(), None, ws.data_ptr(), ws.numel()))
+        return out
+    N.check(lib.vsel_varlen_attn_fwd(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), cu_seqlens.data_ptr(),
+                                     n_seq, int(max_seqlen), t, hq, hkv, d, scale, int(causal),
+                                     out.data_ptr()))
     return out
 
 

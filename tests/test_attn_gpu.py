@@ -376,7 +376,7 @@ def _rows64_pair(ops, q, k, v, cu, L, causal, lse=False):
     from visionselector_amd import _native as N
     outs = []
     for r64 in (0, 1):
-        with N.debug_knob(attn_rows64=r64, attn_split=0):      # (the two-KV-stream form sums in a different order)
+        with N.debug_knob(attn_rows64=r64, attn_split=0, attn_key_parts=0):      # (the two-KV-stream form and key-range parts sum in a different order)
             N.profile_start()
             outs.append(ops.varlen_attn_fwd_lse(q, k, v, cu, L, causal=causal) if lse else ops.varlen_attn(q, k, v, cu, L, causal=causal))
             prof = N.profile_stop()

@@ -130,8 +130,9 @@ int vsel_soft_topk_fwd(void* stream, const float* xs, int64_t b, int64_t n, int6
 /* The same entry in the reference's own BFLOAT16 arithmetic (its released scorers run in bf16: EV/token_compression/
  * selector_model.py:75-89 then rounds lo / hi / mid, x + mid, the sigmoid and the sum -- spacing 2 at 256 .. 512 -- to bf16, and
  * the 64-step bisection stalls on a bf16 neighbour of the root, e.g. sum(ps) = 459.35 for k = 460).  xs [B, N] float32 (rounded
- * to bf16 on entry) -> ps, ts float32 holding bf16 values: the reference's last_combined_scores (:190) bit for bit on the same
- * scores (tests/golden/lisbf16_*.npz).  Opt-in (selector attribute soft_topk_bf16_reference); the default returns the fp32 root. */
+ * to bf16 on entry) -> ps, ts float32 holding bf16 values: the reference's last_combined_scores (:190) on the same
+ * scores: ts bit for bit on every fixture (tests/golden/lisbf16_*.npz); ps bit for bit but for isolated elements (<= 2 per fixture)
+ * one bf16 step apart, where the fp32 sigmoid sits on a bf16 rounding boundary (device expf vs libm).  Opt-in (selector attribute soft_topk_bf16_reference); the default returns the fp32 root. */
 int vsel_soft_topk_fwd_bf16ref(void* stream, const float* xs, int64_t b, int64_t n, int64_t k, float* ps, float* ts);
 /* TopK.backward (FT/compression_method/selector_model.py:60-70).                                  */
 int vsel_soft_topk_bwd(void* stream, const float* grad_ps, const float* xs, const float* ts, int64_t b, int64_t n,

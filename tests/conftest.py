@@ -21,3 +21,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN_DIR
+
+
+def pytest_collection_modifyitems(config, items):
+    """Harness-contract tests (bench.py subprocesses) run LAST: under `pytest -x` a failure there must not hide the parity tests
+    (round 5's driver record lost 201 tests behind tests/test_bench_gpu.py, which sorts in front of every LIS / training / splice file)."""
+    last = [it for it in items if os.path.basename(str(it.fspath)) == "test_bench_gpu.py"]
+    if last:
+        items[:] = [it for it in items if it not in last] + last

@@ -25,7 +25,14 @@ def _run_bench(*args, timeout=900):
 def test_bench_line_one_gpu_small():
     res = _run_bench("--steps", "3", "--warmup", "1", "--images", "8", "--no-cpu-baseline", "--no-attn", "--no-llm", "--no-train")
     assert res["metric"] == "vision_tokens_scored_selected_per_sec" and res["n_gpus"] == 1 and res["steps"] == 3
-    assert res["value"] > 0 and res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1
+    rf = res["roofline"]
+    # frac is ALWAYS a number (round 5's driver run died here on None: the clock had named a helper kernel without a byte model); at 8
+    # images the step is host-bound and tokens re-read out of the Infinity Cache can beat the HBM figure, so only the sign is pinned here
+    assert res["value"] > 0 and rf["bound"] == "hbm" and isinstance(rf["frac"], float) and rf["frac"] > 0
+    assert isinstance(rf["host_bound_step"], bool)
+    for name, row in res["kernels"].items():
+        assert row["algorithmic_bytes_per_launch"], f"kernel {name} of the step has no byte model in bench.kernel_bytes"
+        assert row["avg_us"] > 0
     p = res["parity"]
     assert p["idx_equal_fp64_oracle"] and p["idx_equal_own_scores"] and p["gather_exact"]
 

@@ -774,23 +774,23 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
   const int g_tail = knob(VSEL_KNOB_ATTN_TAIL_FIRST);
   const bool tail_first = causal && !pack && !split2 && d == 128 && g_attn_use_tr && (g_tail == 1 || (g_tail < 0 && !big && n_items > 2 * slots));
 #define VSEL_ATTN_LAUNCH(TR, NWV, DV)                                                                                          \
-  hipLaunchKernelGGL((varlen_attn_fwd_kernel<TR, NWV, DV>), grid, dim3(64 * NWV), 0, st, (const uint16_t*)q, (const uint16_t*)k, \
+  VSEL_LAUNCH((varlen_attn_fwd_kernel<TR, NWV, DV>), grid, dim3(64 * NWV), 0, st, (const uint16_t*)q, (const uint16_t*)k, \
                      (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg, lse)
   if (split2_q64) {
-    hipLaunchKernelGGL((varlen_attn_fwd_kernel<true, 8, 128, false, 2, 2>), grid, dim3(512), 0, st, (const uint16_t*)q,
+    VSEL_LAUNCH((varlen_attn_fwd_kernel<true, 8, 128, false, 2, 2>), grid, dim3(512), 0, st, (const uint16_t*)q,
                        (const uint16_t*)k, (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles,
                        (int)n_seq, slot, pg, lse);
   } else if (split2) {
-    hipLaunchKernelGGL((varlen_attn_fwd_kernel<true, 8, 128, false, 2>), grid, dim3(512), 0, st, (const uint16_t*)q,
+    VSEL_LAUNCH((varlen_attn_fwd_kernel<true, 8, 128, false, 2>), grid, dim3(512), 0, st, (const uint16_t*)q,
                        (const uint16_t*)k, (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles,
                        (int)n_seq, slot, pg, lse);
   } else if (pack) {
-    hipLaunchKernelGGL((varlen_attn_fwd_kernel<true, 1, 128, true>), grid, dim3(64), 0, st, (const uint16_t*)q, (const uint16_t*)k,
+    VSEL_LAUNCH((varlen_attn_fwd_kernel<true, 1, 128, true>), grid, dim3(64), 0, st, (const uint16_t*)q, (const uint16_t*)k,
                        (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles, (int)n_seq, slot, pg, lse);
   } else if (d == 128) {
     if (g_attn_use_tr && tail_first) {
 #define VSEL_ATTN_LAUNCH_TAIL(NWV)                                                                                                  \
-  hipLaunchKernelGGL((varlen_attn_fwd_kernel<true, NWV, 128, false, 1, 1, true>), grid, dim3(64 * NWV), 0, st, (const uint16_t*)q, \
+  VSEL_LAUNCH((varlen_attn_fwd_kernel<true, NWV, 128, false, 1, 1, true>), grid, dim3(64 * NWV), 0, st, (const uint16_t*)q, \
                      (const uint16_t*)k, (const uint16_t*)v, cu_q, (int)hq, (int)hkv, sl2, causal, (uint16_t*)out, q_tiles,        \
                      (int)n_seq, slot, pg, lse)
       if (big) VSEL_ATTN_LAUNCH_TAIL(8); else VSEL_ATTN_LAUNCH_TAIL(4);

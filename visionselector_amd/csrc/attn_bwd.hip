@@ -1083,7 +1083,7 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
     if (n_items >= (1ll << 31)) return fail(VSEL_ERR_UNSUPPORTED, "too many attention work items");
     int slot, taken;
     if (int rc = take_slot(n_items, 512, slot, taken)) return rc;
-    hipLaunchKernelGGL(bwd::attn_bwd_dq_kernel, dim3((unsigned)std::min<int64_t>(n_items, 512)), dim3(256), 0, st,
+    VSEL_LAUNCH(bwd::attn_bwd_dq_kernel, dim3((unsigned)std::min<int64_t>(n_items, 512)), dim3(256), 0, st,
                        (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, (const uint16_t*)out, lse, dvec, lse2,
                        cu_seqlens,
                        (int)hq, (int)hkv, scale, causal, (uint16_t*)dq, q_tiles, (int)n_seq, slot, xcd_local_dq);
@@ -1114,11 +1114,11 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
 #define VSEL_DKDV_ARGS (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu_seqlens, (int)hq, \
                          (int)hkv, scale, causal, (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, k_blocks, (int)n_seq, slot, xcd_local_dkdv
       if (w8) {
-        if (split) hipLaunchKernelGGL((bwd::attn_bwd_dkdv2_kernel<true>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS, split_heads);
-        else hipLaunchKernelGGL((bwd::attn_bwd_dkdv2_kernel<false>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS, 0);
+        if (split) VSEL_LAUNCH((bwd::attn_bwd_dkdv2_kernel<true>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS, split_heads);
+        else VSEL_LAUNCH((bwd::attn_bwd_dkdv2_kernel<false>), grid, dim3(512), 0, st, VSEL_DKDV_ARGS, 0);
       } else {
-        if (split) hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<true>), grid, dim3(256), 0, st, VSEL_DKDV_ARGS);
-        else hipLaunchKernelGGL((bwd::attn_bwd_dkdv_kernel<false>), grid, dim3(256), 0, st, VSEL_DKDV_ARGS);
+        if (split) VSEL_LAUNCH((bwd::attn_bwd_dkdv_kernel<true>), grid, dim3(256), 0, st, VSEL_DKDV_ARGS);
+        else VSEL_LAUNCH((bwd::attn_bwd_dkdv_kernel<false>), grid, dim3(256), 0, st, VSEL_DKDV_ARGS);
       }
 #undef VSEL_DKDV_ARGS
       queue_slot_launched(kSlotBwd, taken, st);
@@ -1126,7 +1126,7 @@ extern "C" int vsel_varlen_attn_bwd(void* stream, const void* dout, const void* 
     }
     if (split) {
       // rows past a sequence's end never exist in the packed layout, so every (t, h) partial row was written
-      hipLaunchKernelGGL(bwd::attn_bwd_group_sum_kernel, dim3((unsigned)cdiv(total * hkv * 32, 256)), dim3(256), 0, st, dk_part,
+      VSEL_LAUNCH(bwd::attn_bwd_group_sum_kernel, dim3((unsigned)cdiv(total * hkv * 32, 256)), dim3(256), 0, st, dk_part,
                          dv_part, total, (int)hq, (int)hkv, scale, (uint16_t*)dk, (uint16_t*)dv, split_heads);
       VSEL_AFTER_LAUNCH(st, "attn_bwd_group_sum_kernel");
     }

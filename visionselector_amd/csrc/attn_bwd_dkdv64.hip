@@ -136,7 +136,7 @@ int dkdv64_launch(hipStream_t st, const void* q, const void* k, const void* v, c
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_dkdv64_work_counter)));
     VSEL_HIP_CHECK(hipMemsetAsync(counters + 8 * slot, 0, 8 * sizeof(int), st));
   }
-  hipLaunchKernelGGL(attn_bwd_dkdv64_kernel, dim3((unsigned)std::min<int64_t>(n_items, 256)), dim3(256), 0, st, (const uint16_t*)q,
+  VSEL_LAUNCH(attn_bwd_dkdv64_kernel, dim3((unsigned)std::min<int64_t>(n_items, 256)), dim3(256), 0, st, (const uint16_t*)q,
                      (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse2, dvec, cu, (int)hq, (int)hkv, scale,
                      scale * 1.4426950408889634f, causal, (uint16_t*)dk, (uint16_t*)dv, dk_part, dv_part, split, k_blocks, (int)n_seq, slot,
                      xcd_local);

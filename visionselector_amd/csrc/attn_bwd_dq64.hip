@@ -148,7 +148,7 @@ int dq64_launch(hipStream_t st, const void* q, const void* k, const void* v, con
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_dq64_work_counter)));
     VSEL_HIP_CHECK(hipMemsetAsync(counters + 8 * slot, 0, 8 * sizeof(int), st));
   }
-  hipLaunchKernelGGL(attn_bwd_dq64_kernel, dim3((unsigned)std::min<int64_t>(n_items, 256)), dim3(256), 0, st, (const uint16_t*)q,
+  VSEL_LAUNCH(attn_bwd_dq64_kernel, dim3((unsigned)std::min<int64_t>(n_items, 256)), dim3(256), 0, st, (const uint16_t*)q,
                      (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, (const uint16_t*)out, lse, dvec, lse2, cu, (int)hq, (int)hkv,
                      scale, scale * 1.4426950408889634f, causal, (uint16_t*)dq, q_tiles, (int)n_seq, slot, xcd_local);
   queue_slot_launched(kSlotDq64, taken, st);

@@ -202,7 +202,7 @@ int attn_fwd64_parts_launch(hipStream_t st, const void* q, const void* k, const 
   float* opart = (float*)ws;
   float* ml = opart + (size_t)plan.max_parts * (size_t)(n_seq * len) * (size_t)hq * kHeadDimP;
   const dim3 grid((unsigned)std::min(plan.n_items, 256));
-  hipLaunchKernelGGL(attn_fwd64_parts_kernel, grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (int)len, (int)hq,
+  VSEL_LAUNCH(attn_fwd64_parts_kernel, grid, dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (int)len, (int)hq,
                      (int)hkv, scale * 1.4426950408889634f, (uint16_t*)out, (int)n_seq, plan, opart, ml, lse);
   VSEL_AFTER_LAUNCH(st, "attn_fwd64_parts_kernel");
   // rows of the split tiles: the LAST query tiles (levels 0 .. s - 1 are split, parts_of is monotone in the tile's key count)
@@ -215,7 +215,7 @@ int attn_fwd64_parts_launch(hipStream_t st, const void* q, const void* k, const 
   const int first_split_row = (plan.q_tiles - split_levels) * kBlockQP;
   const int split_rows = (int)len - first_split_row;
   const int64_t waves = (int64_t)split_rows * hq * n_seq;
-  hipLaunchKernelGGL(attn_fwd64_merge_kernel, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, opart, ml, (int)len, (int)hq, (int)n_seq, plan,
+  VSEL_LAUNCH(attn_fwd64_merge_kernel, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, opart, ml, (int)len, (int)hq, (int)n_seq, plan,
                      first_split_row, split_rows, (uint16_t*)out, lse);
   VSEL_AFTER_LAUNCH(st, "attn_fwd64_merge_kernel");
   return VSEL_OK;

@@ -624,7 +624,7 @@ int attn_fwd_gqa_launch(hipStream_t st, const void* q, const void* k, const void
     VSEL_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(counters + slot), 2 * grid, 1, st));     // (two rounds are dealt: items b and 2 G - 1 - b)
     counter = counters + slot;
   }
-  hipLaunchKernelGGL(attn_fwd_gqa_kernel, dim3(grid), dim3(512), 0, st, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, cu_q,
+  VSEL_LAUNCH(attn_fwd_gqa_kernel, dim3(grid), dim3(512), 0, st, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, cu_q,
                      (int)hq, (int)hkv, scale * 1.4426950408889634f, causal, (uint16_t*)out, (int)q_tiles, (int)n_seq, counter, pg, lse);
   if (!deal) queue_slot_launched(kSlotGqa, slot, st);
   VSEL_AFTER_LAUNCH(st, "attn_fwd_gqa_kernel");

@@ -259,7 +259,7 @@ int attn_fwd_gqa64_launch(hipStream_t st, const void* q, const void* k, const vo
     counter = counters + 8 * taken;
     VSEL_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)counter, 2 * grid, 1, st));     // workgroup b starts with items b and 2 G - 1 - b
   }
-  hipLaunchKernelGGL(attn_fwd_gqa64_kernel, dim3(grid), dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, cu_q,
+  VSEL_LAUNCH(attn_fwd_gqa64_kernel, dim3(grid), dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, cu_q,
                      (int)hq, (int)hkv, scale * 1.4426950408889634f, causal, (uint16_t*)out, q_tiles, (int)n_seq, counter, static_deal, pg, lse);
   queue_slot_launched(kSlotGqa, taken, st);
   VSEL_AFTER_LAUNCH(st, "attn_fwd_gqa64_kernel");

@@ -96,6 +96,14 @@ void prof_mark(hipStream_t st, const char* name);   // event AFTER the named ker
   do {                                                                                    \
     if (::vsel::prof_enabled()) ::vsel::prof_mark((hipStream_t)(st), "<begin>");          \
   } while (0)
+// Every kernel launch of the library goes through this: while the profiler is on, a "<begin>" event is recorded on the launch
+// stream right in front of the kernel, so that the interval booked to the kernel (begin mark -> the mark VSEL_AFTER_LAUNCH records)
+// holds the kernel and two marker packets, NOT the host time that passed since the previous launch was enqueued.
+#define VSEL_LAUNCH(kernel, grid, block, lds_bytes, st, ...)                              \
+  do {                                                                                    \
+    if (::vsel::prof_enabled()) ::vsel::prof_mark((hipStream_t)(st), "<begin>");          \
+    hipLaunchKernelGGL(kernel, grid, block, lds_bytes, st, __VA_ARGS__);                  \
+  } while (0)
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

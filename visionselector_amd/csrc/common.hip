@@ -140,8 +140,10 @@ void queue_slot_launched(int, int, hipStream_t) {}      // (nothing to record: o
 }  // namespace vsel
 
 namespace vsel {
-// Per-kernel timing with HIP events recorded on the launch stream between kernels.  Off by default;
-// bench.py turns it on for the timed region.  Single-threaded use (one process per GPU).
+// Per-kernel timing with HIP events on the launch stream: VSEL_LAUNCH records a "<begin>" mark in front of every kernel and
+// VSEL_AFTER_LAUNCH the named mark behind it; a kernel's time is the interval between the two (the host gap since the previous
+// launch is in front of the begin mark and is not booked to anybody).  Off by default; bench.py turns it on for an instrumented
+// repeat of the timed region.  Single-threaded use (one process per GPU).
 struct Profiler {
   bool on = false;
   std::vector<hipEvent_t> pool;
@@ -162,6 +164,13 @@ void prof_mark(hipStream_t st, const char* name) {
 }  // namespace vsel
 
 extern "C" int vsel_profile_start(void) {
+  // the event pool is created HERE (and kept for the life of the process), never inside an interval it times: a hipEventCreate on
+  // the first instrumented pass used to land between two marks and was booked to whatever kernel came next
+  while (vsel::g_prof.pool.size() < 4096) {
+    hipEvent_t e;
+    VSEL_HIP_CHECK(hipEventCreate(&e));
+    vsel::g_prof.pool.push_back(e);
+  }
   vsel::g_prof.marks.clear();
   vsel::g_prof.on = true;
   return VSEL_OK;

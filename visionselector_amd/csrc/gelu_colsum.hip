@@ -254,7 +254,7 @@ extern "C" int vsel_gelu_colsum(void* stream, const void* x, vsel_dtype dtype, c
   const bool nt = seg->total_rows * cols * (dtype == VSEL_BF16 ? 2 : 4) >= kStreamBytes;   // (from 16 / 64 MB up: no difference)
   const dim3 grid((unsigned)cdiv(cols, 64 * vec), row_splits, S);
 #define VSEL_GELU_LAUNCH(T, NTV, SUMSV)                                                                                          \
-  hipLaunchKernelGGL((gelu_colsum_kernel<T, NTV, SUMSV>), grid, dim3(256), 0, st, (const T*)x, sv, (int)cols, row_splits, rows_per_wg, \
+  VSEL_LAUNCH((gelu_colsum_kernel<T, NTV, SUMSV>), grid, dim3(256), 0, st, (const T*)x, sv, (int)cols, row_splits, rows_per_wg, \
                      (T*)y, partial)
   const bool sums = col_sums != nullptr;
   if (dtype == VSEL_BF16) {
@@ -267,7 +267,7 @@ extern "C" int vsel_gelu_colsum(void* stream, const void* x, vsel_dtype dtype, c
 #undef VSEL_GELU_LAUNCH
   VSEL_AFTER_LAUNCH(st, sums ? "gelu_colsum_kernel" : "gelu_kernel");
   if (!sums) return VSEL_OK;
-  hipLaunchKernelGGL(gelu_colsum_finish_kernel, dim3((unsigned)cdiv(cols, 64), S), dim3(1024), 0, st, partial, (int)cols, row_splits,
+  VSEL_LAUNCH(gelu_colsum_finish_kernel, dim3((unsigned)cdiv(cols, 64), S), dim3(1024), 0, st, partial, (int)cols, row_splits,
                      col_sums);
   VSEL_AFTER_LAUNCH(st, "gelu_colsum_finish_kernel");
   return VSEL_OK;
@@ -302,10 +302,10 @@ extern "C" int vsel_colsum_linear(void* stream, const float* col_sums_in, const 
       if (seg->seg_rows) svc.seg_rows = seg->seg_rows + s0;          // n_rows(s) of the chunk's segments
       const dim3 grid((unsigned)cdiv(cout, 4));
       if (wdtype == VSEL_BF16)
-        hipLaunchKernelGGL((colsum_linear_small_kernel<bf16_t>), grid, dim3(256), 0, st, col_sums_in + (int64_t)s0 * cin,
+        VSEL_LAUNCH((colsum_linear_small_kernel<bf16_t>), grid, dim3(256), 0, st, col_sums_in + (int64_t)s0 * cin,
                            (const bf16_t*)weight, (const bf16_t*)bias, svc, sc, (int)cin, (int)cout, col_sums_out + (int64_t)s0 * cout);
       else
-        hipLaunchKernelGGL((colsum_linear_small_kernel<float>), grid, dim3(256), 0, st, col_sums_in + (int64_t)s0 * cin,
+        VSEL_LAUNCH((colsum_linear_small_kernel<float>), grid, dim3(256), 0, st, col_sums_in + (int64_t)s0 * cin,
                            (const float*)weight, (const float*)bias, svc, sc, (int)cin, (int)cout, col_sums_out + (int64_t)s0 * cout);
       VSEL_AFTER_LAUNCH(st, "colsum_linear_small_kernel");
     }
@@ -318,13 +318,13 @@ extern "C" int vsel_colsum_linear(void* stream, const float* col_sums_in, const 
   float* slabs = (float*)((char*)workspace + p.off_slabs);
   const unsigned mtiles = (unsigned)(p.m_pad / 32);
   // planes of in[s][.] / N_s (row_splits = 1: the "partials" are the sums themselves); rows m >= S of a tile are never read back
-  hipLaunchKernelGGL(colsum_finish_split_kernel, dim3((unsigned)cdiv(cin, 256), S), dim3(256), 0, st, col_sums_in, sv, (int)cin, 1, S,
+  VSEL_LAUNCH(colsum_finish_split_kernel, dim3((unsigned)cdiv(cin, 256), S), dim3(256), 0, st, col_sums_in, sv, (int)cin, 1, S,
                      planes);
   VSEL_AFTER_LAUNCH(st, "colsum_finish_split_kernel");
-  hipLaunchKernelGGL(gemm_nt_bf16x3_kernel<kProjWaves>, dim3((unsigned)cdiv(cout, 64), (unsigned)cdiv(mtiles, kProjWaves), p.ks), dim3(64 * kProjWaves), 0, st, planes,
+  VSEL_LAUNCH(gemm_nt_bf16x3_kernel<kProjWaves>, dim3((unsigned)cdiv(cout, 64), (unsigned)cdiv(mtiles, kProjWaves), p.ks), dim3(64 * kProjWaves), 0, st, planes,
                      (const uint16_t*)weight, S, (int)cout, (int)cin, p.kslice, slabs, (int)mtiles);
   VSEL_AFTER_LAUNCH(st, "gemm_nt_bf16x3_kernel");
-  hipLaunchKernelGGL(colsum_linear_finish_kernel, dim3(mtiles, (unsigned)cdiv(cout, 8)), dim3(256), 0, st, slabs, p.ks, S, (int)cout,
+  VSEL_LAUNCH(colsum_linear_finish_kernel, dim3(mtiles, (unsigned)cdiv(cout, 8)), dim3(256), 0, st, slabs, p.ks, S, (int)cout,
                      p.m_pad, (const uint16_t*)bias, sv, col_sums_out);
   VSEL_AFTER_LAUNCH(st, "colsum_linear_finish_kernel");
   return VSEL_OK;

@@ -951,13 +951,13 @@ inline int launch_score(hipStream_t st, const T* h, const SegView& sv, const vse
   const int iters = (d % (64 * V) == 0) ? d / (64 * V) : 0;
 #define VSEL_SCORE_CASE(I)                                                                              \
   case I:                                                                                               \
-    if (nt) hipLaunchKernelGGL((score_kernel<T, I, true>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores, out_map);  \
-    else hipLaunchKernelGGL((score_kernel<T, I, false>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores, out_map);    \
+    if (nt) VSEL_LAUNCH((score_kernel<T, I, true>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores, out_map);  \
+    else VSEL_LAUNCH((score_kernel<T, I, false>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores, out_map);    \
     break;
   switch (iters) {
     VSEL_SCORE_CASE(1) VSEL_SCORE_CASE(2) VSEL_SCORE_CASE(3) VSEL_SCORE_CASE(4)
     VSEL_SCORE_CASE(5) VSEL_SCORE_CASE(6) VSEL_SCORE_CASE(7) VSEL_SCORE_CASE(8)
-    default: hipLaunchKernelGGL((score_kernel<T, 0, false>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores, out_map);
+    default: VSEL_LAUNCH((score_kernel<T, 0, false>), grid, dim3(256), 0, st, h, sv, d, w, c, sq, (int)rpb, scores, out_map);
   }
 #undef VSEL_SCORE_CASE
   VSEL_AFTER_LAUNCH(st, "score_kernel");
@@ -994,8 +994,8 @@ inline int launch_colsum(hipStream_t st, const T* h, const SegView& sv, int d, i
     const bool nt = stream_policy(total_rows, d, sizeof(T));
 #define VSEL_SEG_LAUNCH(NWV)                                                                                                    \
     do {                                                                                                                        \
-      if (nt) hipLaunchKernelGGL((colsum_seg_kernel<T, true, NWV>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial, xs); \
-      else hipLaunchKernelGGL((colsum_seg_kernel<T, false, NWV>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial, xs);   \
+      if (nt) VSEL_LAUNCH((colsum_seg_kernel<T, true, NWV>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial, xs); \
+      else VSEL_LAUNCH((colsum_seg_kernel<T, false, NWV>), g2, dim3(256), 0, st, h, sv, d, col_tiles, S, partial, xs);   \
     } while (0)
     if (nw == 4) VSEL_SEG_LAUNCH(4); else if (nw == 2) VSEL_SEG_LAUNCH(2); else VSEL_SEG_LAUNCH(1);
 #undef VSEL_SEG_LAUNCH
@@ -1004,11 +1004,11 @@ inline int launch_colsum(hipStream_t st, const T* h, const SegView& sv, int d, i
   }
   const dim3 grid((unsigned)cdiv(d, 64 * V), row_splits, S);
   if ((int64_t)grid.x * grid.y * grid.z <= 1024)       // <= one workgroup per SIMD-quad: latency-bound, use the deep form
-    hipLaunchKernelGGL((colsum_partial_kernel<T, false, true>), grid, dim3(256), 0, st, h, sv, d, row_splits, partial);
+    VSEL_LAUNCH((colsum_partial_kernel<T, false, true>), grid, dim3(256), 0, st, h, sv, d, row_splits, partial);
   else if (stream_policy(total_rows, d, sizeof(T)))
-    hipLaunchKernelGGL((colsum_partial_kernel<T, true>), grid, dim3(256), 0, st, h, sv, d, row_splits, partial);
+    VSEL_LAUNCH((colsum_partial_kernel<T, true>), grid, dim3(256), 0, st, h, sv, d, row_splits, partial);
   else
-    hipLaunchKernelGGL((colsum_partial_kernel<T, false>), grid, dim3(256), 0, st, h, sv, d, row_splits, partial);
+    VSEL_LAUNCH((colsum_partial_kernel<T, false>), grid, dim3(256), 0, st, h, sv, d, row_splits, partial);
   VSEL_AFTER_LAUNCH(st, "colsum_partial_kernel");
   return VSEL_OK;
 }
@@ -1044,41 +1044,41 @@ inline int run_proj(hipStream_t st, const vsel_segments* seg, const vsel_scorer*
       uint16_t* ksp = (uint16_t*)(ws + p.off_ksp);
       float* cpart = (float*)(ws + p.off_cpart);
       if (col_sums || !seg_sums_form(p_in, seg)) {       // (colsum_seg_kernel leaves the planes itself)
-        hipLaunchKernelGGL(colsum_finish_split_kernel, dim3((unsigned)cdiv(d, 256), S), dim3(256), 0, st, partial, sv, d,
+        VSEL_LAUNCH(colsum_finish_split_kernel, dim3((unsigned)cdiv(d, 256), S), dim3(256), 0, st, partial, sv, d,
                            p.row_splits, S, xs);
         VSEL_AFTER_LAUNCH(st, "colsum_finish_split_kernel");
       }
       const unsigned mtiles = (unsigned)cdiv(S, 32);
       const int m_pad = 32 * (int)mtiles;
-      hipLaunchKernelGGL(gemm_nt_bf16x3_kernel<kProjWaves>, dim3((unsigned)cdiv(hd, 64), (unsigned)cdiv(mtiles, kProjWaves), p.ks1), dim3(64 * kProjWaves), 0, st, xs,
+      VSEL_LAUNCH(gemm_nt_bf16x3_kernel<kProjWaves>, dim3((unsigned)cdiv(hd, 64), (unsigned)cdiv(mtiles, kProjWaves), p.ks1), dim3(64 * kProjWaves), 0, st, xs,
                          (const uint16_t*)sc->wk, S, hd, d, p.kslice1, part1, (int)mtiles);
       VSEL_AFTER_LAUNCH(st, "gemm_nt_bf16x3_kernel");
-      hipLaunchKernelGGL(kbar_finish_split_kernel, dim3(mtiles, p.n_cpart), dim3(256), 0, st, part1, p.ks1, S, hd, m_pad,
+      VSEL_LAUNCH(kbar_finish_split_kernel, dim3(mtiles, p.n_cpart), dim3(256), 0, st, part1, p.ks1, S, hd, m_pad,
                          (const uint16_t*)sc->bk, (const uint16_t*)sc->bq, kbar, ksp, cpart);
       VSEL_AFTER_LAUNCH(st, "kbar_finish_split_kernel");
-      hipLaunchKernelGGL(gemm_nn_bf16x3_kernel<kProjWaves>, dim3((unsigned)cdiv(d, 256), (unsigned)cdiv(mtiles, kProjWaves), p.ks2), dim3(64 * kProjWaves), 0, st, ksp,
+      VSEL_LAUNCH(gemm_nn_bf16x3_kernel<kProjWaves>, dim3((unsigned)cdiv(d, 256), (unsigned)cdiv(mtiles, kProjWaves), p.ks2), dim3(64 * kProjWaves), 0, st, ksp,
                          (const uint16_t*)sc->wq, S, d, hd, p.kslice2, part2, (int)mtiles);
       VSEL_AFTER_LAUNCH(st, "gemm_nn_bf16x3_kernel");
-      hipLaunchKernelGGL(w_finish_kernel, dim3(mtiles, (unsigned)cdiv(d, 8)), dim3(256), 0, st, part2, p.ks2, S, d, m_pad,
+      VSEL_LAUNCH(w_finish_kernel, dim3(mtiles, (unsigned)cdiv(d, 8)), dim3(256), 0, st, part2, p.ks2, S, d, m_pad,
                          cpart, p.n_cpart, w, c);
       VSEL_AFTER_LAUNCH(st, "w_finish_kernel");
       return VSEL_OK;
     }
   }
   // generic path: fp32-input MFMA (fp32 weights, or K not a multiple of 16)
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)cdiv(d, 256), S), dim3(256), 0, st, partial, sv, d,
+  VSEL_LAUNCH(colsum_finish_kernel, dim3((unsigned)cdiv(d, 256), S), dim3(256), 0, st, partial, sv, d,
                      p.row_splits, xbar);
   VSEL_AFTER_LAUNCH(st, "colsum_finish_kernel");
-  hipLaunchKernelGGL((gemm_nt_kernel<TW>), dim3((unsigned)cdiv(hd, 32), (unsigned)cdiv(S, 32), p.ks1), dim3(64), 0, st,
+  VSEL_LAUNCH((gemm_nt_kernel<TW>), dim3((unsigned)cdiv(hd, 32), (unsigned)cdiv(S, 32), p.ks1), dim3(64), 0, st,
                      xbar, (const TW*)sc->wk, S, hd, d, p.kslice1, part1);
   VSEL_AFTER_LAUNCH(st, "gemm_nt_kernel");
-  hipLaunchKernelGGL((kbar_finish_kernel<TW>), dim3(S), dim3(256), 0, st, part1, p.ks1, S, hd, (const TW*)sc->bk,
+  VSEL_LAUNCH((kbar_finish_kernel<TW>), dim3(S), dim3(256), 0, st, part1, p.ks1, S, hd, (const TW*)sc->bk,
                      (const TW*)sc->bq, kbar, c);
   VSEL_AFTER_LAUNCH(st, "kbar_finish_kernel");
-  hipLaunchKernelGGL((gemm_nn_kernel<TW>), dim3((unsigned)cdiv(d, 256), (unsigned)cdiv(S, 32), p.ks2), dim3(64), 0, st,
+  VSEL_LAUNCH((gemm_nn_kernel<TW>), dim3((unsigned)cdiv(d, 256), (unsigned)cdiv(S, 32), p.ks2), dim3(64), 0, st,
                      kbar, (const TW*)sc->wq, S, d, hd, p.kslice2, part2);
   VSEL_AFTER_LAUNCH(st, "gemm_nn_kernel");
-  hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)cdiv((int64_t)S * d, 256)), dim3(256), 0, st, part2, p.ks2,
+  VSEL_LAUNCH(slice_sum_kernel, dim3((unsigned)cdiv((int64_t)S * d, 256)), dim3(256), 0, st, part2, p.ks2,
                      (int64_t)S * d, w);
   VSEL_AFTER_LAUNCH(st, "slice_sum_kernel");
   return VSEL_OK;
@@ -1112,11 +1112,11 @@ inline int run_scores_w(hipStream_t st, const T* h, const vsel_segments* seg, co
 inline int launch_select(hipStream_t st, const float* scores, const vsel_segments* seg, int64_t* idx, float* mask) {
   const int64_t maxn = seg->rows_per_seg;            // (= the longest segment for ragged calls)
   if (maxn <= 4 * 1024)
-    hipLaunchKernelGGL(topk_select_reg_kernel<4>, dim3((unsigned)seg->n_seg), dim3(1024), 0, st, scores, make_view(seg), idx, mask);
+    VSEL_LAUNCH(topk_select_reg_kernel<4>, dim3((unsigned)seg->n_seg), dim3(1024), 0, st, scores, make_view(seg), idx, mask);
   else if (maxn <= 16 * 1024)
-    hipLaunchKernelGGL(topk_select_reg_kernel<16>, dim3((unsigned)seg->n_seg), dim3(1024), 0, st, scores, make_view(seg), idx, mask);
+    VSEL_LAUNCH(topk_select_reg_kernel<16>, dim3((unsigned)seg->n_seg), dim3(1024), 0, st, scores, make_view(seg), idx, mask);
   else
-    hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)seg->n_seg), dim3(1024), 0, st, scores, make_view(seg), idx, mask);
+    VSEL_LAUNCH(topk_select_kernel, dim3((unsigned)seg->n_seg), dim3(1024), 0, st, scores, make_view(seg), idx, mask);
   VSEL_AFTER_LAUNCH(st, "topk_select_kernel");
   return VSEL_OK;
 }
@@ -1132,15 +1132,15 @@ inline int launch_gather(hipStream_t st, const T* h, int d, const vsel_segments*
   const int iters = ( d % (64 * V) == 0 && d / (64 * V) <= 8) ? d / (64 * V) : 0;
 #define VSEL_GATHER_CASE(I)                                                                                                   \
   case I:                                                                                                                     \
-    if (nt) hipLaunchKernelGGL((gather_rows_kernel<T, true, I>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map); \
-    else hipLaunchKernelGGL((gather_rows_kernel<T, false, I>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map);   \
+    if (nt) VSEL_LAUNCH((gather_rows_kernel<T, true, I>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map); \
+    else VSEL_LAUNCH((gather_rows_kernel<T, false, I>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map);   \
     break;
   switch (iters) {
     VSEL_GATHER_CASE(1) VSEL_GATHER_CASE(2) VSEL_GATHER_CASE(3) VSEL_GATHER_CASE(4)
     VSEL_GATHER_CASE(5) VSEL_GATHER_CASE(6) VSEL_GATHER_CASE(7) VSEL_GATHER_CASE(8)
     default:
-      if (nt) hipLaunchKernelGGL((gather_rows_kernel<T, true, 0>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map);
-      else hipLaunchKernelGGL((gather_rows_kernel<T, false, 0>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map);
+      if (nt) VSEL_LAUNCH((gather_rows_kernel<T, true, 0>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map);
+      else VSEL_LAUNCH((gather_rows_kernel<T, false, 0>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map);
   }
 #undef VSEL_GATHER_CASE
   VSEL_AFTER_LAUNCH(st, "gather_rows_kernel");

@@ -583,10 +583,10 @@ inline int run_proj_small(hipStream_t st, const vsel_segments* seg, const vsel_s
   float* part1 = (float*)(ws + p.off_part1);
   float* part2 = (float*)(ws + p.off_part2);
   float* cpart = (float*)(ws + p.off_cpart);
-  hipLaunchKernelGGL(proj_nt_small_kernel, dim3((unsigned)cdiv(hd, 32), p.ks1), dim3(64), 0, st, partial, make_view(seg), S,
+  VSEL_LAUNCH(proj_nt_small_kernel, dim3((unsigned)cdiv(hd, 32), p.ks1), dim3(64), 0, st, partial, make_view(seg), S,
                      row_splits, (const uint16_t*)sc->wk, hd, d, p.kslice1, part1, (int64_t)d, 1);
   VSEL_AFTER_LAUNCH(st, "proj_nt_small_kernel");
-  hipLaunchKernelGGL(proj_nn_small_kernel, dim3((unsigned)cdiv(d, 128), p.ks2), dim3(64), 0, st, part1, p.ks1, S,
+  VSEL_LAUNCH(proj_nn_small_kernel, dim3((unsigned)cdiv(d, 128), p.ks2), dim3(64), 0, st, part1, p.ks1, S,
                      (const uint16_t*)sc->bk, (const uint16_t*)sc->bq, (const uint16_t*)sc->wq, d, hd, p.kslice2, part2, cpart,
                      p.n_cpart);
   VSEL_AFTER_LAUNCH(st, "proj_nn_small_kernel");
@@ -610,14 +610,14 @@ inline int run_score_small(hipStream_t st, const T* h, const vsel_segments* seg,
   const int iters = (d % (64 * V) == 0) ? d / (64 * V) : 0;
 #define VSEL_SCORE_SMALL_CASE(I)                                                                                          \
   case I:                                                                                                                 \
-    hipLaunchKernelGGL((score_small_kernel<T, I>), grid, dim3(kSmallScoreThreads), lds, st, h, make_view(seg), d, S, part2, p.ks2, cpart, \
+    VSEL_LAUNCH((score_small_kernel<T, I>), grid, dim3(kSmallScoreThreads), lds, st, h, make_view(seg), d, S, part2, p.ks2, cpart, \
                        p.n_cpart, sq, (int)rpb, scores, out_map);                                                         \
     break;
   switch (iters) {
     VSEL_SCORE_SMALL_CASE(1) VSEL_SCORE_SMALL_CASE(2) VSEL_SCORE_SMALL_CASE(3) VSEL_SCORE_SMALL_CASE(4)
     VSEL_SCORE_SMALL_CASE(5) VSEL_SCORE_SMALL_CASE(6) VSEL_SCORE_SMALL_CASE(7) VSEL_SCORE_SMALL_CASE(8)
     default:
-      hipLaunchKernelGGL((score_small_kernel<T, 0>), grid, dim3(kSmallScoreThreads), lds, st, h, make_view(seg), d, S, part2, p.ks2, cpart,
+      VSEL_LAUNCH((score_small_kernel<T, 0>), grid, dim3(kSmallScoreThreads), lds, st, h, make_view(seg), d, S, part2, p.ks2, cpart,
                          p.n_cpart, sq, (int)rpb, scores, out_map);
   }
 #undef VSEL_SCORE_SMALL_CASE
@@ -640,9 +640,9 @@ inline int launch_select_gather_small(hipStream_t st, const T* h, int d, const v
   const dim3 grid((unsigned)cdiv(seg->k, rpb), (unsigned)seg->n_seg);
   const SegView sv = make_view(seg);
   if (maxn <= 12 * kSmallSelectThreads)
-    hipLaunchKernelGGL((select_gather_small_kernel<T, 12>), grid, dim3(256), 0, st, h, scores, sv, d, idx, out, (int)rpb, src_map);
+    VSEL_LAUNCH((select_gather_small_kernel<T, 12>), grid, dim3(256), 0, st, h, scores, sv, d, idx, out, (int)rpb, src_map);
   else
-    hipLaunchKernelGGL((select_gather_small_kernel<T, 32>), grid, dim3(256), 0, st, h, scores, sv, d, idx, out, (int)rpb, src_map);
+    VSEL_LAUNCH((select_gather_small_kernel<T, 32>), grid, dim3(256), 0, st, h, scores, sv, d, idx, out, (int)rpb, src_map);
   VSEL_AFTER_LAUNCH(st, "select_gather_small_kernel");
   return VSEL_OK;
 }

@@ -340,7 +340,7 @@ static int launch_select_splice(hipStream_t st, const T* h, int d, const vsel_se
     while (rpb > 2 && S * cdiv(max_len_out, rpb) < 128) rpb >>= 1;
     const dim3 grid((unsigned)std::max<int64_t>(1, cdiv(max_len_out, rpb)) + (soft_inside ? 1u : 0u), (unsigned)S);
 #define VSEL_SS_LAUNCH(KPT)                                                                                                 \
-    hipLaunchKernelGGL((select_splice_small_kernel<T, KPT>), grid, dim3(kSpliceThreads), 0, st, h, scores, sv, d, l2p, ids,   \
+    VSEL_LAUNCH((select_splice_small_kernel<T, KPT>), grid, dim3(kSpliceThreads), 0, st, h, scores, sv, d, l2p, ids,   \
                        cu_seqlens, S, (int)total_len, visual_id, embeds, pos, pos_rows, mask, idx, sel, new_ids, new_embeds, \
                        new_pos, new_mask, cu_out, stats, (int)l_out, (int)rpb, (int)seg->total_rows, single, soft_k)
     if (maxn <= 4 * kSpliceThreads) VSEL_SS_LAUNCH(4);
@@ -356,13 +356,13 @@ static int launch_select_splice(hipStream_t st, const T* h, int d, const vsel_se
   if (l_out > 0 && hipMemsetAsync(src_scratch, 0x7f, (size_t)l_out * sizeof(int32_t), st) != hipSuccess)
     return fail(VSEL_ERR_HIP, "hipMemsetAsync(src)");
   const size_t lds = (size_t)((maxn + 31) / 32) * 4 + 16;
-  hipLaunchKernelGGL(splice_index_seg_kernel, dim3((unsigned)S), dim3(kSpliceThreads), lds, st, ids, cu_seqlens, sv, S,
+  VSEL_LAUNCH(splice_index_seg_kernel, dim3((unsigned)S), dim3(kSpliceThreads), lds, st, ids, cu_seqlens, sv, S,
                      (int)total_len, visual_id, idx, l2p, pos, pos_rows, mask, sel, new_ids, new_pos, new_mask, src_scratch,
                      cu_out, stats, (int)l_out);
   VSEL_AFTER_LAUNCH(st, "splice_index_seg_kernel");
   if (l_out > 0) {
     const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(l_out, 4), 2048);
-    hipLaunchKernelGGL((splice_embed_kernel<T>), dim3(blocks), dim3(256), 0, st, embeds, h, src_scratch, (int)l_out, d,
+    VSEL_LAUNCH((splice_embed_kernel<T>), dim3(blocks), dim3(256), 0, st, embeds, h, src_scratch, (int)l_out, d,
                        (int)total_len, (int)seg->total_rows, new_embeds);
     VSEL_AFTER_LAUNCH(st, "splice_embed_kernel");
   }

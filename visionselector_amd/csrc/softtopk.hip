@@ -180,11 +180,11 @@ __global__ __launch_bounds__(NT) void soft_topk_bwd_kernel(const float* __restri
 
 int launch_soft_topk_fwd(hipStream_t st, const float* xs, int64_t b, int64_t n, int64_t k, float* ps, float* ts) {
   if (n <= 4096)           // four waves, one per SIMD; the row routine picks 4 / 8 / 12 / 16 registers per thread from n
-    hipLaunchKernelGGL((soft_topk_fwd_kernel<256, 16>), dim3((unsigned)b), dim3(256), 0, st, xs, (int)n, (int)k, ps, ts);
+    VSEL_LAUNCH((soft_topk_fwd_kernel<256, 16>), dim3((unsigned)b), dim3(256), 0, st, xs, (int)n, (int)k, ps, ts);
   else if (n <= 16384)
-    hipLaunchKernelGGL((soft_topk_fwd_kernel<1024, 16>), dim3((unsigned)b), dim3(1024), 0, st, xs, (int)n, (int)k, ps, ts);
+    VSEL_LAUNCH((soft_topk_fwd_kernel<1024, 16>), dim3((unsigned)b), dim3(1024), 0, st, xs, (int)n, (int)k, ps, ts);
   else
-    hipLaunchKernelGGL((soft_topk_fwd_kernel<1024, 0>), dim3((unsigned)b), dim3(1024), 0, st, xs, (int)n, (int)k, ps, ts);
+    VSEL_LAUNCH((soft_topk_fwd_kernel<1024, 0>), dim3((unsigned)b), dim3(1024), 0, st, xs, (int)n, (int)k, ps, ts);
   VSEL_AFTER_LAUNCH(st, "soft_topk_fwd_kernel");
   return VSEL_OK;
 }
@@ -192,9 +192,9 @@ int launch_soft_topk_fwd(hipStream_t st, const float* xs, int64_t b, int64_t n, 
 int launch_soft_topk_bwd(hipStream_t st, const float* g, const float* xs, const float* ts, int64_t b, int64_t n,
                          float* gx) {
   if (n <= 4096)
-    hipLaunchKernelGGL((soft_topk_bwd_kernel<256>), dim3((unsigned)b), dim3(256), 0, st, g, xs, ts, (int)n, gx);
+    VSEL_LAUNCH((soft_topk_bwd_kernel<256>), dim3((unsigned)b), dim3(256), 0, st, g, xs, ts, (int)n, gx);
   else
-    hipLaunchKernelGGL((soft_topk_bwd_kernel<1024>), dim3((unsigned)b), dim3(1024), 0, st, g, xs, ts, (int)n, gx);
+    VSEL_LAUNCH((soft_topk_bwd_kernel<1024>), dim3((unsigned)b), dim3(1024), 0, st, g, xs, ts, (int)n, gx);
   VSEL_AFTER_LAUNCH(st, "soft_topk_bwd_kernel");
   return VSEL_OK;
 }
@@ -218,7 +218,7 @@ extern "C" int vsel_soft_topk_fwd_bf16ref(void* stream, const float* xs, int64_t
   if (b < 1 || n < 1 || b > 0x7fffffff || n > 0x7fffffff) return fail(VSEL_ERR_INVALID, "bad shape [%lld, %lld]", (long long)b, (long long)n);
   if (!(0 < k && k < n)) return fail(VSEL_ERR_INVALID, "soft top-k needs 0 < k < n (k=%lld, n=%lld)", (long long)k, (long long)n);
   VSEL_PROF_BEGIN(stream);
-  hipLaunchKernelGGL((soft_topk_fwd_bf16ref_kernel<1024>), dim3((unsigned)b), dim3(1024), 0, (hipStream_t)stream, xs, (int)n, (int)k, ps, ts);
+  VSEL_LAUNCH((soft_topk_fwd_bf16ref_kernel<1024>), dim3((unsigned)b), dim3(1024), 0, (hipStream_t)stream, xs, (int)n, (int)k, ps, ts);
   VSEL_AFTER_LAUNCH((hipStream_t)stream, "soft_topk_fwd_bf16ref_kernel");
   return VSEL_OK;
 }

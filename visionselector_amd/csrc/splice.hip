@@ -39,18 +39,18 @@ extern "C" int vsel_splice(void* stream, const int64_t* input_ids, int64_t seq_l
   VSEL_PROF_BEGIN(st);
   const int l_out = (int)(seq_len - n_visual + k);
   const size_t lds = (size_t)((n_visual + 31) / 32) * 4 + 16;
-  hipLaunchKernelGGL(splice_index_kernel, dim3(1), dim3(kSpliceThreads), lds, st, input_ids, (int)seq_len, visual_token_id,
+  VSEL_LAUNCH(splice_index_kernel, dim3(1), dim3(kSpliceThreads), lds, st, input_ids, (int)seq_len, visual_token_id,
                      all_indices, (int)k, (int)n_visual, position_ids, (int)pos_rows, attention_mask, selected_indices,
                      new_input_ids, new_position_ids, new_attention_mask, src_scratch, stats, l_out);
   VSEL_AFTER_LAUNCH(st, "splice_index_kernel");
   const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(l_out, 4), 2048);
   if (l_out > 0) {
     if (dtype == VSEL_BF16)
-      hipLaunchKernelGGL((splice_embed_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)inputs_embeds,
+      VSEL_LAUNCH((splice_embed_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)inputs_embeds,
                          (const bf16_t*)visual_embeds, src_scratch, l_out, (int)d_llm, (int)seq_len, (int)k,
                          (bf16_t*)new_inputs_embeds);
     else
-      hipLaunchKernelGGL((splice_embed_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)inputs_embeds,
+      VSEL_LAUNCH((splice_embed_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)inputs_embeds,
                          (const float*)visual_embeds, src_scratch, l_out, (int)d_llm, (int)seq_len, (int)k,
                          (float*)new_inputs_embeds);
     VSEL_AFTER_LAUNCH(st, "splice_embed_kernel");
@@ -88,18 +88,18 @@ extern "C" int vsel_splice_batched(void* stream, const int64_t* input_ids, int64
   if (l_out > 0 && hipMemsetAsync(src_scratch, 0x7f, (size_t)l_out * sizeof(int32_t), st) != hipSuccess)
     return fail(VSEL_ERR_HIP, "hipMemsetAsync(src)");
   const size_t lds = (size_t)((max_visual + 31) / 32) * 4 + 16;
-  hipLaunchKernelGGL(splice_index_batched_kernel, dim3((unsigned)n_seq), dim3(kSpliceThreads), lds, st, input_ids, cu_seqlens,
+  VSEL_LAUNCH(splice_index_batched_kernel, dim3((unsigned)n_seq), dim3(kSpliceThreads), lds, st, input_ids, cu_seqlens,
                      cu_visual, cu_kept, (int)n_seq, (int)max_visual, visual_token_id, all_indices, position_ids, (int)pos_rows,
                      (int)total_len, selected_indices, new_input_ids, new_position_ids, src_scratch, cu_seqlens_out, stats, l_out);
   VSEL_AFTER_LAUNCH(st, "splice_index_batched_kernel");
   const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(l_out, 4), 2048);
   if (l_out > 0) {
     if (dtype == VSEL_BF16)
-      hipLaunchKernelGGL((splice_embed_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)inputs_embeds,
+      VSEL_LAUNCH((splice_embed_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)inputs_embeds,
                          (const bf16_t*)visual_embeds, src_scratch, l_out, (int)d_llm, (int)total_len, (int)total_kept,
                          (bf16_t*)new_inputs_embeds);
     else
-      hipLaunchKernelGGL((splice_embed_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)inputs_embeds,
+      VSEL_LAUNCH((splice_embed_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)inputs_embeds,
                          (const float*)visual_embeds, src_scratch, l_out, (int)d_llm, (int)total_len, (int)total_kept,
                          (float*)new_inputs_embeds);
     VSEL_AFTER_LAUNCH(st, "splice_embed_kernel");

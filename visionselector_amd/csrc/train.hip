@@ -436,10 +436,10 @@ static int train_fwd_impl(hipStream_t st, const T* h, int64_t n, int64_t k, cons
   const int d = (int)sc->d;
   if (n <= 4096) {
     // soft top-k + hard top-k mask + BCE of the one row in one launch
-    if (n <= 1024) hipLaunchKernelGGL(train_tail_kernel<4>, dim3(1), dim3(256), 0, st, scores, (int)n, (int)k, ps, ts, y, bce);
-    else hipLaunchKernelGGL(train_tail_kernel<16>, dim3(1), dim3(256), 0, st, scores, (int)n, (int)k, ps, ts, y, bce);
+    if (n <= 1024) VSEL_LAUNCH(train_tail_kernel<4>, dim3(1), dim3(256), 0, st, scores, (int)n, (int)k, ps, ts, y, bce);
+    else VSEL_LAUNCH(train_tail_kernel<16>, dim3(1), dim3(256), 0, st, scores, (int)n, (int)k, ps, ts, y, bce);
     VSEL_AFTER_LAUNCH(st, "train_tail_kernel");
-    hipLaunchKernelGGL((mask_apply_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv(n, 4), 4096)), dim3(256), 0, st, h, ps,
+    VSEL_LAUNCH((mask_apply_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv(n, 4), 4096)), dim3(256), 0, st, h, ps,
                        (int)n, d, h_new);
     VSEL_AFTER_LAUNCH(st, "mask_apply_kernel");
     return VSEL_OK;
@@ -448,10 +448,10 @@ static int train_fwd_impl(hipStream_t st, const T* h, int64_t n, int64_t k, cons
   if (rc) return rc;
   rc = launch_select(st, scores, &seg, nullptr, y);
   if (rc) return rc;
-  hipLaunchKernelGGL((mask_apply_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv(n, 4), 4096)), dim3(256), 0, st, h, ps,
+  VSEL_LAUNCH((mask_apply_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv(n, 4), 4096)), dim3(256), 0, st, h, ps,
                      (int)n, d, h_new);
   VSEL_AFTER_LAUNCH(st, "mask_apply_kernel");
-  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, st, ps, y, (int)n, bce);
+  VSEL_LAUNCH(bce_kernel, dim3(1), dim3(1024), 0, st, ps, y, (int)n, bce);
   VSEL_AFTER_LAUNCH(st, "bce_kernel");
   return VSEL_OK;
 }
@@ -483,10 +483,10 @@ static int scores_bwd_impl(hipStream_t st, const float* g, const T* h, int64_t n
   const float rs = 1.0f / (float)sqrt((double)hd);
   const unsigned row_blocks = (unsigned)std::min<int64_t>(cdiv(n, 4), 4096);
 
-  hipLaunchKernelGGL((wcolsum_partial_kernel<T>), dim3((unsigned)cdiv(d, 64 * V), tp.wsplits), dim3(256), 0, st, h, g, (int)n,
+  VSEL_LAUNCH((wcolsum_partial_kernel<T>), dim3((unsigned)cdiv(d, 64 * V), tp.wsplits), dim3(256), 0, st, h, g, (int)n,
                      d, tp.wsplits, wpart);
   VSEL_AFTER_LAUNCH(st, "wcolsum_partial_kernel");
-  hipLaunchKernelGGL(wcolsum_finish_kernel, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st, wpart, g, (int)n, d, tp.wsplits,
+  VSEL_LAUNCH(wcolsum_finish_kernel, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st, wpart, g, (int)n, d, tp.wsplits,
                      xsum, gx, xbar, sg);
   VSEL_AFTER_LAUNCH(st, "wcolsum_finish_kernel");
   // kbar = Wk xbar + bk.  bf16 weights: the forward's single-wave-per-tile bf16x3 kernel, its prologue summing the row splits
@@ -494,49 +494,49 @@ static int scores_bwd_impl(hipStream_t st, const float* g, const T* h, int64_t n
   vsel_segments seg1{1, n, n, 1, 1, nullptr, nullptr};
   const bool small = small_path_ok(&seg1, sc, p);
   if (small) {
-    hipLaunchKernelGGL(proj_nt_small_kernel, dim3((unsigned)cdiv(hd, 32), p.ks1), dim3(64), 0, st, wpart, make_view(&seg1), 1,
+    VSEL_LAUNCH(proj_nt_small_kernel, dim3((unsigned)cdiv(hd, 32), p.ks1), dim3(64), 0, st, wpart, make_view(&seg1), 1,
                        tp.wsplits, (const uint16_t*)sc->wk, hd, d, p.kslice1, part1, (int64_t)2 * d, 1);
     VSEL_AFTER_LAUNCH(st, "proj_nt_small_kernel");
   } else {
-    hipLaunchKernelGGL((gemm_nt_kernel<TW>), dim3((unsigned)cdiv(hd, 32), 1, p.ks1), dim3(64), 0, st, xbar, (const TW*)sc->wk, 1,
+    VSEL_LAUNCH((gemm_nt_kernel<TW>), dim3((unsigned)cdiv(hd, 32), 1, p.ks1), dim3(64), 0, st, xbar, (const TW*)sc->wk, 1,
                        hd, d, p.kslice1, part1);
     VSEL_AFTER_LAUNCH(st, "gemm_nt_kernel");
   }
-  hipLaunchKernelGGL((kbar_finish_kernel<TW>), dim3(1), dim3(256), 0, st, part1, p.ks1, 1, hd, (const TW*)sc->bk,
+  VSEL_LAUNCH((kbar_finish_kernel<TW>), dim3(1), dim3(256), 0, st, part1, p.ks1, 1, hd, (const TW*)sc->bk,
                      (const TW*)sc->bq, kbar, c);
   VSEL_AFTER_LAUNCH(st, "kbar_finish_kernel");
   // dk = (Wq gx + bq sg) rs / N
   if (small) {
-    hipLaunchKernelGGL(proj_nt_small_kernel, dim3((unsigned)cdiv(hd, 32), p.ks1), dim3(64), 0, st, wpart + d, make_view(&seg1), 1,
+    VSEL_LAUNCH(proj_nt_small_kernel, dim3((unsigned)cdiv(hd, 32), p.ks1), dim3(64), 0, st, wpart + d, make_view(&seg1), 1,
                        tp.wsplits, (const uint16_t*)sc->wq, hd, d, p.kslice1, dkraw, (int64_t)2 * d, 0);
     VSEL_AFTER_LAUNCH(st, "proj_nt_small_kernel");
   } else {
-    hipLaunchKernelGGL((gemm_nt_kernel<TW>), dim3((unsigned)cdiv(hd, 32), 1, p.ks1), dim3(64), 0, st, gx, (const TW*)sc->wq, 1,
+    VSEL_LAUNCH((gemm_nt_kernel<TW>), dim3((unsigned)cdiv(hd, 32), 1, p.ks1), dim3(64), 0, st, gx, (const TW*)sc->wq, 1,
                        hd, d, p.kslice1, dkraw);
     VSEL_AFTER_LAUNCH(st, "gemm_nt_kernel");
   }
-  hipLaunchKernelGGL((dk_finish_kernel<TW>), dim3((unsigned)cdiv(hd, 256)), dim3(256), 0, st, dkraw, p.ks1, hd,
+  VSEL_LAUNCH((dk_finish_kernel<TW>), dim3((unsigned)cdiv(hd, 256)), dim3(256), 0, st, dkraw, p.ks1, hd,
                      (const TW*)sc->bq, kbar, sg, rs, (int)n, dk, a, dbq, dbk);
   VSEL_AFTER_LAUNCH(st, "dk_finish_kernel");
   if (!factors) {
     const dim3 og((unsigned)cdiv(d, 1024), (unsigned)std::min<int>(hd, 512));
-    hipLaunchKernelGGL(outer_kernel, og, dim3(256), 0, st, a, gx, hd, d, dwq);
+    VSEL_LAUNCH(outer_kernel, og, dim3(256), 0, st, a, gx, hd, d, dwq);
     VSEL_AFTER_LAUNCH(st, "outer_kernel");
-    hipLaunchKernelGGL(outer_kernel, og, dim3(256), 0, st, dk, xsum, hd, d, dwk);
+    VSEL_LAUNCH(outer_kernel, og, dim3(256), 0, st, dk, xsum, hd, d, dwk);
     VSEL_AFTER_LAUNCH(st, "outer_kernel");
   }
   if (dh) {
-    hipLaunchKernelGGL((gemm_nn_kernel<TW>), dim3((unsigned)cdiv(d, 256), 1, p.ks2), dim3(64), 0, st, kbar, (const TW*)sc->wq, 1,
+    VSEL_LAUNCH((gemm_nn_kernel<TW>), dim3((unsigned)cdiv(d, 256), 1, p.ks2), dim3(64), 0, st, kbar, (const TW*)sc->wq, 1,
                        d, hd, p.kslice2, part2);
     VSEL_AFTER_LAUNCH(st, "gemm_nn_kernel");
-    hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st, part2, p.ks2, (int64_t)d, w);
+    VSEL_LAUNCH(slice_sum_kernel, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st, part2, p.ks2, (int64_t)d, w);
     VSEL_AFTER_LAUNCH(st, "slice_sum_kernel");
-    hipLaunchKernelGGL((gemm_nn_kernel<TW>), dim3((unsigned)cdiv(d, 256), 1, p.ks2), dim3(64), 0, st, dk, (const TW*)sc->wk, 1, d,
+    VSEL_LAUNCH((gemm_nn_kernel<TW>), dim3((unsigned)cdiv(d, 256), 1, p.ks2), dim3(64), 0, st, dk, (const TW*)sc->wk, 1, d,
                        hd, p.kslice2, part2);
     VSEL_AFTER_LAUNCH(st, "gemm_nn_kernel");
-    hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st, part2, p.ks2, (int64_t)d, u);
+    VSEL_LAUNCH(slice_sum_kernel, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st, part2, p.ks2, (int64_t)d, u);
     VSEL_AFTER_LAUNCH(st, "slice_sum_kernel");
-    hipLaunchKernelGGL((dh_kernel<T>), dim3(row_blocks), dim3(256), 0, st, dhn, ps, g, w, u, rs, (int)n, d, dh);
+    VSEL_LAUNCH((dh_kernel<T>), dim3(row_blocks), dim3(256), 0, st, dhn, ps, g, w, u, rs, (int)n, d, dh);
     VSEL_AFTER_LAUNCH(st, "dh_kernel");
   }
   return VSEL_OK;
@@ -551,7 +551,7 @@ static int train_bwd_impl(hipStream_t st, const T* dhn, const T* h, int64_t n, c
   float* dps = (float*)(ws + tp.off_dps);
   float* g = (float*)(ws + tp.off_g);
   const unsigned row_blocks = (unsigned)std::min<int64_t>(cdiv(n, 4), 4096);
-  hipLaunchKernelGGL((rowdot_kernel<T>), dim3(row_blocks), dim3(256), 0, st, dhn, h, ps, y, d_ps_ext, dl_dbce, (int)n, d, dps);
+  VSEL_LAUNCH((rowdot_kernel<T>), dim3(row_blocks), dim3(256), 0, st, dhn, h, ps, y, d_ps_ext, dl_dbce, (int)n, d, dps);
   VSEL_AFTER_LAUNCH(st, "rowdot_kernel");
   int rc = launch_soft_topk_bwd(st, dps, scores, ts, 1, n, g);
   if (rc) return rc;
@@ -644,9 +644,9 @@ extern "C" int vsel_lis_factors_to_grads(void* stream, const float* payload, int
   VSEL_PROF_BEGIN(st);
   const int64_t row = 2 * (hd + d) + 2 * hd;
   const dim3 og((unsigned)cdiv(d, 1024), (unsigned)std::min<int64_t>(hd, 512), 2);
-  hipLaunchKernelGGL(outer_sum_kernel, og, dim3(256), 0, st, payload, (int)n_rows, row, (int)hd, (int)d, scale, dwq, dwk);
+  VSEL_LAUNCH(outer_sum_kernel, og, dim3(256), 0, st, payload, (int)n_rows, row, (int)hd, (int)d, scale, dwq, dwk);
   VSEL_AFTER_LAUNCH(st, "outer_sum_kernel");
-  hipLaunchKernelGGL(bias_sum_kernel, dim3((unsigned)cdiv(hd, 256)), dim3(256), 0, st, payload, (int)n_rows, row, (int)hd, (int)d,
+  VSEL_LAUNCH(bias_sum_kernel, dim3((unsigned)cdiv(hd, 256)), dim3(256), 0, st, payload, (int)n_rows, row, (int)hd, (int)d,
                      scale, dbq, dbk);
   VSEL_AFTER_LAUNCH(st, "bias_sum_kernel");
   return VSEL_OK;

@@ -539,8 +539,14 @@ def bench_train_step(ops, dist, world, rank, iters=20):
         if dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         step_us, comp_us, exch_us = [float(x) for x in t.tolist()]
+        # SURVEY.md 8(d) training bytes: forward 2 N D e (tokens in, masked tokens out) + both weight matrices; backward 2 N D e (dH', H)
+        # + 2 Hd D 4 (fp32 gradients out).  ~11 dependent launches of 3 - 10 us each: launch-bound, the fraction says how far.
+        tbytes = 2 * n * d * 2 + 2 * hd * d * 2 + 2 * n * d * 2 + 2 * hd * d * 4
         out[name] = {"n_tokens_per_rank": n, "k": k, "step_us": step_us, "fwd_bwd_us": comp_us, "grad_allreduce_us": exch_us,
                      "tokens_per_s": world * n / (step_us * 1e-6),
+                     "roofline": {"bound": "hbm", "algorithmic_bytes": tbytes, "achieved": tbytes / (comp_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": tbytes / (comp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                  "note": "forward + backward of one micro-batch (fwd_bwd_us), SURVEY 8(d) training bytes"},
                      "allreduce_busbw_GBps": (2 * (world - 1) / world * bucket.numel() * 4 / (exch_us * 1e-6) / 1e9) if dist else None}
 
         # the same step with the weight gradients exchanged as rank-1 factors (ddp.LisFactorSync): the backward

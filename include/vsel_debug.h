@@ -78,7 +78,13 @@ typedef enum vsel_debug_knob {
   VSEL_KNOB_ATTN_KEY_PARTS = 22,  /* vsel_varlen_attn_fwd_ws: key-range parts of the 256-query items (csrc/attn_fwd64_parts.hip): -1 for uniform causal batches
                                      of <= 128 items (few q heads) from 2048 tokens (default), 0 never, 1 whenever the shapes allow, n > 1: n key tiles per part;
                                      env VSEL_ATTN_KEY_PARTS; deterministic, another fp32 association than the unsplit forms */
-  VSEL_KNOB_COUNT = 23
+  VSEL_KNOB_LIS_GATHER = 23,      /* the gather of the kept rows for uniform segments: 0 = one workgroup per 4 .. 32 kept rows of a segment, > 0 = a flat
+                                     list of kept rows dealt to resident waves, value = 10 * workgroups per CU + rows in flight per wave (2 .. 4);
+                                     env VSEL_GATHER; bit-identical (a copy) */
+  VSEL_KNOB_TRAIN_FUSED = 24,     /* 0 / 1: training backward of one row of <= 4096 scores (bf16 weights) in five launches -- the soft top-k backward in the
+                                     prologue of the weighted column sums, both projections in one launch, one finish kernel, both rank-1 writes in one
+                                     launch -- instead of ten (default 1; env VSEL_TRAIN_FUSED); bit-identical */
+  VSEL_KNOB_COUNT = 25
 } vsel_debug_knob;
 
 /* Set knob to value (clamped to the knob's range).  *previous (may be NULL) receives the value it had.

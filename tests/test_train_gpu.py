@@ -232,6 +232,37 @@ def test_train_bwd_factors_rebuild_the_dense_gradients(ops):
         assert float((p.grad - 2 * ref).abs().max()) <= 2e-6 * max(1e-30, float(ref.abs().max())) + 1e-12
 
 
+@pytest.mark.parametrize("shape", [(3584, 1792, 2304), (2048, 1024, 600), (4096, 2048, 4000), (2048, 1024, 37)])
+def test_train_backward_five_launch_form_is_bit_identical(ops, shape):
+    """The fused training backward (knob train_fused: soft top-k backward in the prologue of the weighted column sums, both projections in
+    one launch, one finish kernel, both rank-1 writes in one launch) against the ten-launch chain: every output bit for bit, dense and
+    rank-1-factor forms, with and without the token gradient and the external BCE gradient."""
+    from visionselector_amd import _native as N
+    d, hd, n = shape
+    k = max(1, int(n * 0.2))
+    c = oin.make_case(d, hd, n, 123)
+    h, wq, bq, wk, bk = (dev(c[x], torch.bfloat16) for x in ("h", "wq", "bq", "wk", "bk"))
+    g = torch.Generator(device="cuda").manual_seed(11)
+    dhn = (torch.randn(n, d, device="cuda", generator=g) / d ** 0.5).bfloat16()
+    ext = torch.randn(n, device="cuda", generator=g) * 1e-3
+    h_new, ps, y, scores, ts, bce = ops.lis_train_fwd(h, wq, bq, wk, bk, k)
+    for need_dh in (False, True):
+        for d_ps_ext, w in ((None, 0.7), (ext, 0.0), (ext, 1.3)):
+            outs = {}
+            for fused in (1, 0):
+                with N.debug_knob("train_fused", fused):
+                    N.profile_start()
+                    dense = ops.lis_train_bwd(dhn, h, wq, bq, wk, bk, ps, y, scores, ts, d_ps_ext, w, need_dh=need_dh)
+                    torch.cuda.synchronize()
+                    names = set(N.profile_stop())
+                    fac = ops.lis_train_bwd_factors(dhn, h, wq, bq, wk, bk, ps, y, scores, ts, d_ps_ext, w, need_dh=need_dh)
+                assert ("train_bwd_finish_kernel" in names) == bool(fused) and ("soft_topk_bwd_kernel" in names) == (not fused), names
+                outs[fused] = [t for t in dense if t is not None] + [t for t in (fac if isinstance(fac, (tuple, list)) else [fac]) if t is not None]
+            assert len(outs[0]) == len(outs[1])
+            for a_, b_ in zip(outs[1], outs[0]):
+                assert torch.equal(a_, b_)
+
+
 # ---------------------------------------------------------------------------------------------------
 # against the reference's OWN bf16 backward (tests/golden/lisbf16_*.npz `topk_grad_bf16`, `bwd_*`): the reference trains with
 # bf16 modules and tokens (FT/qwenvl/train/train_qwen_selector.py:175-180; TopK.backward FT/compression_method/

@@ -84,7 +84,7 @@ DEBUG_SIGNATURES = {
 KNOBS = {"lis_pipeline": 0, "lis_small_path": 1, "lis_fused_select": 2, "attn_use_tr": 3, "attn_waves": 4, "attn_pack": 5,
          "attn_split": 6, "attn_split_q64": 7, "attn_bwd_split": 8, "lis_splice_fused": 9, "attn_bwd_waves": 10, "attn_tail_first": 11, "lis_seg_sums": 12,
          "attn_xcd_queue": 13, "attn_rows64": 14, "attn_bwd_dq64": 15, "attn_bwd_dkdv64": 16, "attn_static": 17, "attn_skip_empty": 18, "attn_gqa": 19, "attn_gqa_form": 20,
-         "attn_bwd_updown": 21, "attn_key_parts": 22}
+         "attn_bwd_updown": 21, "attn_key_parts": 22, "lis_gather": 23, "train_fused": 24}
 
 _lib = None
 

@@ -54,6 +54,8 @@ constexpr KnobSpec kKnobs[VSEL_KNOB_COUNT] = {
     {"VSEL_ATTN_GQA_FORM", -1, -1, 1},   // VSEL_KNOB_ATTN_GQA_FORM
     {"VSEL_ATTN_BWD_UPDOWN", 1, 0, 1},   // VSEL_KNOB_ATTN_BWD_UPDOWN
     {"VSEL_ATTN_KEY_PARTS", -1, -1, 64}, // VSEL_KNOB_ATTN_KEY_PARTS
+    {"VSEL_GATHER", 82, 0, 84},          // VSEL_KNOB_LIS_GATHER
+    {"VSEL_TRAIN_FUSED", 1, 0, 1},       // VSEL_KNOB_TRAIN_FUSED
 };
 int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 int knob_default(int id) {

@@ -1121,6 +1121,74 @@ inline int launch_select(hipStream_t st, const float* scores, const vsel_segment
   return VSEL_OK;
 }
 
+// The gather for UNIFORM segments as a flat list of kept rows dealt to a fixed set of waves (knob LIS_GATHER): wave w of W copies
+// kept rows w, w + W, w + 2 W ... of the call (row g = segment g / k, rank g % k), DEPTH rows of ITERS x 16 B per lane in flight per wave.
+// The workgroups stay resident for the whole launch (no per-8-rows workgroup churn, no third partial round of workgroups) and a wave's
+// next row is on its way while the current one is stored.  The wave index is made uniform, so the index fetch is a scalar load and the
+// row pointers live in SGPRs.  Same bytes to the same places as gather_rows_kernel.
+template <typename T, bool NT, int ITERS, int DEPTH>
+__global__ __launch_bounds__(256) void gather_rows_flat_kernel(const T* __restrict__ h, int rows_per_seg, int k, int d,
+                                                               const int64_t* __restrict__ idx, T* __restrict__ out, int total,
+                                                               int w_div_k, int w_mod_k, const int64_t* __restrict__ src_map) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int W = gridDim.x * 4;
+  int g = blockIdx.x * 4 + wave;                     // kept row of the call (= output row)
+  if (g >= total) return;
+  int sg = g / k, jr = g - sg * k;                   // its segment and rank, advanced by W per step without dividing again
+  auto advance = [&]() {
+    g += W;
+    sg += w_div_k;
+    jr += w_mod_k;
+    if (jr >= k) { jr -= k; ++sg; }
+  };
+  auto load_row = [&](u32x4 (&x)[ITERS]) {
+    const int64_t l = (int64_t)sg * rows_per_seg + idx[g];
+    const int64_t srow = src_map ? src_map[l] : l;
+    const u32x4* sp = reinterpret_cast<const u32x4*>(h + srow * d) + lane;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      if constexpr (NT) x[i] = __builtin_nontemporal_load(sp + 64 * i);
+      else x[i] = sp[64 * i];
+    }
+  };
+  auto store_row = [&](const u32x4 (&x)[ITERS], int grow) {
+    u32x4* dp = reinterpret_cast<u32x4*>(out + (int64_t)grow * d) + lane;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      if constexpr (NT) __builtin_nontemporal_store(x[i], dp + 64 * i);
+      else dp[64 * i] = x[i];
+    }
+  };
+  u32x4 x[DEPTH][ITERS];
+  int gs = g;                                        // the row the next store writes
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u) {
+    if (g < total) load_row(x[u]);
+    advance();
+  }
+  auto step = [&](u32x4 (&xu)[ITERS]) {
+    store_row(xu, gs);
+    gs += W;
+    if (g < total) load_row(xu);
+    advance();
+  };
+  for (;;) {
+    if (gs >= total) break;
+    step(x[0]);
+    if (gs >= total) break;
+    step(x[1]);
+    if constexpr (DEPTH > 2) {
+      if (gs >= total) break;
+      step(x[2]);
+    }
+    if constexpr (DEPTH > 3) {
+      if (gs >= total) break;
+      step(x[3]);
+    }
+  }
+}
+
 template <typename T>
 inline int launch_gather(hipStream_t st, const T* h, int d, const vsel_segments* seg, const int64_t* idx, T* out,
                          const int64_t* src_map = nullptr) {
@@ -1130,6 +1198,34 @@ inline int launch_gather(hipStream_t st, const T* h, int d, const vsel_segments*
   const bool nt = stream_policy(seg->total_rows, d, sizeof(T));
   constexpr int V = Elem<T>::kVec;
   const int iters = ( d % (64 * V) == 0 && d / (64 * V) <= 8) ? d / (64 * V) : 0;
+  // flat resident form (uniform segments, whole-chunk rows): knob LIS_GATHER = 10 * workgroups-per-CU + rows in flight per wave
+  const int gform = knob(VSEL_KNOB_LIS_GATHER);
+  const int64_t total_out = seg->n_seg * seg->k;
+  if (gform > 0 && iters > 0 && !seg->seg_rows && !seg->seg_out && total_out < (1ll << 30) && total_out >= 4096) {
+    const int depth = gform % 10, per_cu = std::max(1, gform / 10);
+    const int64_t G = std::min<int64_t>(cdiv(total_out, 4), 256 * per_cu);
+    const int W = (int)G * 4, kk = (int)seg->k;
+#define VSEL_FLAT_CASE2(I, DP)                                                                                                         \
+    do {                                                                                                                               \
+      if (nt) VSEL_LAUNCH((gather_rows_flat_kernel<T, true, I, DP>), dim3((unsigned)G), dim3(256), 0, st, h, (int)seg->rows_per_seg, kk, d, \
+                          idx, out, (int)total_out, W / kk, W % kk, src_map);                                                         \
+      else VSEL_LAUNCH((gather_rows_flat_kernel<T, false, I, DP>), dim3((unsigned)G), dim3(256), 0, st, h, (int)seg->rows_per_seg, kk, d,   \
+                       idx, out, (int)total_out, W / kk, W % kk, src_map);                                                            \
+    } while (0)
+#define VSEL_FLAT_CASE(I)                                                                                                              \
+    case I:                                                                                                                            \
+      if (depth <= 2) VSEL_FLAT_CASE2(I, 2); else if (depth == 3) VSEL_FLAT_CASE2(I, 3); else VSEL_FLAT_CASE2(I, 4);                   \
+      break;
+    switch (iters) {
+      VSEL_FLAT_CASE(4) VSEL_FLAT_CASE(7) VSEL_FLAT_CASE(8)
+      default: goto per_segment_form;
+    }
+#undef VSEL_FLAT_CASE
+#undef VSEL_FLAT_CASE2
+    VSEL_AFTER_LAUNCH(st, "gather_rows_kernel");
+    return VSEL_OK;
+  }
+per_segment_form:
 #define VSEL_GATHER_CASE(I)                                                                                                   \
   case I:                                                                                                                     \
     if (nt) VSEL_LAUNCH((gather_rows_kernel<T, true, I>), grid, dim3(256), 0, st, h, make_view(seg), d, idx, out, (int)rpb, src_map); \

@@ -29,9 +29,9 @@ constexpr int kSmallSelectThreads = 256;
 // -------------------------------------------------------------------------------------------------------------------------
 //     split_stride: floats between consecutive row splits of one segment (K for the sweep-1 partials); mean = 0: the sums are
 //     used as they are instead of being divided by the segment's row count (training backward: Wq (sum_i g_i x_i))
-static __attribute__((unused)) __global__ __launch_bounds__(64) void proj_nt_small_kernel(const float* __restrict__ partial, SegView sv, int S, int row_splits,
-                                                                  const uint16_t* __restrict__ w, int N, int K, int kslice,
-                                                                  float* __restrict__ part, int64_t split_stride, int mean) {
+__device__ __forceinline__ void proj_nt_small_body(const float* __restrict__ partial, const SegView& sv, int S, int row_splits,
+                                                   const uint16_t* __restrict__ w, int N, int K, int kslice,
+                                                   float* __restrict__ part, int64_t split_stride, int mean) {
   __shared__ __attribute__((aligned(16))) uint16_t xs[3][kSmallMaxSeg][kSliceNT];
   const int lane = threadIdx.x;
   const int i = lane & 31, kg = lane >> 5;
@@ -127,6 +127,23 @@ static __attribute__((unused)) __global__ __launch_bounds__(64) void proj_nt_sma
     }
   }
   VSEL_STAMP_DRAIN(1, 3);
+}
+
+static __attribute__((unused)) __global__ __launch_bounds__(64) void proj_nt_small_kernel(const float* __restrict__ partial, SegView sv, int S, int row_splits,
+                                                                  const uint16_t* __restrict__ w, int N, int K, int kslice,
+                                                                  float* __restrict__ part, int64_t split_stride, int mean) {
+  proj_nt_small_body(partial, sv, S, row_splits, w, N, K, kslice, part, split_stride, mean);
+}
+
+// Two independent P1 products of the same shape in ONE launch (training backward: kbar = Wk xbar and dk_raw = Wq (sum_i g_i x_i), both
+// from the weighted column-sum partials): grid (ceil(N / 32), KS, 2), blockIdx.z picks the operand set.  Same body, same bits.
+static __attribute__((unused)) __global__ __launch_bounds__(64) void proj_nt_small_pair_kernel(const float* __restrict__ partial0, const float* __restrict__ partial1,
+                                                                       SegView sv, int S, int row_splits, const uint16_t* __restrict__ w0,
+                                                                       const uint16_t* __restrict__ w1, int N, int K, int kslice,
+                                                                       float* __restrict__ part0, float* __restrict__ part1_, int64_t split_stride,
+                                                                       int mean0, int mean1) {
+  if (blockIdx.z == 0) proj_nt_small_body(partial0, sv, S, row_splits, w0, N, K, kslice, part0, split_stride, mean0);
+  else proj_nt_small_body(partial1, sv, S, row_splits, w1, N, K, kslice, part1_, split_stride, mean1);
 }
 
 // -------------------------------------------------------------------------------------------------------------------------

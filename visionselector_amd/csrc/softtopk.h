@@ -25,6 +25,28 @@ __device__ __forceinline__ float block_sum(float v, float (*red)[NW], int slot) 
   return t;
 }
 
+// ---- TopK.backward (FT/compression_method/selector_model.py:60-70), shared by soft_topk_bwd_kernel and the training backward's fused
+// sweep (train.hip): the two block sums over one row by NT threads in a fixed order, and one element of the gradient.
+template <int NT>
+__device__ __forceinline__ void soft_topk_bwd_sums(const float* __restrict__ g, const float* __restrict__ x, float t, int n,
+                                                   float (*red)[NT / 64], float& sv_out, float& suv_out) {
+  float sv = 0.f, suv = 0.f;
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const float p = sigmoidf_ref(x[i] + t);
+    const float v = p * (1.0f - p);             // :66  sigmoid'(x + t)
+    sv += v;
+    suv += g[i] * v;
+  }
+  sv_out = block_sum<NT / 64>(sv, red, 0);      // :67
+  suv_out = block_sum<NT / 64>(suv, red, 1);    // :70 uv.sum()
+}
+__device__ __forceinline__ float soft_topk_bwd_elem(float gi, float xi, float t, float sv, float suv) {
+  const float p = sigmoidf_ref(xi + t);
+  const float v = p * (1.0f - p);
+  const float uv = gi * v;                      // :69
+  return (-suv * v) / sv + uv;                  // :70-71
+}
+
 // ---- the threshold of _find_ts (selector_model.py:72-86) -------------------------------------------------------------------
 // The reference bisects 64 times for the t with sum_i sigmoid(x_i + t) = k, from lo = -max(x) - 10, hi = -min(x) + 10.  Bisection
 // costs one block-wide reduction per bit of t (26-27 dependent reductions until lo and hi are adjacent floats; 24 us for one row

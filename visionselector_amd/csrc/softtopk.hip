@@ -161,21 +161,9 @@ __global__ __launch_bounds__(NT) void soft_topk_bwd_kernel(const float* __restri
   const float* g = grad_ps + (int64_t)row * n;
   const float t = ts[row];
   const int tid = threadIdx.x;
-  float sv = 0.f, suv = 0.f;
-  for (int i = tid; i < n; i += NT) {
-    const float p = sigmoidf_ref(x[i] + t);
-    const float v = p * (1.0f - p);             // :66  sigmoid'(x + t)
-    sv += v;
-    suv += g[i] * v;
-  }
-  sv = block_sum<NW>(sv, red, 0);               // :67
-  suv = block_sum<NW>(suv, red, 1);             // :70 uv.sum()
-  for (int i = tid; i < n; i += NT) {
-    const float p = sigmoidf_ref(x[i] + t);
-    const float v = p * (1.0f - p);
-    const float uv = g[i] * v;                  // :69
-    grad_xs[(int64_t)row * n + i] = (-suv * v) / sv + uv;   // :70-71
-  }
+  float sv, suv;
+  soft_topk_bwd_sums<NT>(g, x, t, n, red, sv, suv);
+  for (int i = tid; i < n; i += NT) grad_xs[(int64_t)row * n + i] = soft_topk_bwd_elem(g[i], x[i], t, sv, suv);
 }
 
 int launch_soft_topk_fwd(hipStream_t st, const float* xs, int64_t b, int64_t n, int64_t k, float* ps, float* ts) {

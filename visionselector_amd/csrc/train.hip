@@ -213,26 +213,48 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ dhn, 
 }
 
 // partial[rs][0][c] = sum_i x[i][c], partial[rs][1][c] = sum_i g[i] x[i][c]   over the block's rows
-template <typename T>
+// FUSED (one row of <= 4096 scores, the training backward): g is not read but made here -- the workgroup's prologue repeats
+// soft_topk_bwd_kernel<256>'s two block sums over (dps, scores) (same threads, same order: the same bits in every workgroup) and each
+// wave turns dps[r] into g[r] for the rows it adds; the workgroups of column tile 0 also leave g[r] in g_out (sum_i g_i, dh).  One
+// launch and one dependent round trip fewer than soft_topk_bwd + this sweep.
+template <typename T, bool FUSED>
 __global__ __launch_bounds__(256) void wcolsum_partial_kernel(const T* __restrict__ h, const float* __restrict__ g, int n,
-                                                              int d, int row_splits, float* __restrict__ partial) {
+                                                              int d, int row_splits, float* __restrict__ partial,
+                                                              const float* __restrict__ xs, const float* __restrict__ ts,
+                                                              float* __restrict__ g_out) {
   constexpr int V = Elem<T>::kVec;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rs = blockIdx.y;
   const int col = (blockIdx.x * 64 + lane) * V;
   const int rows_per = (n + row_splits - 1) / row_splits;
   const int rb = rs * rows_per, re = min(n, rb + rows_per);
+  __shared__ float red[4][64][2 * V + 1];
+  float t = 0.f, sv = 1.f, suv = 0.f;
+  if constexpr (FUSED) {
+    t = ts[0];
+    soft_topk_bwd_sums<256>(g, xs, t, n, reinterpret_cast<float (*)[4]>(&red[0][0][0]), sv, suv);   // (g = dps here)
+    __syncthreads();                                   // red is reused below
+  }
   float a0[V], a1[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
-  if (col < d) {
+  if (col < d || (FUSED && blockIdx.x == 0)) {
+    const int colc = min(col, d - V);
     for (int r0 = rb + wave; r0 < re; r0 += 32) {          // 8 rows in flight per wave (clamped); rows are added in order
       float v[8][V], gr[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int r = min(r0 + 4 * u, re - 1);
-        load_vec(h + (int64_t)r * d + col, v[u]);
-        gr[u] = g[r];
+        load_vec(h + (int64_t)r * d + colc, v[u]);
+        if constexpr (FUSED) gr[u] = soft_topk_bwd_elem(g[r], xs[r], t, sv, suv);
+        else gr[u] = g[r];
+      }
+      if constexpr (FUSED) {
+        if (blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (r0 + 4 * u < re) g_out[r0 + 4 * u] = gr[u];
+        }
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
@@ -242,7 +264,6 @@ __global__ __launch_bounds__(256) void wcolsum_partial_kernel(const T* __restric
         }
     }
   }
-  __shared__ float red[4][64][2 * V + 1];
 #pragma unroll
   for (int i = 0; i < V; ++i) { red[wave][lane][i] = a0[i]; red[wave][lane][V + i] = a1[i]; }
   __syncthreads();
@@ -310,9 +331,73 @@ __global__ __launch_bounds__(256) void dk_finish_kernel(const float* __restrict_
   dbq[h] = kb * s;
 }
 
-// out[r][c] = a[r] * b[c]   (rank-1 weight gradient, fp32)
-__global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ a, const float* __restrict__ b, int rows,
-                                                    int cols, float* __restrict__ out) {
+// wcolsum_finish + kbar_finish + dk_finish of ONE row in one launch (training backward, small-batch form): block b finishes columns
+// 256 b .. of xsum / gx / xbar and elements 256 b .. of kbar / dk / a / dbq / dbk; every block that needs sum_i g_i rebuilds it
+// itself (<= 4096 values out of L2, wcolsum_finish_kernel's order).  Element for element the three kernels' arithmetic.
+template <typename TW>
+__global__ __launch_bounds__(256) void train_bwd_finish_kernel(const float* __restrict__ wpart, const float* __restrict__ g, int n, int d,
+                                                               int row_splits, const float* __restrict__ part1, const float* __restrict__ dkraw,
+                                                               int KS, int hd, const TW* __restrict__ bk, const TW* __restrict__ bq, float rs,
+                                                               float* __restrict__ xsum, float* __restrict__ gx, float* __restrict__ xbar,
+                                                               float* __restrict__ sg_out, float* __restrict__ kbar, float* __restrict__ dk,
+                                                               float* __restrict__ a, float* __restrict__ dbq, float* __restrict__ dbk) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < d) {
+    float va = 0.f, vb = 0.f;
+    for (int r0 = 0; r0 < row_splits; r0 += 16) {            // 2 x 16 loads in flight (clamped), added in rs order
+      float ta[16], tb[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int64_t rsp = min(r0 + u, row_splits - 1);
+        ta[u] = wpart[rsp * 2 * d + c];
+        tb[u] = wpart[rsp * 2 * d + d + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (r0 + u < row_splits) { va += ta[u]; vb += tb[u]; }
+    }
+    xsum[c] = va;
+    gx[c] = vb;
+    xbar[c] = va / (float)n;
+  }
+  if (blockIdx.x * 256 >= hd && blockIdx.x != 0) return;     // (block-uniform)
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += g[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  const float s = (red[0] + red[1]) + (red[2] + red[3]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) sg_out[0] = s;
+  const int hh = c;
+  if (hh >= hd) return;
+  float v = 0.f;                                             // kbar_finish_kernel (M = 1)
+  for (int k0 = 0; k0 < KS; k0 += 16) {
+    float tk[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) tk[u] = part1[(int64_t)min(k0 + u, KS - 1) * hd + hh];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (k0 + u < KS) v += tk[u];
+  }
+  v += load_elem(bk + hh);
+  kbar[hh] = v;
+  const float vd = strided_sum(dkraw + hh, KS, hd);          // dk_finish_kernel
+  const float dkv = (vd + load_elem(bq + hh) * s) * rs / (float)n;
+  dk[hh] = dkv;
+  dbk[hh] = dkv * (float)n;
+  const float kb = v * rs;
+  a[hh] = kb;
+  dbq[hh] = kb * s;
+}
+
+// both rank-1 weight gradients in one launch: blockIdx.z picks (a0 (x) b0 -> out0) or (a1 (x) b1 -> out1)
+__global__ __launch_bounds__(256) void outer_pair_kernel(const float* __restrict__ a0, const float* __restrict__ b0, float* __restrict__ out0,
+                                                         const float* __restrict__ a1, const float* __restrict__ b1, float* __restrict__ out1,
+                                                         int rows, int cols) {
+  const float* a = blockIdx.z ? a1 : a0;
+  const float* b = blockIdx.z ? b1 : b0;
+  float* out = blockIdx.z ? out1 : out0;
   const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (c4 >= cols) return;
   const f32x4 bv = *reinterpret_cast<const f32x4*>(b + c4);
@@ -460,7 +545,8 @@ static int train_fwd_impl(hipStream_t st, const T* h, int64_t n, int64_t k, cons
 template <typename T, typename TW>
 static int scores_bwd_impl(hipStream_t st, const float* g, const T* h, int64_t n, const vsel_scorer* sc, char* ws,
                            const TrainPlan& tp, float* dwq, float* dbq, float* dwk, float* dbk, T* dh, const T* dhn,
-                           const float* ps, float* factors = nullptr) {
+                           const float* ps, float* factors = nullptr, const float* fuse_dps = nullptr,
+                           const float* fuse_scores = nullptr, const float* fuse_ts = nullptr) {
   constexpr int V = Elem<T>::kVec;
   const int d = (int)sc->d, hd = (int)sc->hd;
   const LisPlan& p = tp.lis;
@@ -483,16 +569,41 @@ static int scores_bwd_impl(hipStream_t st, const float* g, const T* h, int64_t n
   const float rs = 1.0f / (float)sqrt((double)hd);
   const unsigned row_blocks = (unsigned)std::min<int64_t>(cdiv(n, 4), 4096);
 
-  VSEL_LAUNCH((wcolsum_partial_kernel<T>), dim3((unsigned)cdiv(d, 64 * V), tp.wsplits), dim3(256), 0, st, h, g, (int)n,
-                     d, tp.wsplits, wpart);
+  vsel_segments seg1{1, n, n, 1, 1, nullptr, nullptr};
+  const bool small = small_path_ok(&seg1, sc, p);
+  // fused = dps / scores / ts given instead of g (train_bwd_impl, one row of <= 4096 scores, bf16 weights on the small-batch form):
+  // five launches -- row dots | weighted column sums with the soft top-k backward in their prologue | both projections | one finish |
+  // both rank-1 writes -- instead of ten (knob TRAIN_FUSED; the same bits either way)
+  const bool fused = fuse_dps != nullptr;
+  if (fused) {
+    if constexpr (std::is_same<TW, bf16_t>::value) {
+      float* gbuf = (float*)(ws + tp.off_g);
+      VSEL_LAUNCH((wcolsum_partial_kernel<T, true>), dim3((unsigned)cdiv(d, 64 * V), tp.wsplits), dim3(256), 0, st, h, fuse_dps, (int)n,
+                  d, tp.wsplits, wpart, fuse_scores, fuse_ts, gbuf);
+      VSEL_AFTER_LAUNCH(st, "wcolsum_partial_kernel");
+      VSEL_LAUNCH(proj_nt_small_pair_kernel, dim3((unsigned)cdiv(hd, 32), p.ks1, 2), dim3(64), 0, st, wpart, wpart + d, make_view(&seg1), 1,
+                  tp.wsplits, (const uint16_t*)sc->wk, (const uint16_t*)sc->wq, hd, d, p.kslice1, part1, dkraw, (int64_t)2 * d, 1, 0);
+      VSEL_AFTER_LAUNCH(st, "proj_nt_small_pair_kernel");
+      VSEL_LAUNCH((train_bwd_finish_kernel<TW>), dim3((unsigned)std::max<int64_t>(cdiv(d, 256), cdiv(hd, 256))), dim3(256), 0, st, wpart, gbuf,
+                  (int)n, d, tp.wsplits, part1, dkraw, p.ks1, hd, (const TW*)sc->bk, (const TW*)sc->bq, rs, xsum, gx, xbar, sg, kbar, dk, a,
+                  dbq, dbk);
+      VSEL_AFTER_LAUNCH(st, "train_bwd_finish_kernel");
+      if (!factors) {
+        const dim3 og((unsigned)cdiv(d, 1024), (unsigned)std::min<int>(hd, 512), 2);
+        VSEL_LAUNCH(outer_pair_kernel, og, dim3(256), 0, st, a, gx, dwq, dk, xsum, dwk, hd, d);
+        VSEL_AFTER_LAUNCH(st, "outer_pair_kernel");
+      }
+    }
+    g = (const float*)(ws + tp.off_g);               // (dh below)
+  } else {
+  VSEL_LAUNCH((wcolsum_partial_kernel<T, false>), dim3((unsigned)cdiv(d, 64 * V), tp.wsplits), dim3(256), 0, st, h, g, (int)n,
+                     d, tp.wsplits, wpart, nullptr, nullptr, nullptr);
   VSEL_AFTER_LAUNCH(st, "wcolsum_partial_kernel");
   VSEL_LAUNCH(wcolsum_finish_kernel, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st, wpart, g, (int)n, d, tp.wsplits,
                      xsum, gx, xbar, sg);
   VSEL_AFTER_LAUNCH(st, "wcolsum_finish_kernel");
   // kbar = Wk xbar + bk.  bf16 weights: the forward's single-wave-per-tile bf16x3 kernel, its prologue summing the row splits
   // of wpart itself (same bits as the forward's kbar); else the fp32-input MFMA form
-  vsel_segments seg1{1, n, n, 1, 1, nullptr, nullptr};
-  const bool small = small_path_ok(&seg1, sc, p);
   if (small) {
     VSEL_LAUNCH(proj_nt_small_kernel, dim3((unsigned)cdiv(hd, 32), p.ks1), dim3(64), 0, st, wpart, make_view(&seg1), 1,
                        tp.wsplits, (const uint16_t*)sc->wk, hd, d, p.kslice1, part1, (int64_t)2 * d, 1);
@@ -519,11 +630,10 @@ static int scores_bwd_impl(hipStream_t st, const float* g, const T* h, int64_t n
                      (const TW*)sc->bq, kbar, sg, rs, (int)n, dk, a, dbq, dbk);
   VSEL_AFTER_LAUNCH(st, "dk_finish_kernel");
   if (!factors) {
-    const dim3 og((unsigned)cdiv(d, 1024), (unsigned)std::min<int>(hd, 512));
-    VSEL_LAUNCH(outer_kernel, og, dim3(256), 0, st, a, gx, hd, d, dwq);
-    VSEL_AFTER_LAUNCH(st, "outer_kernel");
-    VSEL_LAUNCH(outer_kernel, og, dim3(256), 0, st, dk, xsum, hd, d, dwk);
-    VSEL_AFTER_LAUNCH(st, "outer_kernel");
+    const dim3 og((unsigned)cdiv(d, 1024), (unsigned)std::min<int>(hd, 512), 2);
+    VSEL_LAUNCH(outer_pair_kernel, og, dim3(256), 0, st, a, gx, dwq, dk, xsum, dwk, hd, d);
+    VSEL_AFTER_LAUNCH(st, "outer_pair_kernel");
+  }
   }
   if (dh) {
     VSEL_LAUNCH((gemm_nn_kernel<TW>), dim3((unsigned)cdiv(d, 256), 1, p.ks2), dim3(64), 0, st, kbar, (const TW*)sc->wq, 1,
@@ -553,6 +663,9 @@ static int train_bwd_impl(hipStream_t st, const T* dhn, const T* h, int64_t n, c
   const unsigned row_blocks = (unsigned)std::min<int64_t>(cdiv(n, 4), 4096);
   VSEL_LAUNCH((rowdot_kernel<T>), dim3(row_blocks), dim3(256), 0, st, dhn, h, ps, y, d_ps_ext, dl_dbce, (int)n, d, dps);
   VSEL_AFTER_LAUNCH(st, "rowdot_kernel");
+  vsel_segments seg1{1, n, n, 1, 1, nullptr, nullptr};
+  if (std::is_same<TW, bf16_t>::value && n <= 4096 && knob(VSEL_KNOB_TRAIN_FUSED) != 0 && small_path_ok(&seg1, sc, tp.lis))
+    return scores_bwd_impl<T, TW>(st, nullptr, h, n, sc, ws, tp, dwq, dbq, dwk, dbk, dh, dhn, ps, factors, dps, scores, ts);
   int rc = launch_soft_topk_bwd(st, dps, scores, ts, 1, n, g);
   if (rc) return rc;
   return scores_bwd_impl<T, TW>(st, g, h, n, sc, ws, tp, dwq, dbq, dwk, dbk, dh, dhn, ps, factors);

@@ -27,24 +27,29 @@ __device__ __forceinline__ float block_sum(float v, float (*red)[NW], int slot) 
 
 // ---- TopK.backward (FT/compression_method/selector_model.py:60-70), shared by soft_topk_bwd_kernel and the training backward's fused
 // sweep (train.hip): the two block sums over one row by NT threads in a fixed order, and one element of the gradient.
+// Contraction is OFF inside both and every fused multiply-add is written out: hipcc vectorises the standalone kernel's loops (packed
+// fp32 pairs) and not the fused sweep's, and left to itself it contracts a * b + c in one and not in the other -- the two forms then
+// differ in the last bit of g, i.e. in all of dbq = kbar rs sum_i g_i (a sum that is 0 in exact arithmetic).
 template <int NT>
 __device__ __forceinline__ void soft_topk_bwd_sums(const float* __restrict__ g, const float* __restrict__ x, float t, int n,
                                                    float (*red)[NT / 64], float& sv_out, float& suv_out) {
+#pragma clang fp contract(off)
   float sv = 0.f, suv = 0.f;
   for (int i = threadIdx.x; i < n; i += NT) {
     const float p = sigmoidf_ref(x[i] + t);
     const float v = p * (1.0f - p);             // :66  sigmoid'(x + t)
     sv += v;
-    suv += g[i] * v;
+    suv = __builtin_fmaf(g[i], v, suv);
   }
   sv_out = block_sum<NT / 64>(sv, red, 0);      // :67
   suv_out = block_sum<NT / 64>(suv, red, 1);    // :70 uv.sum()
 }
 __device__ __forceinline__ float soft_topk_bwd_elem(float gi, float xi, float t, float sv, float suv) {
+#pragma clang fp contract(off)
   const float p = sigmoidf_ref(xi + t);
   const float v = p * (1.0f - p);
-  const float uv = gi * v;                      // :69
-  return (-suv * v) / sv + uv;                  // :70-71
+  const float q = (-suv * v) / sv;              // :70
+  return __builtin_fmaf(gi, v, q);              // :69, :71  uv - uv.sum() v / v.sum()
 }
 
 // ---- the threshold of _find_ts (selector_model.py:72-86) -------------------------------------------------------------------

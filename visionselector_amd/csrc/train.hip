@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void dk_finish_kernel(const float* __restrict_
   if (h >= hd) return;
   const float v = strided_sum(part + h, KS, hd);             // (ks order, all slab loads in flight)
   const float s = sg[0];
-  const float dkv = (v + load_elem(bq + h) * s) * rs / (float)n;
+  const float dkv = __builtin_fmaf(load_elem(bq + h), s, v) * rs / (float)n;     // (written out: the same bits in train_bwd_finish_kernel)
   dk[h] = dkv;
   dbk[h] = dkv * (float)n;
   const float kb = kbar[h] * rs;
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void train_bwd_finish_kernel(const float* __re
   v += load_elem(bk + hh);
   kbar[hh] = v;
   const float vd = strided_sum(dkraw + hh, KS, hd);          // dk_finish_kernel
-  const float dkv = (vd + load_elem(bq + hh) * s) * rs / (float)n;
+  const float dkv = __builtin_fmaf(load_elem(bq + hh), s, vd) * rs / (float)n;
   dk[hh] = dkv;
   dbk[hh] = dkv * (float)n;
   const float kb = v * rs;

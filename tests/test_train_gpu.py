@@ -233,10 +233,11 @@ def test_train_bwd_factors_rebuild_the_dense_gradients(ops):
 
 
 @pytest.mark.parametrize("shape", [(3584, 1792, 2304), (2048, 1024, 600), (4096, 2048, 4000), (2048, 1024, 37)])
-def test_train_backward_five_launch_form_is_bit_identical(ops, shape):
+def test_train_backward_four_launch_form_is_bit_identical(ops, shape):
     """The fused training backward (knob train_fused: soft top-k backward in the prologue of the weighted column sums, both projections in
-    one launch, one finish kernel, both rank-1 writes in one launch) against the ten-launch chain: every output bit for bit, dense and
-    rank-1-factor forms, with and without the token gradient and the external BCE gradient."""
+    one launch, the finish arithmetic inside the launch of both rank-1 writes -- a finish kernel of its own in the factor form) against the
+    ten-launch chain: every output bit for bit, dense and rank-1-factor forms, with and without the token gradient and the external BCE
+    gradient."""
     from visionselector_amd import _native as N
     d, hd, n = shape
     k = max(1, int(n * 0.2))
@@ -256,7 +257,7 @@ def test_train_backward_five_launch_form_is_bit_identical(ops, shape):
                     torch.cuda.synchronize()
                     names = set(N.profile_stop())
                     fac = ops.lis_train_bwd_factors(dhn, h, wq, bq, wk, bk, ps, y, scores, ts, d_ps_ext, w, need_dh=need_dh)
-                assert ("train_bwd_finish_kernel" in names) == bool(fused) and ("soft_topk_bwd_kernel" in names) == (not fused), names
+                assert ("outer_finish_pair_kernel" in names) == bool(fused) and ("soft_topk_bwd_kernel" in names) == (not fused), names
                 outs[fused] = [t for t in dense if t is not None] + [t for t in (fac if isinstance(fac, (tuple, list)) else [fac]) if t is not None]
             assert len(outs[0]) == len(outs[1])
             for a_, b_ in zip(outs[1], outs[0]):

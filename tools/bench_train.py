@@ -7,11 +7,14 @@ import sys
 import torch
 
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from visionselector_amd import _native, ops  # noqa: E402
+from visionselector_amd import _native  # noqa: E402
+if "--lib" in sys.argv:
+    _native.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+from visionselector_amd import ops  # noqa: E402
 
 d, hd = 3584, 1792
 res = {}
-for n in (1024, 2304, 8192):
+for n in ((int(sys.argv[sys.argv.index("--n") + 1]),) if "--n" in sys.argv else (1024, 2304, 8192)):
     k = int(n * 0.2)
     g = torch.Generator(device="cuda").manual_seed(0)
     h = torch.randn(n, d, device="cuda", generator=g).bfloat16()

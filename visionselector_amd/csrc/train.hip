@@ -19,12 +19,45 @@ int launch_soft_topk_fwd(hipStream_t st, const float* xs, int64_t b, int64_t n, 
 int launch_soft_topk_bwd(hipStream_t st, const float* g, const float* xs, const float* ts, int64_t b, int64_t n, float* gx);
 
 // h_new[i, :] = (ps[i] * h[i, :]).type(dtype)     (:164-166)   wave per row
-template <typename T>
+// BCE: one EXTRA workgroup (the last) computes the constraint loss of the row instead of rows of h_new -- bce = mean_i
+// -(y_i max(log p_i, -100) + (1 - y_i) max(log(1 - p_i), -100)) (:310, ATen clamp) with the thread -> element map and the summation
+// order train_tail_kernel used when it still did this itself (thread (wave, lane): elements wave kpw 64 + lane + 64 j in j order, then
+// wave, then waves 0..3); ps comes from the tail's workgroup 0, y from its workgroup 1 (launch order), so the loss no longer sits on the
+// soft top-k's critical path.
+template <typename T, bool BCE>
 __global__ __launch_bounds__(256) void mask_apply_kernel(const T* __restrict__ h, const float* __restrict__ ps, int n,
-                                                         int d, T* __restrict__ out) {
+                                                         int d, T* __restrict__ out, const float* __restrict__ y,
+                                                         float* __restrict__ bce) {
   constexpr int V = Elem<T>::kVec;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int r = blockIdx.x * 4 + wave; r < n; r += gridDim.x * 4) {
+  const int row_blocks = BCE ? gridDim.x - 1 : gridDim.x;
+  if constexpr (BCE) {
+    if ((int)blockIdx.x == row_blocks) {
+      __shared__ float red[2][4];
+      const int kpw = (n + 255) / 256;
+      const int e0 = wave * kpw * 64 + lane;
+      float bacc = 0.f;
+      for (int j0 = 0; j0 < kpw; j0 += 16) {           // 2 x 16 loads in flight (clamped), added in j order
+        float tp[16], ty[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int e = min(e0 + 64 * (j0 + u), n - 1);
+          tp[u] = ps[e];
+          ty[u] = y[e];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (j0 + u < kpw && e0 + 64 * (j0 + u) < n) {
+            const float p = tp[u], yv = ty[u];
+            bacc += (yv - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - yv * fmaxf(logf(p), -100.0f);
+          }
+      }
+      const float btot = block_sum<4>(bacc, red, 0);
+      if (threadIdx.x == 0) bce[0] = btot / (float)n;
+      return;
+    }
+  }
+  for (int r = blockIdx.x * 4 + wave; r < n; r += row_blocks * 4) {
     const float p = ps[r];
     const T* src = h + (int64_t)r * d;
     T* dst = out + (int64_t)r * d;
@@ -65,15 +98,15 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ ps,
   }
 }
 
-// The forward's tail for one row of N <= 256 KPT scores in ONE launch (three before: soft top-k, hard top-k mask, BCE):
-//   ts, ps = _find_ts(scores, k)                 (find_ts_newton, as soft_topk_fwd_kernel)
-//   y      = hard top-k mask of the scores       (topk_select_reg_kernel's integer select: larger key first, then lower index)
-//   bce    = mean_i BCE(ps_i, y_i)               (ATen's -100 clamp; fixed summation order: wave, then waves 0..3)
+// The forward's tail for one row of N <= 256 KPT scores in ONE launch of TWO workgroups (three launches before round 2, one workgroup
+// until round 6: the root and the select are independent, and run back to back they were 12.8 us of a 49 us forward):
+//   workgroup 0:  ts, ps = _find_ts(scores, k)   (find_ts_newton, as soft_topk_fwd_kernel)
+//   workgroup 1:  y      = hard top-k mask of the scores (topk_select_reg_kernel's integer select: larger key first, then lower index)
+//   bce = mean_i BCE(ps_i, y_i) is left to mask_apply_kernel's extra workgroup (next launch).
 // Wave w owns the contiguous elements [w span, (w + 1) span), element j of a lane = e0 + 64 j.
 template <int KPT>
 __global__ __launch_bounds__(256) void train_tail_kernel(const float* __restrict__ xs, int n, int k, float* __restrict__ ps,
-                                                         float* __restrict__ ts, float* __restrict__ y,
-                                                         float* __restrict__ bce) {
+                                                         float* __restrict__ ts, float* __restrict__ y) {
   constexpr int NT = 256, NW = 4;
   __shared__ float red[6][NW];
   __shared__ uint32_t hist[4][256];
@@ -82,32 +115,41 @@ __global__ __launch_bounds__(256) void train_tail_kernel(const float* __restrict
   const int kpw = (n + NT - 1) / NT;                  // 64-element groups per wave (<= KPT)
   const int e0 = wave * kpw * 64 + lane;
   float xr[KPT];
-  float mx = -INFINITY, mn = INFINITY, sx = 0.f;
 #pragma unroll
   for (int j = 0; j < KPT; ++j) xr[j] = xs[min(e0 + 64 * j, n - 1)];      // unconditional (clamped) loads
+  if (blockIdx.x == 0) {
+    float mx = -INFINITY, mn = INFINITY, sx = 0.f;
 #pragma unroll
-  for (int j = 0; j < KPT; ++j) {
-    const bool ok = j < kpw && e0 + 64 * j < n;
-    if (ok) { mx = fmaxf(mx, xr[j]); mn = fminf(mn, xr[j]); sx += xr[j]; }
-    else xr[j] = -INFINITY;                           // sigmoid(-inf + t) = 0: padding never contributes
+    for (int j = 0; j < KPT; ++j) {
+      const bool ok = j < kpw && e0 + 64 * j < n;
+      if (ok) { mx = fmaxf(mx, xr[j]); mn = fminf(mn, xr[j]); sx += xr[j]; }
+      else xr[j] = -INFINITY;                           // sigmoid(-inf + t) = 0: padding never contributes
+    }
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    if (lane == 0) { red[4][wave] = mx; red[5][wave] = mn; }
+    __syncthreads();
+    mx = red[4][0]; mn = red[5][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { mx = fmaxf(mx, red[4][w]); mn = fminf(mn, red[5][w]); }
+    // ---- _find_ts (selector_model.py:72-86): the same root by bracketed Newton steps (softtopk.h, find_ts_newton) --------------
+    __syncthreads();                                  // red[4..5] are reused by the iteration
+    const float t = find_ts_newton<NW, NW, KPT>(xr, sx, mx, mn, n, k, red);
+    if (tid == 0) ts[0] = t;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int e = e0 + 64 * j;
+      if (j < kpw && e < n) ps[e] = sigmoidf_ref(xr[j] + t);          // :86
+    }
+    return;
   }
+  // ---- hard top-k mask: 4-pass radix select on the ordered keys, then the ordered tie rule ------------------------------
 #pragma unroll
   for (int p4 = 0; p4 < 4; ++p4) hist[p4][tid] = 0;
-  mx = wave_max(mx);
-  mn = wave_min(mn);
-  if (lane == 0) { red[4][wave] = mx; red[5][wave] = mn; }
-  __syncthreads();
-  mx = red[4][0]; mn = red[5][0];
-#pragma unroll
-  for (int w = 1; w < NW; ++w) { mx = fmaxf(mx, red[4][w]); mn = fminf(mn, red[5][w]); }
-  // ---- _find_ts (selector_model.py:72-86): the same root by bracketed Newton steps (softtopk.h, find_ts_newton) ----------------
-  __syncthreads();                                  // red[4..5] are reused by the iteration
-  const float t = find_ts_newton<NW, NW, KPT>(xr, sx, mx, mn, n, k, red);
-  if (tid == 0) ts[0] = t;
-  // ---- hard top-k mask: 4-pass radix select on the ordered keys, then the ordered tie rule ------------------------------
   uint32_t key[KPT];
 #pragma unroll
   for (int j = 0; j < KPT; ++j) key[j] = (j < kpw && e0 + 64 * j < n) ? order_key(xr[j]) : 0u;
+  __syncthreads();                                    // the zeroed histograms
   uint32_t prefix = 0, maskbits = 0, kk = (uint32_t)k;
 #pragma unroll 1
   for (int pass = 3; pass >= 0; --pass) {
@@ -152,8 +194,6 @@ __global__ __launch_bounds__(256) void train_tail_kernel(const float* __restrict
   for (int wv = 0; wv < NW; ++wv)
     if (wv < wave) run_eq += wtot[wv][1];
   const unsigned long long below = (1ull << lane) - 1ull;
-  // ---- ps, y, BCE ---------------------------------------------------------------------------------------------------
-  float bacc = 0.f;
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
     const int e = e0 + 64 * j;
@@ -161,17 +201,9 @@ __global__ __launch_bounds__(256) void train_tail_kernel(const float* __restrict
     const bool eq = (beq[j] >> lane) & 1ull;
     const uint32_t eq_before = run_eq + __popcll(beq[j] & below);
     const bool sel = valid && (key[j] > thr || (eq && eq_before < need));
-    if (valid) {
-      const float p = sigmoidf_ref(xr[j] + t);          // :86
-      const float yv = sel ? 1.0f : 0.0f;
-      ps[e] = p;
-      y[e] = yv;
-      bacc += (yv - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - yv * fmaxf(logf(p), -100.0f);
-    }
+    if (valid) y[e] = sel ? 1.0f : 0.0f;
     run_eq += __popcll(beq[j]);
   }
-  const float btot = block_sum<NW>(bacc, red, 0);
-  if (tid == 0) bce[0] = btot / (float)n;
 }
 
 // dps[i] = <d_hnew[i,:], h[i,:]> + d_ps_ext[i] + dl_dbce * (p - y) / max((1 - p) p, 1e-12) / N     wave per row
@@ -186,6 +218,23 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ dhn, 
     const T* a = dhn + (int64_t)r * d;
     const T* b = h + (int64_t)r * d;
     float acc = 0.f;
+    if (d <= 8 * 64 * V) {
+      // both rows whole in flight (2 x <= 8 loads per lane, clamped): one round trip per row pair instead of two; the FMAs in the
+      // order of the loop below
+      float va[8][V], vb[8][V];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int cc = min(lane * V + u * 64 * V, d - V);
+        load_vec(a + cc, va[u]);
+        load_vec(b + cc, vb[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (lane * V + u * 64 * V < d) {
+#pragma unroll
+          for (int q = 0; q < V; ++q) acc = fmaf(va[u][q], vb[u][q], acc);
+        }
+    } else
     for (int c0 = lane * V; c0 < d; c0 += 4 * 64 * V) {      // 2 x 4 loads in flight (clamped); same order of the FMAs
       float va[4][V], vb[4][V];
 #pragma unroll
@@ -217,51 +266,64 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ dhn, 
 // soft_topk_bwd_kernel<256>'s two block sums over (dps, scores) (same threads, same order: the same bits in every workgroup) and each
 // wave turns dps[r] into g[r] for the rows it adds; the workgroups of column tile 0 also leave g[r] in g_out (sum_i g_i, dh).  One
 // launch and one dependent round trip fewer than soft_topk_bwd + this sweep.
-template <typename T, bool FUSED>
+// NWORD = 32-bit words per lane and row (4 / 2 / 1: 16- / 8- / 4-byte loads): the narrower forms give 2 x / 4 x the column tiles
+// when (column tiles x row chunks) would leave CUs idle -- one image is 7 x 18 = 126 workgroups at 16 bytes per lane, each pulling
+// 128 KB through ONE CU's memory pipe.  Per column the rows are added in the same order whatever the width: the same bits.
+template <typename T, bool FUSED, int NWORD>
 __global__ __launch_bounds__(256) void wcolsum_partial_kernel(const T* __restrict__ h, const float* __restrict__ g, int n,
                                                               int d, int row_splits, float* __restrict__ partial,
                                                               const float* __restrict__ xs, const float* __restrict__ ts,
                                                               float* __restrict__ g_out) {
-  constexpr int V = Elem<T>::kVec;
+  constexpr int V = NWORD * (4 / (int)sizeof(T));                   // elements per lane
+  typedef uint32_t raw_t __attribute__((ext_vector_type(NWORD)));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rs = blockIdx.y;
   const int col = (blockIdx.x * 64 + lane) * V;
-  const int rows_per = (n + row_splits - 1) / row_splits;
+  const int rows_per = (n + row_splits - 1) / row_splits;           // <= 128 (make_train_plan: the forward's 128-row chunks)
   const int rb = rs * rows_per, re = min(n, rb + rows_per);
   __shared__ float red[4][64][2 * V + 1];
-  float t = 0.f, sv = 1.f, suv = 0.f;
-  if constexpr (FUSED) {
-    t = ts[0];
-    soft_topk_bwd_sums<256>(g, xs, t, n, reinterpret_cast<float (*)[4]>(&red[0][0][0]), sv, suv);   // (g = dps here)
-    __syncthreads();                                   // red is reused below
+  __shared__ float sred[2][4];
+  // (1) the wave's whole share of the chunk -- rows rb + wave + 4 q, q < 32 -- goes in flight at once as raw vectors (the launch is
+  // latency-bound: one round trip instead of four), under the prologue below
+  raw_t raw[32];
+  {
+    const T* base = h + min(col, d - V);
+#pragma unroll
+    for (int q = 0; q < 32; ++q) raw[q] = *reinterpret_cast<const raw_t*>(base + (int64_t)min(rb + wave + 4 * q, re - 1) * d);
   }
+  // (2) g of those rows: lane q holds row q's (one soft top-k backward element per lane instead of 32 uniform ones per wave)
+  const int myr = rb + wave + 4 * (lane & 31);
+  float gl = 0.f;
+  if constexpr (FUSED) {
+    const float t = ts[0];
+    float sv, suv;
+    soft_topk_bwd_sums<256>(g, xs, t, n, sred, sv, suv);            // (g = dps here)
+    if (myr < re) gl = soft_topk_bwd_elem(g[myr], xs[myr], t, sv, suv);
+    if (blockIdx.x == 0 && lane < 32 && myr < re) g_out[myr] = gl;
+  } else {
+    if (myr < re) gl = g[myr];
+  }
+  // (3) rows added in order q = 0, 1, ... (the order of the 8-rows-per-step loop this replaces)
   float a0[V], a1[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
-  if (col < d || (FUSED && blockIdx.x == 0)) {
-    const int colc = min(col, d - V);
-    for (int r0 = rb + wave; r0 < re; r0 += 32) {          // 8 rows in flight per wave (clamped); rows are added in order
-      float v[8][V], gr[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int r = min(r0 + 4 * u, re - 1);
-        load_vec(h + (int64_t)r * d + colc, v[u]);
-        if constexpr (FUSED) gr[u] = soft_topk_bwd_elem(g[r], xs[r], t, sv, suv);
-        else gr[u] = g[r];
-      }
-      if constexpr (FUSED) {
-        if (blockIdx.x == 0 && lane == 0) {
+  for (int q = 0; q < 32; ++q) {
+    if (rb + wave + 4 * q < re) {                      // (wave-uniform)
+      const float gr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl), q));
+      float v[V];
 #pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (r0 + 4 * u < re) g_out[r0 + 4 * u] = gr[u];
+      for (int wd = 0; wd < NWORD; ++wd) {
+        const uint32_t word = raw[q][wd];
+        if constexpr (sizeof(T) == 2) {
+          v[2 * wd] = __uint_as_float(word << 16);
+          v[2 * wd + 1] = __uint_as_float(word & 0xffff0000u);
+        } else {
+          v[wd] = __uint_as_float(word);
         }
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (r0 + 4 * u < re) {
-#pragma unroll
-          for (int i = 0; i < V; ++i) { a0[i] += v[u][i]; a1[i] = fmaf(gr[u], v[u][i], a1[i]); }
-        }
+      for (int i = 0; i < V; ++i) { a0[i] += v[i]; a1[i] = fmaf(gr, v[i], a1[i]); }
     }
   }
 #pragma unroll
@@ -275,6 +337,22 @@ __global__ __launch_bounds__(256) void wcolsum_partial_kernel(const T* __restric
       dst[d + col + i] = (red[0][lane][V + i] + red[1][lane][V + i]) + (red[2][lane][V + i] + red[3][lane][V + i]);
     }
   }
+}
+
+// the widest loads (16 / 8 / 4 bytes per lane) that still give ~200 workgroups; D must be a multiple of the lane's element count
+template <typename T, bool FUSED>
+static int launch_wcolsum(hipStream_t st, const T* h, const float* g, int n, int d, int wsplits, float* wpart, const float* xs,
+                          const float* ts, float* g_out) {
+  constexpr int E = 4 / (int)sizeof(T);                              // elements per 32-bit word
+  int nw = 4;
+  while (nw > 1 && (cdiv(d, 64 * nw * E) * wsplits < 200 || d % (nw * E) != 0)) nw >>= 1;
+  if (d % (nw * E) != 0) return fail(VSEL_ERR_UNSUPPORTED, "D must be a multiple of %d", nw * E);
+  const dim3 grid((unsigned)cdiv(d, 64 * nw * E), wsplits);
+  if (nw == 4) VSEL_LAUNCH((wcolsum_partial_kernel<T, FUSED, 4>), grid, dim3(256), 0, st, h, g, n, d, wsplits, wpart, xs, ts, g_out);
+  else if (nw == 2) VSEL_LAUNCH((wcolsum_partial_kernel<T, FUSED, 2>), grid, dim3(256), 0, st, h, g, n, d, wsplits, wpart, xs, ts, g_out);
+  else VSEL_LAUNCH((wcolsum_partial_kernel<T, FUSED, 1>), grid, dim3(256), 0, st, h, g, n, d, wsplits, wpart, xs, ts, g_out);
+  VSEL_AFTER_LAUNCH(st, "wcolsum_partial_kernel");
+  return VSEL_OK;
 }
 
 // xsum[c], gx[c], xbar[c] = xsum / N; block 0 also reduces sg = sum_i g_i
@@ -341,11 +419,34 @@ __global__ __launch_bounds__(256) void train_bwd_finish_kernel(const float* __re
                                                                float* __restrict__ xsum, float* __restrict__ gx, float* __restrict__ xbar,
                                                                float* __restrict__ sg_out, float* __restrict__ kbar, float* __restrict__ dk,
                                                                float* __restrict__ a, float* __restrict__ dbq, float* __restrict__ dbk) {
+  // Everything a thread will add is LOADED first (clamped, unconditional: one round trip for the whole kernel instead of one per
+  // stage -- the stages are a few hundred bytes each and every one of them used to wait ~1.5 us for its first line), then added in the
+  // three kernels' orders.  Rare shapes with more than 16 row splits / 24 k-slices / 16 x 256 scores take the looped tails below.
   const int c = blockIdx.x * 256 + threadIdx.x;
+  const int cc = min(c, d - 1), hh = min(c, hd - 1);
+  const bool do_h = blockIdx.x * 256 < hd || blockIdx.x == 0;           // (block-uniform) this block needs sum_i g_i
+  float ta[16], tb[16], tg[16], tk[16], td[24];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int64_t rsp = min(u, row_splits - 1);
+    ta[u] = wpart[rsp * 2 * d + cc];
+    tb[u] = wpart[rsp * 2 * d + d + cc];
+  }
+  if (do_h) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) tg[u] = g[min((int)threadIdx.x + 256 * u, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) tk[u] = part1[(int64_t)min(u, KS - 1) * hd + hh];
+#pragma unroll
+    for (int u = 0; u < 24; ++u) td[u] = dkraw[(int64_t)min(u, KS - 1) * hd + hh];
+  }
+  const float bkv = load_elem(bk + hh), bqv = load_elem(bq + hh);
   if (c < d) {
     float va = 0.f, vb = 0.f;
-    for (int r0 = 0; r0 < row_splits; r0 += 16) {            // 2 x 16 loads in flight (clamped), added in rs order
-      float ta[16], tb[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (u < row_splits) { va += ta[u]; vb += tb[u]; }
+    for (int r0 = 16; r0 < row_splits; r0 += 16) {           // (more than 16 row splits: wcolsum_finish_kernel's loop, same order)
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int64_t rsp = min(r0 + u, row_splits - 1);
@@ -360,30 +461,44 @@ __global__ __launch_bounds__(256) void train_bwd_finish_kernel(const float* __re
     gx[c] = vb;
     xbar[c] = va / (float)n;
   }
-  if (blockIdx.x * 256 >= hd && blockIdx.x != 0) return;     // (block-uniform)
+  if (!do_h) return;
   __shared__ float red[4];
   float acc = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) acc += g[i];
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+    if ((int)threadIdx.x + 256 * u < n) acc += tg[u];
+  for (int i = threadIdx.x + 4096; i < n; i += 256) acc += g[i];
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   const float s = (red[0] + red[1]) + (red[2] + red[3]);
   if (blockIdx.x == 0 && threadIdx.x == 0) sg_out[0] = s;
-  const int hh = c;
-  if (hh >= hd) return;
-  float v = 0.f;                                             // kbar_finish_kernel (M = 1)
-  for (int k0 = 0; k0 < KS; k0 += 16) {
-    float tk[16];
+  if (c >= hd) return;
+  float v = 0.f;                                             // kbar_finish_kernel (M = 1): ks order, 16 per batch
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+    if (u < KS) v += tk[u];
+  for (int k0 = 16; k0 < KS; k0 += 16) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) tk[u] = part1[(int64_t)min(k0 + u, KS - 1) * hd + hh];
 #pragma unroll
     for (int u = 0; u < 16; ++u)
       if (k0 + u < KS) v += tk[u];
   }
-  v += load_elem(bk + hh);
+  v += bkv;
   kbar[hh] = v;
-  const float vd = strided_sum(dkraw + hh, KS, hd);          // dk_finish_kernel
-  const float dkv = __builtin_fmaf(load_elem(bq + hh), s, vd) * rs / (float)n;
+  float vd = 0.f;                                            // dk_finish_kernel: strided_sum's order (ks order, 24 per batch)
+#pragma unroll
+  for (int u = 0; u < 24; ++u)
+    if (u < KS) vd += td[u];
+  for (int k0 = 24; k0 < KS; k0 += 24) {
+#pragma unroll
+    for (int u = 0; u < 24; ++u) td[u] = dkraw[(int64_t)min(k0 + u, KS - 1) * hd + hh];
+#pragma unroll
+    for (int u = 0; u < 24; ++u)
+      if (k0 + u < KS) vd += td[u];
+  }
+  const float dkv = __builtin_fmaf(bqv, s, vd) * rs / (float)n;
   dk[hh] = dkv;
   dbk[hh] = dkv * (float)n;
   const float kb = v * rs;
@@ -405,6 +520,138 @@ __global__ __launch_bounds__(256) void outer_pair_kernel(const float* __restrict
     const float av = a[r];
     f32x4 o = {av * bv[0], av * bv[1], av * bv[2], av * bv[3]};
     *reinterpret_cast<f32x4*>(out + (int64_t)r * cols + c4) = o;
+  }
+}
+
+// train_bwd_finish_kernel AND both rank-1 writes in one launch (the dense backward; the factor form has no rank-1 writes and keeps the
+// finish kernel): grid (ceil(D / 1024), kOuterRowGroups, 2 = {dWq, dWk}).  A workgroup rebuilds what it multiplies -- its 1024
+// columns of gx (dWq) / xsum (dWk) from the row-chunk partials, the a (dWq) / dk (dWk) of its <= 64 rows from the projection slabs,
+// sum_i g_i -- all loads up front, operation for operation the finish kernel's arithmetic (same bits), then streams its rows of the
+// gradient.  The row group 0 workgroups also leave gx / xsum / xbar, the column tile 0 workgroups kbar, a, dbq (dWq side) / dk, dbk
+// (dWk side), workgroup (0, 0, 0) sum_i g_i: everything the finish kernel left for the token-gradient stage.
+constexpr int kOuterRowGroups = 64;     // (32 / 128 row groups and non-temporal stores measured within +-1.5 us of this: profiles/EXPERIMENTS.md)
+template <typename TW>
+__global__ __launch_bounds__(256) void outer_finish_pair_kernel(const float* __restrict__ wpart, const float* __restrict__ g, int n, int d,
+                                                                int row_splits, const float* __restrict__ part1, const float* __restrict__ dkraw,
+                                                                int KS, int hd, const TW* __restrict__ bk, const TW* __restrict__ bq, float rs,
+                                                                float* __restrict__ xsum, float* __restrict__ gx, float* __restrict__ xbar,
+                                                                float* __restrict__ sg_out, float* __restrict__ kbar, float* __restrict__ dk,
+                                                                float* __restrict__ a, float* __restrict__ dbq, float* __restrict__ dbk,
+                                                                float* __restrict__ dwq, float* __restrict__ dwk) {
+  const int which = blockIdx.z;                                       // 0: dWq = a (x) gx      1: dWk = dk (x) xsum
+  const int tid = threadIdx.x;
+  const int c4 = (blockIdx.x * 256 + tid) * 4;
+  const bool c_ok = c4 < d;
+  const int by = blockIdx.y;
+  const int my_row = by + kOuterRowGroups * tid;                       // thread t < rows of the block: its row factor
+  const bool r_ok = tid < 64 && my_row < hd;
+  const int hh = r_ok ? my_row : 0;
+  __shared__ float red[4];
+  __shared__ float left[64];
+  // ---- all loads first ---------------------------------------------------------------------------------------------------
+  f32x4 tc[16];
+  {
+    const float* src = wpart + (which ? 0 : d) + (c_ok ? c4 : 0);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) tc[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)min(u, row_splits - 1) * 2 * d);
+  }
+  float tg[16], tk[24];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) tg[u] = g[min(tid + 256 * u, n - 1)];
+  {
+    const float* src = (which ? dkraw : part1) + hh;
+#pragma unroll
+    for (int u = 0; u < 24; ++u) tk[u] = src[(int64_t)min(u, KS - 1) * hd];
+  }
+  const float bkv = load_elem(bk + hh), bqv = load_elem(bq + hh);
+  // ---- column factor: the row-chunk partials in rs order (wcolsum_finish_kernel) -------------------------------------------
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+    if (u < row_splits) bv += tc[u];
+  for (int r0 = 16; r0 < row_splits; r0 += 16) {
+    const float* src = wpart + (which ? 0 : d) + (c_ok ? c4 : 0);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) tc[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)min(r0 + u, row_splits - 1) * 2 * d);
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (r0 + u < row_splits) bv += tc[u];
+  }
+  if (by == 0 && c_ok) {
+    if (which) {
+      *reinterpret_cast<f32x4*>(xsum + c4) = bv;
+      const float nf = (float)n;
+      f32x4 xb = {bv[0] / nf, bv[1] / nf, bv[2] / nf, bv[3] / nf};
+      *reinterpret_cast<f32x4*>(xbar + c4) = xb;
+    } else {
+      *reinterpret_cast<f32x4*>(gx + c4) = bv;
+    }
+  }
+  // ---- sum_i g_i (wcolsum_finish_kernel's order) ----------------------------------------------------------------------------
+  float acc = 0.f;
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+    if (tid + 256 * u < n) acc += tg[u];
+  for (int i = tid + 4096; i < n; i += 256) acc += g[i];
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  const float s = (red[0] + red[1]) + (red[2] + red[3]);
+  if (blockIdx.x == 0 && by == 0 && which == 0 && tid == 0) sg_out[0] = s;
+  // ---- row factor of this thread's row ------------------------------------------------------------------------------------
+  if (tid < 64) {
+    float lf = 0.f;
+    if (which == 0) {
+      float v = 0.f;                                            // kbar_finish_kernel: ks order, 16 per batch
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (u < KS) v += tk[u];
+      for (int k0 = 16; k0 < KS; k0 += 16) {
+        float t2[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t2[u] = part1[(int64_t)min(k0 + u, KS - 1) * hd + hh];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (k0 + u < KS) v += t2[u];
+      }
+      v += bkv;
+      const float kb = v * rs;
+      lf = kb;
+      if (blockIdx.x == 0 && r_ok) {
+        kbar[hh] = v;
+        a[hh] = kb;
+        dbq[hh] = kb * s;
+      }
+    } else {
+      float vd = 0.f;                                           // dk_finish_kernel: strided_sum's order (24 per batch)
+#pragma unroll
+      for (int u = 0; u < 24; ++u)
+        if (u < KS) vd += tk[u];
+      for (int k0 = 24; k0 < KS; k0 += 24) {
+        float t2[24];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) t2[u] = dkraw[(int64_t)min(k0 + u, KS - 1) * hd + hh];
+#pragma unroll
+        for (int u = 0; u < 24; ++u)
+          if (k0 + u < KS) vd += t2[u];
+      }
+      const float dkv = __builtin_fmaf(bqv, s, vd) * rs / (float)n;
+      lf = dkv;
+      if (blockIdx.x == 0 && r_ok) {
+        dk[hh] = dkv;
+        dbk[hh] = dkv * (float)n;
+      }
+    }
+    left[tid] = lf;
+  }
+  __syncthreads();
+  // ---- the workgroup's rows of the gradient ----------------------------------------------------------------------------------
+  if (!c_ok) return;
+  float* out = which ? dwk : dwq;
+  for (int i = 0, r = by; r < hd; ++i, r += kOuterRowGroups) {
+    const float av = left[i];
+    f32x4 o = {av * bv[0], av * bv[1], av * bv[2], av * bv[3]};
+    *reinterpret_cast<f32x4*>(out + (int64_t)r * d + c4) = o;
   }
 }
 
@@ -521,11 +768,11 @@ static int train_fwd_impl(hipStream_t st, const T* h, int64_t n, int64_t k, cons
   const int d = (int)sc->d;
   if (n <= 4096) {
     // soft top-k + hard top-k mask + BCE of the one row in one launch
-    if (n <= 1024) VSEL_LAUNCH(train_tail_kernel<4>, dim3(1), dim3(256), 0, st, scores, (int)n, (int)k, ps, ts, y, bce);
-    else VSEL_LAUNCH(train_tail_kernel<16>, dim3(1), dim3(256), 0, st, scores, (int)n, (int)k, ps, ts, y, bce);
+    if (n <= 1024) VSEL_LAUNCH(train_tail_kernel<4>, dim3(2), dim3(256), 0, st, scores, (int)n, (int)k, ps, ts, y);
+    else VSEL_LAUNCH(train_tail_kernel<16>, dim3(2), dim3(256), 0, st, scores, (int)n, (int)k, ps, ts, y);
     VSEL_AFTER_LAUNCH(st, "train_tail_kernel");
-    VSEL_LAUNCH((mask_apply_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv(n, 4), 4096)), dim3(256), 0, st, h, ps,
-                       (int)n, d, h_new);
+    VSEL_LAUNCH((mask_apply_kernel<T, true>), dim3((unsigned)std::min<int64_t>(cdiv(n, 4), 4096) + 1), dim3(256), 0, st, h, ps,
+                       (int)n, d, h_new, y, bce);
     VSEL_AFTER_LAUNCH(st, "mask_apply_kernel");
     return VSEL_OK;
   }
@@ -533,8 +780,8 @@ static int train_fwd_impl(hipStream_t st, const T* h, int64_t n, int64_t k, cons
   if (rc) return rc;
   rc = launch_select(st, scores, &seg, nullptr, y);
   if (rc) return rc;
-  VSEL_LAUNCH((mask_apply_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv(n, 4), 4096)), dim3(256), 0, st, h, ps,
-                     (int)n, d, h_new);
+  VSEL_LAUNCH((mask_apply_kernel<T, false>), dim3((unsigned)std::min<int64_t>(cdiv(n, 4), 4096)), dim3(256), 0, st, h, ps,
+                     (int)n, d, h_new, nullptr, nullptr);
   VSEL_AFTER_LAUNCH(st, "mask_apply_kernel");
   VSEL_LAUNCH(bce_kernel, dim3(1), dim3(1024), 0, st, ps, y, (int)n, bce);
   VSEL_AFTER_LAUNCH(st, "bce_kernel");
@@ -578,27 +825,30 @@ static int scores_bwd_impl(hipStream_t st, const float* g, const T* h, int64_t n
   if (fused) {
     if constexpr (std::is_same<TW, bf16_t>::value) {
       float* gbuf = (float*)(ws + tp.off_g);
-      VSEL_LAUNCH((wcolsum_partial_kernel<T, true>), dim3((unsigned)cdiv(d, 64 * V), tp.wsplits), dim3(256), 0, st, h, fuse_dps, (int)n,
-                  d, tp.wsplits, wpart, fuse_scores, fuse_ts, gbuf);
-      VSEL_AFTER_LAUNCH(st, "wcolsum_partial_kernel");
+      if (int rc = launch_wcolsum<T, true>(st, h, fuse_dps, (int)n, d, tp.wsplits, wpart, fuse_scores, fuse_ts, gbuf)) return rc;
       VSEL_LAUNCH(proj_nt_small_pair_kernel, dim3((unsigned)cdiv(hd, 32), p.ks1, 2), dim3(64), 0, st, wpart, wpart + d, make_view(&seg1), 1,
                   tp.wsplits, (const uint16_t*)sc->wk, (const uint16_t*)sc->wq, hd, d, p.kslice1, part1, dkraw, (int64_t)2 * d, 1, 0);
       VSEL_AFTER_LAUNCH(st, "proj_nt_small_pair_kernel");
-      VSEL_LAUNCH((train_bwd_finish_kernel<TW>), dim3((unsigned)std::max<int64_t>(cdiv(d, 256), cdiv(hd, 256))), dim3(256), 0, st, wpart, gbuf,
-                  (int)n, d, tp.wsplits, part1, dkraw, p.ks1, hd, (const TW*)sc->bk, (const TW*)sc->bq, rs, xsum, gx, xbar, sg, kbar, dk, a,
-                  dbq, dbk);
-      VSEL_AFTER_LAUNCH(st, "train_bwd_finish_kernel");
-      if (!factors) {
-        const dim3 og((unsigned)cdiv(d, 1024), (unsigned)std::min<int>(hd, 512), 2);
-        VSEL_LAUNCH(outer_pair_kernel, og, dim3(256), 0, st, a, gx, dwq, dk, xsum, dwk, hd, d);
-        VSEL_AFTER_LAUNCH(st, "outer_pair_kernel");
+      if (!factors && hd <= 64 * kOuterRowGroups) {
+        VSEL_LAUNCH((outer_finish_pair_kernel<TW>), dim3((unsigned)cdiv(d, 1024), kOuterRowGroups, 2), dim3(256), 0, st, wpart, gbuf, (int)n, d,
+                    tp.wsplits, part1, dkraw, p.ks1, hd, (const TW*)sc->bk, (const TW*)sc->bq, rs, xsum, gx, xbar, sg, kbar, dk, a, dbq, dbk,
+                    dwq, dwk);
+        VSEL_AFTER_LAUNCH(st, "outer_finish_pair_kernel");
+      } else {
+        VSEL_LAUNCH((train_bwd_finish_kernel<TW>), dim3((unsigned)std::max<int64_t>(cdiv(d, 256), cdiv(hd, 256))), dim3(256), 0, st, wpart, gbuf,
+                    (int)n, d, tp.wsplits, part1, dkraw, p.ks1, hd, (const TW*)sc->bk, (const TW*)sc->bq, rs, xsum, gx, xbar, sg, kbar, dk, a,
+                    dbq, dbk);
+        VSEL_AFTER_LAUNCH(st, "train_bwd_finish_kernel");
+        if (!factors) {
+          const dim3 og((unsigned)cdiv(d, 1024), (unsigned)std::min<int>(hd, 512), 2);
+          VSEL_LAUNCH(outer_pair_kernel, og, dim3(256), 0, st, a, gx, dwq, dk, xsum, dwk, hd, d);
+          VSEL_AFTER_LAUNCH(st, "outer_pair_kernel");
+        }
       }
     }
     g = (const float*)(ws + tp.off_g);               // (dh below)
   } else {
-  VSEL_LAUNCH((wcolsum_partial_kernel<T, false>), dim3((unsigned)cdiv(d, 64 * V), tp.wsplits), dim3(256), 0, st, h, g, (int)n,
-                     d, tp.wsplits, wpart, nullptr, nullptr, nullptr);
-  VSEL_AFTER_LAUNCH(st, "wcolsum_partial_kernel");
+  if (int rc = launch_wcolsum<T, false>(st, h, g, (int)n, d, tp.wsplits, wpart, nullptr, nullptr, nullptr)) return rc;
   VSEL_LAUNCH(wcolsum_finish_kernel, dim3((unsigned)cdiv(d, 256)), dim3(256), 0, st, wpart, g, (int)n, d, tp.wsplits,
                      xsum, gx, xbar, sg);
   VSEL_AFTER_LAUNCH(st, "wcolsum_finish_kernel");

@@ -627,11 +627,11 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 2 : 1) void varlen_attn_fwd_kern
         if (P > 1 && dt % P != pidx) continue;        // (two-stream form: every partial stores the d-tiles it owns)
         const int d0 = 32 * dt + 8 * g4 + 4 * hh;
         if (d0 >= kHeadDim) continue;                 // head_dim 80: the last d-tile is half padding
-        const uint32_t w0 = f32_to_bf16_bits(o[dt][4 * g4] * inv) | (f32_to_bf16_bits(o[dt][4 * g4 + 1] * inv) << 16);
-        const uint32_t w1 = f32_to_bf16_bits(o[dt][4 * g4 + 2] * inv) | (f32_to_bf16_bits(o[dt][4 * g4 + 3] * inv) << 16);
+        // (v_cvt_pk_bf16_f32 = round to nearest even, the software rounding bit for bit on finite values: 2 instructions per four values
+        // where f32_to_bf16_bits + the packing were ~22)
         uint2 pk;
-        pk.x = w0;
-        pk.y = w1;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk.x) : "v"(o[dt][4 * g4] * inv), "v"(o[dt][4 * g4 + 1] * inv));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk.y) : "v"(o[dt][4 * g4 + 2] * inv), "v"(o[dt][4 * g4 + 3] * inv));
         *reinterpret_cast<uint2*>(op + d0) = pk;
       }
   }

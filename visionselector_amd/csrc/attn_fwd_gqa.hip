@@ -38,6 +38,7 @@ constexpr int kCtl = kKV + 8 * kQRegion;         // control words (candidate ite
 constexpr int kLds = kCtl + 16;
 }  // namespace gqa
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ int g_gqa_work_counter[64];           // 64 launch slots in rotation (one counter per launch)
 
 __device__ __forceinline__ bf16x8_t gq_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8_t, v); }
@@ -487,28 +488,37 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_gqa_kernel(const uint16_t* __
       lse[(int64_t)(cur.qs + wave_qmin + e_j) * hq + head] = l_tot > 0.f ? (m_run + log2f(l_tot)) * 0.6931471805599453f : -INFINITY;
     char* const stage = smem + kQ0 + wave * kQRegion;
     const uint32_t wa = (uint32_t)(e_j * kRowBytes + 8 * e_hh) ^ (uint32_t)((e_j & 15) << 4);
+    // (round 6: the conversion spelled out -- two v_pk_mul_f32 and two v_cvt_pk_bf16_f32 per four values.  Left to hipcc, `(__bf16)(o * inv)`
+    // element by element became 48 conversions + 16 v_perm + 16 v_alignbit + 35 moves per wave and item, and the row stores a 64-bit
+    // address and an exec round trip each: 290 VALU per item, ~2.8 - 4 k cycles of an item's ~27 k with no MFMA in them.  Same RNE rounding:
+    // the same bits.)
+    const f32x2 inv2 = {inv, inv};
 #pragma unroll
     for (int dt = 0; dt < kDTiles; ++dt)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        // (v_cvt_pk_bf16_f32: round to nearest even, the software rounding of attn.hip bit for bit on finite values)
-        bf16x4_t pk;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(o[dt][4 * g4 + e] * inv);
-        *reinterpret_cast<bf16x4_t*>(stage + (wa ^ (uint32_t)((4 * dt + g4) << 4))) = pk;
+        const f32x2 lo = f32x2{o[dt][4 * g4], o[dt][4 * g4 + 1]} * inv2;
+        const f32x2 hi = f32x2{o[dt][4 * g4 + 2], o[dt][4 * g4 + 3]} * inv2;
+        u32x2 pk;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[0]) : "v"(lo[0]), "v"(lo[1]));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[1]) : "v"(hi[0]), "v"(hi[1]));
+        *reinterpret_cast<u32x2*>(stage + (wa ^ (uint32_t)((4 * dt + g4) << 4))) = pk;
       }
     // rows 4 i + (lane >> 4), position lane & 15 holds chunk (lane & 15) ^ (row & 15)
     char* const ob = reinterpret_cast<char*>(out + ((int64_t)(cur.qs + wave_qmin) * hq + head) * kHeadDim);
-    const uint32_t ostride = (uint32_t)hq * kHeadDim * 2;
+    const uint32_t ostride = (uint32_t)hq * kHeadDim * 2;            // a multiple of 256 bytes: the chunk bits below never carry into it
     const int rows = cur.qlen - wave_qmin;             // rows of this wave that exist (> 0 here)
     u32x4 rowv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) rowv[i] = *reinterpret_cast<const u32x4*>(stage + i * 1024 + el * 16);
+    // byte offset of row 4 i + e_l4, chunk e_p ^ ((4 i + e_l4) & 15):  (e_l4 ostride + i 4 ostride) ^ ((e_p ^ e_l4) << 4) ^ (((4 i) & 15) << 4)
+    uint32_t off = (uint32_t)e_l4 * ostride + (uint32_t)((e_p ^ e_l4) << 4);
+    const uint32_t step = 4u * ostride;
+    const int rows_left = rows - e_l4;                 // row 4 i + e_l4 exists  <=>  4 i < rows_left
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int r = 4 * i + e_l4;
-      const uint32_t c = (uint32_t)(e_p ^ (r & 15));
-      if (r < rows) *reinterpret_cast<u32x4*>(ob + (uint32_t)r * ostride + c * 16u) = rowv[i];
+      if (4 * i < rows_left) *reinterpret_cast<u32x4*>(ob + (off ^ (uint32_t)(((4 * i) & 15) << 4))) = rowv[i];
+      off += step;
     }
   };
 

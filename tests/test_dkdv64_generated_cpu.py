@@ -6,6 +6,10 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from visionselector_amd import build as vbuild  # noqa: E402
+
+vbuild.generate_bodies()                        # (what build() does first: the bodies are generated, not in history)
 GEN = os.path.join(ROOT, "tools", "gen_attn_bwd_dkdv64.py")
 INC = os.path.join(ROOT, "visionselector_amd", "csrc", "attn_bwd_dkdv64_body.inc")
 
@@ -13,7 +17,9 @@ INC = os.path.join(ROOT, "visionselector_amd", "csrc", "attn_bwd_dkdv64_body.inc
 def test_committed_body_is_the_generators_output(tmp_path):
     out = tmp_path / "body.inc"
     subprocess.check_call([sys.executable, GEN], env=dict(os.environ, DKDV64_OUT=str(out), DKDV64_OPTS=""), stdout=subprocess.DEVNULL)
-    assert out.read_text() == open(INC).read(), "run `python tools/gen_attn_bwd_dkdv64.py` and commit csrc/attn_bwd_dkdv64_body.inc"
+    assert out.read_text() == open(INC).read(), "stale generated body: run `python -m visionselector_amd.build`"
+    import hashlib
+    assert hashlib.sha256(out.read_text().encode()).hexdigest() == vbuild.recorded_hashes()["attn_bwd_dkdv64_body.inc"], "generator changed: `python -m visionselector_amd.build --rehash`"
 
 
 def test_body_register_budget_mfma_count_and_lds_size():

@@ -1,6 +1,8 @@
-"""The per-item body of attn_fwd64_kernel is GENERATED (tools/gen_attn_fwd64.py -> csrc/attn_fwd64_body.inc).  The committed file
-must be what the committed generator writes with its default options, and the generator's own consistency checks (counted LDS
-waits, register pipelines) must hold for the option sets the tools build."""
+"""The per-item body of attn_fwd64_kernel is GENERATED at build time (tools/gen_attn_fwd64.py -> csrc/attn_fwd64_body.inc, git-ignored;
+visionselector_amd/build.py).  History holds the generator and the sha256 of what it writes (csrc/generated_bodies.sha256): the
+generator must reproduce that hash, the in-tree body the library was built from must be the generator's output, and the generator's
+own consistency checks (counted LDS waits, register pipelines) must hold for the option sets the tools build."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -8,6 +10,10 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from visionselector_amd import build as vbuild  # noqa: E402
+
+vbuild.generate_bodies()                        # (what build() does first: the bodies are not in history)
 GEN = os.path.join(ROOT, "tools", "gen_attn_fwd64.py")
 INC = os.path.join(ROOT, "visionselector_amd", "csrc", "attn_fwd64_body.inc")
 HEADS_OPTS = "heads=1,xitem=1,epi=1,qearly=1"          # options of the committed csrc/attn_fwd_gqa64_body.inc
@@ -20,8 +26,21 @@ def _gen(tmp_path, opts=""):
     return out.read_text()
 
 
+def _sha(text):
+    return hashlib.sha256(text.encode()).hexdigest()
+
+
 def test_committed_body_is_the_generators_output(tmp_path):
-    assert _gen(tmp_path) == open(INC).read(), "run `python tools/gen_attn_fwd64.py` and commit csrc/attn_fwd64_body.inc"
+    text = _gen(tmp_path)
+    assert text == open(INC).read(), "stale csrc/attn_fwd64_body.inc: run `python -m visionselector_amd.build`"
+    assert _sha(text) == vbuild.recorded_hashes()["attn_fwd64_body.inc"], "generator changed: `python -m visionselector_amd.build --rehash`"
+
+
+def test_every_generated_body_has_its_recorded_hash():
+    want = vbuild.recorded_hashes()
+    assert sorted(want) == sorted(e[4] for e in vbuild.GENERATED)
+    for e in vbuild.GENERATED:
+        assert _sha(open(os.path.join(vbuild.CSRC, e[4])).read()) == want[e[4]], e[4]
 
 
 @pytest.mark.parametrize("opts", ["move_chunk=0", "pvsplit=1", "wgrp=0,srot=0", "dmak=top,dmav=top,pre=0", "trace=1",
@@ -50,7 +69,8 @@ def test_committed_parts_body_is_the_generators_output(tmp_path):
     env = dict(os.environ, F64_OUT=str(out), F64_OPTS="raw=1", F64_PREFIX="VSEL_FWD64P")
     subprocess.check_call([sys.executable, GEN], env=env, stdout=subprocess.DEVNULL)
     inc = os.path.join(ROOT, "visionselector_amd", "csrc", "attn_fwd64_parts_body.inc")
-    assert out.read_text() == open(inc).read(), "run F64_OPTS=raw=1 F64_PREFIX=VSEL_FWD64P F64_OUT=... python tools/gen_attn_fwd64.py"
+    assert out.read_text() == open(inc).read(), "stale csrc/attn_fwd64_parts_body.inc: run `python -m visionselector_amd.build`"
+    assert _sha(out.read_text()) == vbuild.recorded_hashes()["attn_fwd64_parts_body.inc"]
 
 
 def test_committed_heads_body_is_the_generators_output(tmp_path):

@@ -21,8 +21,78 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+# The hand-scheduled tile loops are GENERATED gfx950 inline-asm bodies (30.9 k lines for five kernels): they are produced here, at
+# build time, from the generators under tools/ -- history tracks the generators and csrc/generated_bodies.sha256 (tests/test_*_generated_cpu.py
+# hold the generators to those hashes), not the 31 k lines.  (generator, environment prefix, options, macro prefix, output)
+ROOT_DIR = os.path.dirname(PKG_DIR)
+GENERATED = (
+    ("gen_attn_fwd64.py", "F64", "", "", "attn_fwd64_body.inc"),
+    ("gen_attn_fwd64.py", "F64", "raw=1", "VSEL_FWD64P", "attn_fwd64_parts_body.inc"),
+    ("gen_attn_fwd64.py", "F64", "heads=1,xitem=1,epi=1,qearly=1", "VSEL_GQA64", "attn_fwd_gqa64_body.inc"),
+    ("gen_attn_bwd_dq64.py", "DQ64", "", "", "attn_bwd_dq64_body.inc"),
+    ("gen_attn_bwd_dkdv64.py", "DKDV64", "", "", "attn_bwd_dkdv64_body.inc"),
+)
+HASHES_PATH = os.path.join(CSRC, "generated_bodies.sha256")
+
+
+def generate_body(entry, out_path: str) -> str:
+    """Run one generator into out_path; returns the text."""
+    gen, env_prefix, opts, macro_prefix, _ = entry
+    env = dict(os.environ)
+    env[f"{env_prefix}_OUT"] = out_path
+    env[f"{env_prefix}_OPTS"] = opts
+    if macro_prefix:
+        env[f"{env_prefix}_PREFIX"] = macro_prefix
+    else:
+        env.pop(f"{env_prefix}_PREFIX", None)
+    subprocess.check_call([sys.executable, os.path.join(ROOT_DIR, "tools", gen)], env=env, stdout=subprocess.DEVNULL)
+    with open(out_path) as f:
+        return f.read()
+
+
+def recorded_hashes() -> dict:
+    with open(HASHES_PATH) as f:
+        return dict(reversed(ln.split()) for ln in f if ln.strip() and not ln.startswith("#"))
+
+
+def generate_bodies(verbose: bool = False) -> None:
+    """csrc/*_body.inc from the generators (rewritten only when the text changes, so object files stay fresh); every body must match
+    the hash history holds for it -- a generator edit is committed together with `python -m visionselector_amd.build --rehash`."""
+    import hashlib
+    import tempfile
+    want = recorded_hashes()
+    for entry in GENERATED:
+        dst = os.path.join(CSRC, entry[4])
+        with tempfile.TemporaryDirectory() as td:
+            text = generate_body(entry, os.path.join(td, "body.inc"))
+        got = hashlib.sha256(text.encode()).hexdigest()
+        if want.get(entry[4]) != got:
+            raise RuntimeError(f"{entry[4]}: tools/{entry[0]} writes sha256 {got}, csrc/generated_bodies.sha256 records {want.get(entry[4])}; "
+                               "if the generator was changed on purpose run `python -m visionselector_amd.build --rehash`")
+        old = open(dst).read() if os.path.exists(dst) else None
+        if old != text:
+            with open(dst, "w") as f:
+                f.write(text)
+            if verbose:
+                print(f"[vsel build] generated {entry[4]} ({text.count(chr(10))} lines)", flush=True)
+
+
+def rehash() -> None:
+    import hashlib
+    import tempfile
+    lines = ["# sha256 of the generated kernel bodies (visionselector_amd/build.py GENERATED): hash  file\n"]
+    for entry in GENERATED:
+        with tempfile.TemporaryDirectory() as td:
+            text = generate_body(entry, os.path.join(td, "body.inc"))
+        lines.append(f"{hashlib.sha256(text.encode()).hexdigest()}  {entry[4]}\n")
+    with open(HASHES_PATH, "w") as f:
+        f.writelines(lines)
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
+        return True
+    if any(not os.path.exists(os.path.join(CSRC, e[4])) for e in GENERATED):
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + \
@@ -85,6 +155,7 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
     """Compile every csrc/*.hip into libvsel.so.  hipcc cross-compiles gfx950 without a GPU."""
     if not force and not _stale():
         return LIB_PATH
+    generate_bodies(verbose)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     build_dir = os.path.join(PKG_DIR, "build")
@@ -128,4 +199,6 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
+    if "--rehash" in sys.argv:
+        rehash()
     print(build_native(force="--force" in sys.argv))

@@ -29,6 +29,10 @@ typedef enum {
   VSEL_ERR_BUSY = 5          /* more than 64 streams have launches of one attention kernel family in flight (a work-queue counter
                                 slot per stream): synchronise one of them and call again                                            */
 } vsel_status;
+/* Streams and graphs (attention entries whose work items are queued).  A queued launch uses the work-queue counter slot of ITS stream
+ * handle: pass explicit streams -- hipStreamPerThread (one handle value for a different stream in every host thread) is refused with
+ * VSEL_ERR_UNSUPPORTED.  A captured graph bakes in the slot of its capture stream: replay it on that stream (or at least never
+ * concurrently with itself or with eager launches of the same kernel family on the capture stream). */
 
 typedef enum {
   VSEL_BF16 = 0,             /* tokens / weights stored as bfloat16                              */

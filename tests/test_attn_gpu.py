@@ -551,9 +551,12 @@ def test_key_range_parts_forward_matches_oracle_and_unsplit_form(ops, lens, hq, 
         base = ops.varlen_attn(qc, kc, vc, cu_t, max(lens))
     with N.debug_knob(attn_key_parts=cap):
         N.profile_start()
-        got = ops.varlen_attn(qc, kc, vc, cu_t, max(lens))
+        got = ops.varlen_attn(qc, kc, vc, cu_t, max(lens), key_parts=True)
         prof = N.profile_stop()
-        again = ops.varlen_attn(qc, kc, vc, cu_t, max(lens))
+        again = ops.varlen_attn(qc, kc, vc, cu_t, max(lens), key_parts=True)
+        N.profile_start()
+        ops.varlen_attn(qc, kc, vc, cu_t, max(lens))            # the default never takes the parts form (opt-in: ADVICE r5)
+        assert "attn_fwd64_parts_kernel" not in N.profile_stop()
     assert "attn_fwd64_parts_kernel" in prof and "attn_fwd64_merge_kernel" in prof, prof
     assert torch.equal(got, again)
     assert float((got.float() - base.float()).abs().max()) <= 2 ** -7 * float(base.float().abs().max())

@@ -117,7 +117,8 @@ def extra_flags() -> list:
     """VSEL_HIPCC_FLAGS (e.g. -DVSEL_TRACE, -save-temps).  Optimisation-level and debug-info flags are refused: the attention
     kernels' asm-issued LDS reads rely on the -O3 register allocation (no spills, checked below)."""
     flags = os.environ.get("VSEL_HIPCC_FLAGS", "").split()
-    bad = [f for f in flags if f.startswith("-O") or f.startswith("-g") or f in ("-fno-inline", "-fno-unroll-loops")]
+    bad = [f for f in flags if f.startswith("-O") or f.startswith("-g") or f in ("-fno-inline", "-fno-unroll-loops") or
+           f.startswith("-DVSEL_EXPERIMENT") or "_KO_" in f]          # (knock-out experiments compute WRONG results: tools/build_variant.sh only)
     if bad:
         raise ValueError(f"VSEL_HIPCC_FLAGS: {bad} would change code generation of the hand-scheduled kernels; not accepted")
     return flags

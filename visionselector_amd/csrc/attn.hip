@@ -712,9 +712,9 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
     // items of the 8-wave form that hold work (ragged batches: from the token count when the entry point knows it -- the item LIST is
     // sized by the longest sequence, but a shorter sequence's items at the levels it does not reach are skipped in runs)
     const int64_t bq8 = 32 * (8 / rep_);
-    const int64_t items8 = (total > 0 ? std::min(cdiv(total, bq8) + n_seq, cdiv(max_seqlen_q, bq8) * n_seq) : cdiv(max_seqlen_q, bq8) * n_seq) * hkv;
+    const int64_t gqa_items8 = (total > 0 ? std::min(cdiv(total, bq8) + n_seq, cdiv(max_seqlen_q, bq8) * n_seq) : cdiv(max_seqlen_q, bq8) * n_seq) * hkv;
     const int64_t bq64 = 32 * (4 / ((rep_ + 1) / 2));
-    const int64_t items64 = (total > 0 ? std::min(cdiv(total, bq64) + n_seq, cdiv(max_seqlen_q, bq64) * n_seq) : cdiv(max_seqlen_q, bq64) * n_seq) * hkv;
+    const int64_t gqa_items64 = (total > 0 ? std::min(cdiv(total, bq64) + n_seq, cdiv(max_seqlen_q, bq64) * n_seq) : cdiv(max_seqlen_q, bq64) * n_seq) * hkv;
     // which form (-1: none).  The generated loop for groups of <= 4 heads (64-query items), for long-ish sequences (>= 1536 tokens: the tile
     // loop dominates) and for grids of one or two rounds of items; the 8-wave form from 1.6 rounds of its items when they are dealt
     // (uniform batches), from three rounds when they are drawn (ragged ones).
@@ -722,9 +722,9 @@ static int attn_launch(hipStream_t st, const void* q, const void* k, const void*
     int form = -1;
     if (g_gqa == 1) form = knob(VSEL_KNOB_ATTN_GQA_FORM) == 1 ? 1 : (knob(VSEL_KNOB_ATTN_GQA_FORM) == 0 ? 0 : (rep_ <= 4 ? 1 : 0));
     else if (g_gqa < 0 && max_seqlen_q < 2048 && !split2) {
-      if ((rep_ <= 4 || max_seqlen_q >= (uniform ? 1024 : 1536)) && items64 >= 128) form = 1;     // (dealt: 16 x 1100 182 vs 189 us, 32 x 1216 430 vs 448)
-      else if (items8 >= (uniform ? 400 : 768)) form = 0;       // (dealt: from 1.6 rounds of its items -- 6 x 524 25.5 us against 26.8 / 36.2)
-      else if (items64 >= 128 && 20 * items64 <= 36 * 256) form = 1;
+      if ((rep_ <= 4 || max_seqlen_q >= (uniform ? 1024 : 1536)) && gqa_items64 >= 128) form = 1;     // (dealt: 16 x 1100 182 vs 189 us, 32 x 1216 430 vs 448)
+      else if (gqa_items8 >= (uniform ? 400 : 768)) form = 0;       // (dealt: from 1.6 rounds of its items -- 6 x 524 25.5 us against 26.8 / 36.2)
+      else if (gqa_items64 >= 128 && 20 * gqa_items64 <= 36 * 256) form = 1;
       if (form >= 0 && knob(VSEL_KNOB_ATTN_GQA_FORM) >= 0) form = knob(VSEL_KNOB_ATTN_GQA_FORM);
     }
     if (form >= 0) {

@@ -20,6 +20,13 @@
 //     and the work queue is drawn TWO items ahead (the atomic's round trip is never waited for); one barrier per key tile and none
 //     between items.
 #include "attn_common.h"
+// Timing experiments (knock-outs with WRONG results, loader / priority variants) compile only with -DVSEL_EXPERIMENT, which
+// visionselector_amd/build.py refuses for the shipped library: one stray -DVSEL_GQA_KO_* can no longer ship an incorrect kernel.
+#if (defined(VSEL_GQA_KO_HALF) || defined(VSEL_GQA_KO_S) || defined(VSEL_GQA_KO_MAX) || defined(VSEL_GQA_KO_EXP) || defined(VSEL_GQA_KO_PROBS) || \
+     defined(VSEL_GQA_KO_PV) || defined(VSEL_GQA_KO_DMA) || defined(VSEL_GQA_KO_BAR) || defined(VSEL_GQA_KO_EPI) || defined(VSEL_GQA_LOADER) ||   \
+     defined(VSEL_GQA_PRIO)) && !defined(VSEL_EXPERIMENT)
+#error "VSEL_GQA_KO_* / VSEL_GQA_LOADER / VSEL_GQA_PRIO are timing experiments: add -DVSEL_EXPERIMENT (tools/build_variant.sh), never in the shipped library"
+#endif
 #include <atomic>
 
 #include <algorithm>
@@ -39,7 +46,7 @@ constexpr int kLds = kCtl + 16;
 }  // namespace gqa
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ int g_gqa_work_counter[64];           // 64 launch slots in rotation (one counter per launch)
+__device__ int g_gqa_work_counter[64 * 8];       // 64 launch slots, one counter each, 32 bytes apart (concurrent streams do not share a line's atomics)
 
 __device__ __forceinline__ bf16x8_t gq_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 // x ^ K as an asm statement: the compiler would hoist the (loop-invariant) variants out of the item loop and keep every one of them in a
@@ -631,8 +638,8 @@ int attn_fwd_gqa_launch(hipStream_t st, const void* q, const void* k, const void
     if (int rc = queue_slot_acquire(kSlotGqa, st, &slot)) return rc;
     int* counters = nullptr;
     VSEL_HIP_CHECK(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_gqa_work_counter)));
-    VSEL_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(counters + slot), 2 * grid, 1, st));     // (two rounds are dealt: items b and 2 G - 1 - b)
-    counter = counters + slot;
+    VSEL_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(counters + 8 * slot), 2 * grid, 1, st));     // (two rounds are dealt: items b and 2 G - 1 - b)
+    counter = counters + 8 * slot;
   }
   VSEL_LAUNCH(attn_fwd_gqa_kernel, dim3(grid), dim3(512), 0, st, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, cu_q,
                      (int)hq, (int)hkv, scale * 1.4426950408889634f, causal, (uint16_t*)out, (int)q_tiles, (int)n_seq, counter, pg, lse);

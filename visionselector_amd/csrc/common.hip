@@ -117,6 +117,10 @@ SlotTable g_slot_tables[16][kSlotFamilies];
 int queue_slot_acquire(int family, hipStream_t st, int* slot) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(VSEL_ERR_HIP, "hipGetDevice");
+  // hipStreamPerThread is ONE handle value for a different stream in every host thread: a slot keyed by it would be shared by launches
+  // that stream order does not serialise
+  if (st == hipStreamPerThread)
+    return fail(VSEL_ERR_UNSUPPORTED, "queued attention launches on hipStreamPerThread: pass an explicit stream (work-queue counters are per stream handle)");
   std::lock_guard<std::mutex> lock(g_slot_mu);
   SlotTable& t = g_slot_tables[dev][family];
   int free_slot = -1;

@@ -681,8 +681,11 @@ def topk_select_splice(scores, h, input_ids, inputs_embeds, visual_token_id: int
 # ------------------------------------------------------------------------------------------------
 
 def varlen_attn(q, k, v, cu_seqlens: torch.Tensor, max_seqlen: int, causal: bool = True,
-                softmax_scale: Optional[float] = None) -> torch.Tensor:
-    """q [T,Hq,d], k/v [T,Hkv,d] bf16, cu_seqlens int32 [S+1] on device -> out [T,Hq,d]."""
+                softmax_scale: Optional[float] = None, key_parts: bool = False) -> torch.Tensor:
+    """q [T,Hq,d], k/v [T,Hkv,d] bf16, cu_seqlens int32 [S+1] on device -> out [T,Hq,d].
+    key_parts=True: one long prompt (or a few of EQUAL length) on few heads may run as key-range parts through a workspace
+    (vsel_varlen_attn_fwd_ws) -- opt-in, because that form sums in another fp32 order than the others (a prompt's result would otherwise
+    depend on what it is packed with) and ignores cu_seqlens beyond their count: the equal-length layout is checked here."""
     dev = _dev(q, k, v, cu_seqlens)
     if q.dtype != torch.bfloat16 or k.dtype != torch.bfloat16 or v.dtype != torch.bfloat16:
         raise TypeError("varlen_attn takes bfloat16 q/k/v")
@@ -695,7 +698,9 @@ def varlen_attn(q, k, v, cu_seqlens: torch.Tensor, max_seqlen: int, causal: bool
     lib = N.lib()
     n_seq = cu_seqlens.numel() - 1
     # one long prompt (or a few of equal length): key-range parts through a workspace (vsel_varlen_attn_fwd_ws; 0 bytes = not such a batch)
-    ws_bytes = lib.vsel_varlen_attn_fwd_workspace_bytes(n_seq, int(max_seqlen), t, hq, hkv, d, int(causal))
+    ws_bytes = lib.vsel_varlen_attn_fwd_workspace_bytes(n_seq, int(max_seqlen), t, hq, hkv, d, int(causal)) if key_parts else 0
+    if ws_bytes and n_seq > 1 and not torch.equal(cu_seqlens, torch.arange(0, t + 1, int(max_seqlen), dtype=torch.int32, device=dev)):
+        ws_bytes = 0                                  # (total == n_seq * max_seqlen by coincidence: not an equal-length batch)
     if ws_bytes:
         ws = _workspace(ws_bytes, dev)
         N.check(lib.vsel_varlen_attn_fwd_ws(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), cu_seqlens.data_ptr(), n_seq, int(max_seqlen),

@@ -500,3 +500,27 @@ def test_fused_select_gather_is_bit_identical(ops):
             outs[limit] = a + ops.lis_select_varlen(h2, lens, ks, wq, bq, wk, bk)
     for x, y in zip(outs[0], outs[64]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("d,hd,n,k,b", [(2048, 1024, 576, 115, 56), (3584, 1792, 300, 150, 40), (4096, 2048, 729, 145, 33)])
+def test_flat_resident_gather_is_bit_identical(ops, d, hd, n, k, b):
+    """Uniform batches of >= 4096 kept rows gather through a flat list of kept rows dealt to resident waves (knob lis_gather = 10 x
+    workgroups per CU + rows in flight; round 6) instead of one workgroup per few rows of a segment: the same rows to the same places,
+    with and without the producer's row permutation (vsel_lis_select_permuted), whatever the depth."""
+    from visionselector_amd import _native
+    g = torch.Generator(device="cuda").manual_seed(d + n)
+    h = torch.randn(b, n, d, device="cuda", generator=g).bfloat16()
+    wq, wk = [(0.02 * torch.randn(hd, d, device="cuda", generator=g)).bfloat16() for _ in range(2)]
+    bq, bk = [(0.02 * torch.randn(hd, device="cuda", generator=g)).bfloat16() for _ in range(2)]
+    perm = torch.cat([torch.randperm(n, device="cuda", generator=g) + i * n for i in range(b)])       # logical -> physical, per image
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(b * n, device="cuda")
+    outs = {}
+    for form in (0, 82, 43, 24):
+        with _native.debug_knob(lis_gather=form, lis_fused_select=0):
+            outs[form] = ops.lis_select(h, wq, bq, wk, bk, k) + ops.lis_select_permuted(h, perm, inv, wq, bq, wk, bk, k)
+    out0, idx0 = outs[0][0], outs[0][1]
+    assert torch.equal(out0, torch.gather(h, 1, idx0[..., None].expand(-1, -1, d)))
+    for form in (82, 43, 24):
+        for x, y in zip(outs[0], outs[form]):
+            assert torch.equal(x, y), form

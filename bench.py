@@ -303,7 +303,7 @@ def main():
     # the kernel named "dominant" is only the longest of several few-us kernels -- said on the line so nobody reads a roofline into it.
     host_bound = bool(step_us_kernels < 0.6 * ms_per_step * 1e3)
     if dom is not None:
-        # from 32 images up libvsel cuts a call into two halves (lis.hip): each sweep / gather launch covers b / 2 images
+        # (with VSEL_PIPELINE=1 libvsel cuts a call of >= 32 images into two halves: a launch then covers b / launches_per_step images)
         b_launch = b / max(1.0, kern[dom]["launches_per_step"])
         kb = kern[dom]["algorithmic_bytes_per_launch"]
         avg_s = kern[dom]["avg_us"] * 1e-6

@@ -465,3 +465,21 @@ def test_bench_spawn_ranks_propagates_rank_exit_code(tmp_path, monkeypatch):
     assert bench.spawn_ranks(2, []) != 0
     script.write_text("import sys\nsys.exit(0)\n")
     assert bench.spawn_ranks(2, []) == 0
+
+
+def test_every_kernel_of_the_lis_step_has_a_byte_model_in_bench():
+    """bench.py builds `roofline` from the kernel the HIP-event clock names: every kernel name the LIS inference path can mark
+    (VSEL_AFTER_LAUNCH in csrc/lis_kernels.h / lis_small.h) must be priced by bench.kernel_bytes, or `roofline.frac` could be empty again
+    (round 5's driver run: frac = None under `pytest -x` hid 201 parity tests)."""
+    import re
+    import importlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    names = set()
+    for f in ("lis_kernels.h", "lis_small.h"):
+        names |= set(re.findall(r'VSEL_AFTER_LAUNCH\(\s*\w+\s*,\s*"(\w+)"\s*\)', open(os.path.join(root, "visionselector_amd", "csrc", f)).read()))
+    assert {"colsum_seg_kernel", "score_kernel", "gather_rows_kernel", "topk_select_kernel", "w_finish_kernel"} <= names
+    for nm in sorted(names):
+        kb = bench.kernel_bytes(nm, 8, 2304, 3584, 1792, 460)
+        assert kb is not None and kb > 0, f"bench.kernel_bytes has no model for {nm}"

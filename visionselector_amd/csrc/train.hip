@@ -659,8 +659,19 @@ __global__ __launch_bounds__(256) void outer_finish_pair_kernel(const float* __r
 //   dwq[r][c] = scale sum_i a_i[r] gx_i[c],  dwk[r][c] = scale sum_i dk_i[r] xsum_i[c]   (i in order; fp32)
 // grid (ceil(cols / 1024), row blocks, 2 = {dwq, dwk}); a block stages its <= 64 x R left factors through LDS.
 __global__ __launch_bounds__(256) void outer_sum_kernel(const float* __restrict__ payload, int R, int64_t row_stride, int hd, int d,
-                                                        float scale, float* __restrict__ dwq, float* __restrict__ dwk) {
+                                                        float scale, float* __restrict__ dwq, float* __restrict__ dwk,
+                                                        float* __restrict__ dbq, float* __restrict__ dbk) {
   const int which = blockIdx.z;
+  // the bias gradients ride along (they were a launch of their own): the column-tile-0 workgroups sum dbq (z = 0) / dbk (z = 1) of
+  // their rows over the payload rows in order -- bias_sum_kernel's arithmetic
+  if (blockIdx.x == 0 && dbq) {
+    for (int r = blockIdx.y + (int)gridDim.y * (int)threadIdx.x; r < hd; r += (int)gridDim.y * 256) {
+      const float* pb = payload + 2 * (hd + d) + (which ? hd : 0) + r;
+      float sb = 0.f;
+      for (int i = 0; i < R; ++i) sb += pb[(int64_t)i * row_stride];
+      (which ? dbk : dbq)[r] = sb * scale;
+    }
+  }
   const float* left = payload + (which ? hd + d : 0);              // a / dk   [hd]
   const float* right = payload + (which ? 2 * hd + d : hd);         // gx / xsum [d]
   float* out = which ? dwk : dwq;
@@ -684,21 +695,6 @@ __global__ __launch_bounds__(256) void outer_sum_kernel(const float* __restrict_
     }
     if (c_ok) *reinterpret_cast<f32x4*>(out + (int64_t)r * d + c4) = acc * scale;
   }
-}
-
-// dbq[h] = scale sum_i dbq_i[h], dbk likewise (i in order)
-__global__ __launch_bounds__(256) void bias_sum_kernel(const float* __restrict__ payload, int R, int64_t row_stride, int hd, int d,
-                                                       float scale, float* __restrict__ dbq, float* __restrict__ dbk) {
-  const int h = blockIdx.x * 256 + threadIdx.x;
-  if (h >= hd) return;
-  const float* p = payload + 2 * (hd + d) + h;
-  float s0 = 0.f, s1 = 0.f;
-  for (int i = 0; i < R; ++i) {
-    s0 += p[(int64_t)i * row_stride];
-    s1 += p[(int64_t)i * row_stride + hd];
-  }
-  dbq[h] = s0 * scale;
-  dbk[h] = s1 * scale;
 }
 
 // dh[i,:] = ps[i] d_hnew[i,:] + (g[i] rs) w[:] + u[:]      (first term dropped when dhn == NULL)
@@ -1007,11 +1003,8 @@ extern "C" int vsel_lis_factors_to_grads(void* stream, const float* payload, int
   VSEL_PROF_BEGIN(st);
   const int64_t row = 2 * (hd + d) + 2 * hd;
   const dim3 og((unsigned)cdiv(d, 1024), (unsigned)std::min<int64_t>(hd, 512), 2);
-  VSEL_LAUNCH(outer_sum_kernel, og, dim3(256), 0, st, payload, (int)n_rows, row, (int)hd, (int)d, scale, dwq, dwk);
+  VSEL_LAUNCH(outer_sum_kernel, og, dim3(256), 0, st, payload, (int)n_rows, row, (int)hd, (int)d, scale, dwq, dwk, dbq, dbk);
   VSEL_AFTER_LAUNCH(st, "outer_sum_kernel");
-  VSEL_LAUNCH(bias_sum_kernel, dim3((unsigned)cdiv(hd, 256)), dim3(256), 0, st, payload, (int)n_rows, row, (int)hd, (int)d,
-                     scale, dbq, dbk);
-  VSEL_AFTER_LAUNCH(st, "bias_sum_kernel");
   return VSEL_OK;
 }
 
